@@ -1,0 +1,313 @@
+"""MI355X-native iLQG hot path behind the call signatures of DifferentialDynamicProgramming.jl.
+
+Host-side mirror of the reference's interface for this path (same names, argument order and error
+behaviour), written in Python because no Julia toolchain exists in the build image; the Julia
+`@ccall` wrapper a maintainer would use lives in ``julia/DDPAmd.jl``.
+
+    back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u)   src/backward_pass.jl:162-252
+    boxQP(H,g,lower,upper,x0)                               src/boxQP.jl:29-188
+    forward_pass(traj_new,x0,u,x,α,problem,lims)            src/forward_pass.jl:9-33
+    iLQG(problem,x0,u0; lims, ...)                          src/iLQG.jl:143-341
+    GaussianPolicy                                          src/iLQG.jl:39-53
+
+All compute runs in libddp_amd.so (HIP, gfx950) through the C ABI of include/ddp_amd.h.  There is no
+CPU fallback: without the library or without a GPU every call raises ``DDPError``.
+
+Arrays follow the reference's shapes; an extra trailing axis is the batch of independent
+trajectories (``K[m,n,N,B]``), which the reference does not have.
+"""
+from __future__ import annotations
+
+import ctypes as _C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import DDPError, Handle, default_handle  # noqa: F401
+
+__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG",
+           "df", "Handle", "DDPError", "DEFAULT_ALPHA"]
+
+DEFAULT_ALPHA = 10.0 ** np.linspace(0, -3, 11)     # iLQG.jl:145
+
+
+@dataclass
+class GaussianPolicy:
+    """src/iLQG.jl:39-53.  ``K[m,n,T]`` (quirk Q19b: the docstring of the reference says n×m),
+    ``k[m,T]``, ``Σ`` = Quui (never written by back_pass in the reference — zeros here),
+    ``Σi`` = the unregularised Quu."""
+    T: int = 0
+    n: int = 0
+    m: int = 0
+    K: np.ndarray = field(default_factory=lambda: np.zeros((0, 0, 0)))
+    k: np.ndarray = field(default_factory=lambda: np.zeros((0, 0)))
+    Σ: np.ndarray = field(default_factory=lambda: np.zeros((0, 0, 0)))
+    Σi: np.ndarray = field(default_factory=lambda: np.zeros((0, 0, 0)))
+
+    def isempty(self):
+        return self.T == self.n == self.m == 0
+
+    def __len__(self):
+        return self.T
+
+
+# ------------------------------------------------------------------ registered problem families
+@dataclass
+class LQProblem:
+    """x⁺ = A x + B u, cost = ½Σ x∘(Qx) + ½Σ u∘(Ru) — the closures of src/demo_linear.jl:30-50.
+    A/B may be [n,n]/[n,m] (LTI), [..,N] (LTV) and, with ``dyn_batched``, carry a trailing batch axis."""
+    A: np.ndarray
+    B: np.ndarray
+    Q: np.ndarray
+    R: np.ndarray
+    dyn_batched: bool = False
+    kind = 0
+
+    @property
+    def n(self):
+        return self.A.shape[0]
+
+    @property
+    def m(self):
+        return self.B.shape[1]
+
+    @property
+    def dyn_tv(self):
+        return (self.A.ndim - (1 if self.dyn_batched else 0)) == 3
+
+
+@dataclass
+class PendcartProblem:
+    """src/system_pendcart.jl:42-59,83-106 (explicit Euler step, quadratic cost of length N+1)."""
+    g: float = 9.82
+    l: float = 0.35
+    h: float = 0.01
+    d: float = 0.99
+    Q: np.ndarray = field(default_factory=lambda: np.diag([10.0, 1.0, 2.0, 1.0]))
+    R: np.ndarray = field(default_factory=lambda: np.array([[1.0]]))
+    goal: np.ndarray = field(default_factory=lambda: np.array([np.pi, 0.0, 0.0, 0.0]))
+    kind = 1
+    n = 4
+    m = 1
+    dyn_tv = False
+    dyn_batched = False
+
+
+class _DevProblem:
+    """ddp_problem struct + the arrays it points at (host arrays for the host-pointer flavours)."""
+
+    def __init__(self, prob, N, B):
+        P = _lib.Problem()
+        P.kind, P.n, P.m, P.N, P.B = prob.kind, prob.n, prob.m, N, B
+        self.Q, self.R = _lib.f64(prob.Q), _lib.f64(np.atleast_2d(prob.R))
+        P.Q, P.R = _lib.ptr(self.Q), _lib.ptr(self.R)
+        if prob.kind == 0:
+            self.A, self.B = _lib.f64(prob.A), _lib.f64(prob.B)
+            P.A, P.Bm = _lib.ptr(self.A), _lib.ptr(self.B)
+            P.dyn_tv, P.dyn_batched = int(prob.dyn_tv), int(prob.dyn_batched)
+        else:
+            P.g, P.l, P.h, P.d = prob.g, prob.l, prob.h, prob.d
+            for i in range(4):
+                P.goal[i] = float(prob.goal[i])
+        self.struct = P
+        self.cost_len = N + 1 if prob.kind == 1 else N
+
+
+def _lims(lims):
+    if lims is None or np.size(lims) == 0:
+        return None
+    return _lib.f64(lims)
+
+
+# ---------------------------------------------------------------------------------- back_pass
+def back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u, *, fx_batched=None, cost_batched=None,
+              handle=None):
+    """Drop-in for ``back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u)`` (backward_pass.jl:217).
+
+    Dispatch on array rank like the reference (``fx`` 2-D → LTI :217, 3-D → LTV :162, ``cxx`` 3-D →
+    time-varying cost :179).  ``cx`` of rank 3 means a batch ``cx[n,N,B]``; then ``λ`` may be a vector
+    of length B and ``fx``/``cxx`` of rank 4 are per-trajectory.
+    Returns ``(diverge, GaussianPolicy, Vx, Vxx, dV)``; with a batch every output carries a trailing
+    batch axis and ``diverge`` is an int32 vector."""
+    h = handle or default_handle()
+    cx, cu, u = _lib.f64(cx), _lib.f64(cu), _lib.f64(u)
+    batched = cx.ndim == 3
+    n, N = cx.shape[0], cx.shape[1]
+    m = cu.shape[0]
+    B = cx.shape[2] if batched else 1
+    fx, fu, cxx, cxu, cuu = map(_lib.f64, (fx, fu, cxx, np.reshape(cxu, np.shape(cxu)), cuu))
+    if fx_batched is None:
+        fx_batched = fx.ndim == 4
+    if cost_batched is None:
+        cost_batched = cxx.ndim == 4
+    fx_tv = (fx.ndim - int(fx_batched)) == 3
+    cost_tv = (cxx.ndim - int(cost_batched)) == 3
+    # the reference's @asserts (backward_pass.jl:221-225 / :8-11 / :183-187)
+    assert cu.shape[:2] == (m, N), "size(cu) should be (m, N)"
+    assert fx.shape[:2] == (n, n) and fu.shape[:2] == (n, m), "size(fx), size(fu)"
+    assert cxx.shape[:2] == (n, n), "size(cxx) should be (n, n)"
+    assert cxu.shape[:2] == (n, m), "size(cxu) should be (n, m)"
+    assert cuu.reshape((m, m) + cuu.shape[2:] if cuu.ndim >= 2 else (m, m)).shape[:2] == (m, m), "size(cuu)"
+    cuu = cuu.reshape((m, m) + (cuu.shape[2:] if cuu.ndim >= 2 else ()))
+    L = _lims(lims)
+    d = _lib.BPDesc(n, m, N, B, int(fx_tv), int(fx_batched), int(cost_tv), int(cost_batched), int(regType),
+                    int(L is not None))
+    lam = np.ascontiguousarray(np.broadcast_to(np.asarray(λ, dtype=np.float64), (B,)))
+    K = np.zeros((m, n, N, B), order="F"); k = np.zeros((m, N, B), order="F")
+    Quu = np.zeros((m, m, N, B), order="F"); Vx = np.zeros((n, N, B), order="F")
+    Vxx = np.zeros((n, n, N, B), order="F"); dV = np.zeros((2, B), order="F")
+    div = np.zeros(B, dtype=np.int32)
+    _lib.check(_lib.lib().ddp_back_pass_f64(h.raw, _C.byref(d), *map(_lib.ptr, (cx, cu, cxx, cxu, cuu, fx, fu, lam, L, u,
+                                                                              K, k, Quu, Vx, Vxx, dV)),
+                                            div.ctypes.data_as(_lib.i32p)))
+    if not batched:
+        pol = GaussianPolicy(N, n, m, K[..., 0], k[..., 0], np.zeros((m, m, N)), Quu[..., 0])
+        return int(div[0]), pol, Vx[..., 0], Vxx[..., 0], dV[:, 0]
+    pol = GaussianPolicy(N, n, m, K, k, np.zeros((m, m, N, B)), Quu)
+    return div, pol, Vx, Vxx, dV
+
+
+# -------------------------------------------------------------------------------------- boxQP
+def boxQP(H, g, lower, upper, x0, *, maxIter=100, minGrad=1e-8, minRelImprove=1e-8, stepDec=0.6, minStep=1e-22,
+          Armijo=0.1, handle=None):
+    """Drop-in for ``boxQP(H,g,lower,upper,x0; ...)`` (boxQP.jl:29-36): returns ``(x, result, Hfree, free)``.
+    ``H`` of rank 3 / vectors of rank 2 solve a batch (trailing axis)."""
+    h = handle or default_handle()
+    H, g, lower, upper, x0 = map(_lib.f64, (H, g, lower, upper, x0))
+    batched = H.ndim == 3
+    m = H.shape[0]
+    cnt = H.shape[2] if batched else 1
+    x = np.zeros((m, cnt), order="F"); Hf = np.zeros((m, m, cnt), order="F")
+    res = np.zeros(cnt, dtype=np.int32); fr = np.zeros((m, cnt), dtype=np.uint8, order="F")
+    o = _lib.QPOpts(maxIter, minGrad, minRelImprove, stepDec, minStep, Armijo)
+    _lib.check(_lib.lib().ddp_boxqp_f64(h.raw, m, cnt, *map(_lib.ptr, (H, g, lower, upper, x0)), _C.byref(o),
+                                        _lib.ptr(x), res.ctypes.data_as(_lib.i32p), _lib.ptr(Hf),
+                                        fr.ctypes.data_as(_lib.u8p)))
+    if not batched:
+        free = fr[:, 0].astype(bool)
+        nf = int(free.sum())
+        return x[:, 0], int(res[0]), Hf[:nf, :nf, 0], free
+    return x, res, Hf, fr.astype(bool)
+
+
+# ------------------------------------------------------------------------------- forward_pass
+def forward_pass(traj_new, x0, u, x, α, problem, lims, *, handle=None):
+    """Drop-in for ``forward_pass(traj_new,x0,u,x,α,f,costfun,lims,diff)`` (forward_pass.jl:9) with a
+    registered ``problem`` standing in for the closures ``f``/``costfun`` (``diff`` is ``-``).
+    ``traj_new`` may be an empty ``GaussianPolicy`` (then ``x`` is ignored, iLQG.jl:185).
+    A vector ``α`` rolls all step sizes out concurrently (outputs get a trailing α axis).
+    Returns ``(xnew, unew, cnew)``."""
+    h = handle or default_handle()
+    u, x0 = _lib.f64(u), _lib.f64(x0)
+    batched = u.ndim == 3
+    m, N = u.shape[:2]
+    n = x0.shape[0]
+    B = u.shape[2] if batched else 1
+    dp = _DevProblem(problem, N, B)
+    alphas = np.atleast_1d(np.asarray(α, dtype=np.float64))
+    na = len(alphas)
+    empty = traj_new is None or traj_new.isempty()
+    K = None if empty else _lib.f64(traj_new.K)
+    k = None if empty else _lib.f64(traj_new.k)
+    xx = None if empty else _lib.f64(x)
+    L = _lims(lims)
+    CL = dp.cost_len
+    xnew = np.zeros((n, N, B, na), order="F"); unew = np.zeros((m, N, B, na), order="F")
+    cnew = np.zeros((CL, B, na), order="F"); csum = np.zeros((B, na), order="F")
+    _lib.check(_lib.lib().ddp_forward_pass_f64(h.raw, _C.byref(dp.struct), _lib.ptr(K), _lib.ptr(k), _lib.ptr(x0),
+                                               _lib.ptr(u), _lib.ptr(xx), _lib.ptr(alphas), na, _lib.ptr(L),
+                                               _lib.ptr(xnew), _lib.ptr(unew), _lib.ptr(cnew), _lib.ptr(csum)))
+    if not batched:
+        xnew, unew, cnew = xnew[:, :, 0], unew[:, :, 0], cnew[:, 0]
+    if np.ndim(α) == 0:
+        xnew, unew, cnew = xnew[..., 0], unew[..., 0], cnew[..., 0]
+    return xnew, unew, cnew
+
+
+# ------------------------------------------------------------------------------------------ df
+def df(problem, x, u, *, handle=None):
+    """The ``df`` closure of the registered families (STEP 1, iLQG.jl:225-229).  Returns
+    ``(fx,fu,fxx,fxu,fuu,cx,cu,cxx,cxu,cuu)`` like the reference (second-order terms are ``[]``)."""
+    h = handle or default_handle()
+    x, u = _lib.f64(x), _lib.f64(u)
+    batched = u.ndim == 3
+    m, N = u.shape[:2]
+    n = x.shape[0]
+    B = u.shape[2] if batched else 1
+    dp = _DevProblem(problem, N, B)
+    cx = np.zeros((n, N, B), order="F"); cu = np.zeros((m, N, B), order="F")
+    pend = problem.kind == 1
+    fx = np.zeros((n, n, N, B), order="F") if pend else None
+    fu = np.zeros((n, m, N, B), order="F") if pend else None
+    _lib.check(_lib.lib().ddp_df_f64(h.raw, _C.byref(dp.struct), _lib.ptr(x), _lib.ptr(u), _lib.ptr(cx), _lib.ptr(cu),
+                                     _lib.ptr(fx), _lib.ptr(fu)))
+    if not pend:
+        fx, fu = dp.A, dp.B
+    elif not batched:
+        fx, fu = fx[..., 0], fu[..., 0]
+    if not batched:
+        cx, cu = cx[..., 0], cu[..., 0]
+    e = np.zeros((0,))
+    return fx, fu, e, e, e, cx, cu, dp.Q, np.zeros((n, m)), dp.R
+
+
+# ---------------------------------------------------------------------------------------- iLQG
+STATUS = {1: "SUCCESS: gradient norm < tol_grad", 2: "SUCCESS: cost change < tol_fun", 3: "EXIT: λ > λmax",
+          4: "EXIT: Maximum iterations reached", -1: "EXIT: Initial control sequence caused divergence"}
+
+
+def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0,
+         λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0, verbosity=0, trace_cap=None, handle=None):
+    """Drop-in for ``iLQG(f,costfun,df,x0,u0; lims, α, tol_fun, ...)`` (iLQG.jl:143-163) with a registered
+    ``problem`` standing in for the three closures.  ``u0[m,N,B]`` / ``x0[n,B]`` solve a batch of
+    independent problems, each with its own λ schedule, line search and termination.
+    Returns ``(x, u, traj_new, Vx, Vxx, cost, trace)``; ``trace`` is a dict with the reference's trace
+    keys that survive batching (``:cost`` per iteration) plus the per-trajectory summary ``stats``.
+    Returns ``None`` when the initial control sequence diverges (iLQG.jl:205-210) in the unbatched case."""
+    h = handle or default_handle()
+    u0, x0 = _lib.f64(u0), _lib.f64(x0)
+    batched = u0.ndim == 3
+    m, N = u0.shape[:2]
+    n = x0.shape[0]
+    B = u0.shape[2] if batched else 1
+    if x0.ndim > 1 and x0.shape[1] == N and not batched:
+        raise NotImplementedError("pre-rolled initial trajectories (size(x0,2) == N) are not offloaded")
+    dp = _DevProblem(problem, N, B)
+    o = _lib.ILQGOpts()
+    _lib.lib().ddp_ilqg_default_opts(_C.byref(o))
+    o.lambda_, o.dlambda, o.lambda_factor, o.lambda_max, o.lambda_min = λ, dλ, λfactor, λmax, λmin
+    o.tol_fun, o.tol_grad, o.max_iter, o.regType, o.reduce_ratio_min = tol_fun, tol_grad, max_iter, regType, reduce_ratio_min
+    alphas = np.asarray(α, dtype=np.float64)
+    if len(alphas) > 16:
+        raise ValueError("at most 16 line-search step sizes are supported")
+    o.n_alpha = len(alphas)
+    for i, a in enumerate(alphas):
+        o.alpha[i] = a
+    L = _lims(lims)
+    CL = dp.cost_len
+    x = np.zeros((n, N, B), order="F"); u = np.zeros((m, N, B), order="F")
+    K = np.zeros((m, n, N, B), order="F"); k = np.zeros((m, N, B), order="F"); Quu = np.zeros((m, m, N, B), order="F")
+    Vx = np.zeros((n, N, B), order="F"); Vxx = np.zeros((n, n, N, B), order="F"); cost = np.zeros((CL, B), order="F")
+    stats = np.zeros((8, B), order="F")
+    cap = trace_cap if trace_cap is not None else 4 * max_iter + 64
+    cap = min(cap, 4096)
+    tr = np.zeros((cap, B), order="F")
+    git = _C.c_int(0)
+    _lib.check(_lib.lib().ddp_ilqg_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), _lib.ptr(u0), _lib.ptr(L),
+                                       *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr),
+                                       _C.byref(git)))
+    trace = dict(stats=stats, status=stats[0].astype(int), iter=stats[1].astype(int), λ=stats[5], grad_norm=stats[6],
+                 cost=tr, global_iters=git.value)
+    if verbosity > 0:
+        for b in range(min(B, 8)):
+            print("[%d] %s after %d iterations, cost %.6g" % (b, STATUS.get(int(stats[0, b]), "?"), int(stats[1, b]), stats[7, b]))
+    if not batched:
+        if int(stats[0, 0]) == -1:
+            return None
+        it = int(stats[1, 0])
+        trace["cost"] = tr[: max(it - 1, 0), 0]
+        pol = GaussianPolicy(N, n, m, K[..., 0], k[..., 0], np.zeros((m, m, N)), Quu[..., 0])
+        return x[..., 0], u[..., 0], pol, Vx[..., 0], Vxx[..., 0], cost[:, 0], trace
+    pol = GaussianPolicy(N, n, m, K, k, np.zeros((m, m, N, B)), Quu)
+    return x, u, pol, Vx, Vxx, cost, trace

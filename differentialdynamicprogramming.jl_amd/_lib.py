@@ -1,0 +1,149 @@
+"""ctypes loader of libddp_amd.so (the C ABI of include/ddp_amd.h).
+
+There is NO fallback: if the shared library is missing, or no HIP device is present when a handle is
+requested, this raises.  Nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddp_amd.so")
+
+dp = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+EXPORTS = [
+    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_destroy", "ddp_sync", "ddp_stream",
+    "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_memset",
+    "ddp_event_create", "ddp_event_destroy", "ddp_event_record", "ddp_event_elapsed_ms",
+    "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
+    "ddp_cost_len", "ddp_forward_pass_f64_dev", "ddp_forward_pass_f64", "ddp_df_f64_dev", "ddp_df_f64",
+    "ddp_ilqg_default_opts", "ddp_ilqg_f64", "ddp_ilqg_f64_dev",
+]
+
+
+class BPDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n", "m", "N", "B", "fx_tv", "fx_batched", "cost_tv", "cost_batched",
+                                       "regType", "has_lims")]
+
+
+class QPOpts(C.Structure):
+    _fields_ = [("maxIter", C.c_int), ("minGrad", C.c_double), ("minRelImprove", C.c_double),
+                ("stepDec", C.c_double), ("minStep", C.c_double), ("Armijo", C.c_double)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("B", C.c_int),
+                ("A", vp), ("Bm", vp), ("dyn_tv", C.c_int), ("dyn_batched", C.c_int), ("Q", vp), ("R", vp),
+                ("g", C.c_double), ("l", C.c_double), ("h", C.c_double), ("d", C.c_double),
+                ("goal", C.c_double * 4)]
+
+
+class ILQGOpts(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("dlambda", C.c_double), ("lambda_factor", C.c_double),
+                ("lambda_max", C.c_double), ("lambda_min", C.c_double), ("tol_fun", C.c_double),
+                ("tol_grad", C.c_double), ("max_iter", C.c_int), ("regType", C.c_int),
+                ("reduce_ratio_min", C.c_double), ("n_alpha", C.c_int), ("alpha", C.c_double * 16)]
+
+
+_lib = None
+
+
+class DDPError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DDPError("libddp_amd.so not built (%s): run `python __graft_entry__.py` or "
+                           "`python differentialdynamicprogramming.jl_amd/build.py`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ddp_last_error.restype = C.c_char_p
+        L.ddp_version.restype = C.c_char_p
+        L.ddp_stream.restype = vp
+        L.ddp_stream.argtypes = [vp]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if name not in ("ddp_last_error", "ddp_version", "ddp_stream"):
+                fn.restype = C.c_int
+        L.ddp_ilqg_default_opts.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DDPError("libddp_amd: %s (rc=%d)" % (lib().ddp_last_error().decode(), rc))
+
+
+class Handle:
+    """One HIP stream + scratch on one device (ddp_create / ddp_destroy)."""
+
+    def __init__(self, device=0):
+        self._h = vp()
+        check(lib().ddp_create(int(device), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().ddp_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def raw(self):
+        return self._h
+
+    def sync(self):
+        check(lib().ddp_sync(self._h))
+
+    # --- device buffers for callers without their own allocator
+    def malloc(self, nbytes):
+        p = vp()
+        check(lib().ddp_malloc(self._h, C.c_size_t(nbytes), C.byref(p)))
+        return p
+
+    def free(self, p):
+        check(lib().ddp_free(self._h, p))
+
+    def to_device(self, arr):
+        arr = np.asfortranarray(arr)
+        p = self.malloc(arr.nbytes)
+        check(lib().ddp_memcpy_h2d(self._h, p, arr.ctypes.data_as(vp), C.c_size_t(arr.nbytes)))
+        return p
+
+    def to_host(self, p, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype, order="F")
+        check(lib().ddp_memcpy_d2h(self._h, out.ctypes.data_as(vp), p, C.c_size_t(out.nbytes)))
+        return out
+
+
+_default = {}
+
+
+def default_handle(device=0):
+    if device not in _default:
+        _default[device] = Handle(device)
+    return _default[device]
+
+
+def f64(a):
+    """Fortran-ordered contiguous float64 view/copy (Julia memory layout)."""
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(vp)

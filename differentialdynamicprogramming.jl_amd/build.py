@@ -1,0 +1,57 @@
+"""Builds libddp_amd.so (HIP, gfx950) in-tree:  python build.py [--force]
+
+One hipcc invocation per translation unit (run in parallel), then a link step.  hipcc
+cross-compiles for gfx950 without a GPU, so this also runs in the CPU-only build container.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libddp_amd.so")
+SOURCES = ["capi.hip", "back_pass.hip", "forward_pass.hip", "df.hip", "ilqg.hip"]
+HEADERS = ["ddp_internal.h", "boxqp_dev.h", os.path.join("..", "..", "include", "ddp_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-but-set-variable", "-Wno-unused-variable"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    if _stale(obj, deps):
+        cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        return src, True
+    return src, False
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(_compile, srcs))
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
+    if any(changed for _, changed in results) or _stale(LIB, objs):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    if verbose:
+        print("libddp_amd.so:", ", ".join("%s%s" % (s, "*" if c else "") for s, c in results))
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

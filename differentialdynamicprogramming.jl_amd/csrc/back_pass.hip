@@ -1,0 +1,512 @@
+// back_pass.hip — batched iLQG backward pass for gfx950 (MI355X).
+//
+// Replaces  back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u)  of the reference:
+//   src/backward_pass.jl:217-252  (LTI dynamics, time-invariant cost)       FXTV=0 CTV=0
+//   src/backward_pass.jl:162-177  (LTV dynamics, time-invariant cost)       FXTV=1 CTV=0
+//   src/backward_pass.jl:179-215  (LTV dynamics, time-varying cost)         FXTV=1 CTV=1
+//   shared tail @end_backward_pass src/backward_pass.jl:28-79 (Cholesky or boxQP, gains, value update)
+//
+// Mapping: ONE 64-lane wavefront per trajectory (work-group = 1 wave, so the four per-step
+// hand-offs below are wave-level, not CU-level barriers).  The time loop is a strict dependency
+// chain (Vxx_{i+1} -> Vxx_i); Vxx/Vx, the stacked Jacobian F=[fx fu] and the step's small
+// intermediates live in LDS, the Qxx entries stay in registers between the expansion and the
+// value update.  Per step:
+//   P1  W = Vxx·F                (n·(n+m) dot products of length n, lanes over elements)
+//       q = [cx;cu] + F'Vx        (Qx;Qu)
+//   P2  upper triangle of Qxx = cxx + fx'W_x  (kept in registers), Qux/Quu (+ regularised
+//       variants) = rows n..n+m of F'W  (+ λ·F_u'F for regType 2)
+//   P3  every lane: Cholesky of QuuF (or boxQP, all lanes redundantly => wave-uniform control
+//       flow); lane c<n solves column c of K, lane n solves k and accumulates dV
+//   P4  Vxx_i = sym(Qxx + K'T + Qux'K), T = Quu·K + Qux;  Vx_i;  stores of K,k,Vx,Vxx,Quu
+// Global traffic per step: reads cx_i,cu_i (+u_i with limits, + fx_i,fu_i / cxx_i,cxu_i,cuu_i when
+// time-varying), writes K_i,k_i,Vx_i,Vxx_i,Quu_i — the algorithmic bytes of SURVEY.md §8(d).
+// cx/cu/u are prefetched in chunks of TC time steps, time-varying operands one step ahead.
+#include "ddp_internal.h"
+#include "boxqp_dev.h"
+
+namespace {
+
+struct BPArgs {
+    int n, m, N, B;
+    int fx_batched, cost_batched, regType;
+    const double *cx, *cu, *cxx, *cxu, *cuu, *fx, *fu, *lambda, *lims, *u;
+    const int32_t *active;
+    double *K, *k, *Quu, *Vx, *Vxx, *dV;
+    int32_t *diverge;
+};
+
+constexpr int TC = 8;   // time steps per cx/cu/u prefetch chunk
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// LDS carve-up (doubles).  Identical on host (size computation) and device.
+struct BPLds {
+    int Fs, Vs, vs, Ws, Qs, cxxs, cxus, cuus, Quxs, Quxrs, Quus, QuuFs, Ks, ks, Ts, Quuks, cbuf, total;
+    __host__ __device__ BPLds(int n, int m, bool lims)
+    {
+        const int p = n + m;
+        int o = 0;
+        Fs = o; o += n * p;
+        Vs = o; o += n * n;
+        vs = o; o += n;
+        Ws = o; o += n * p;
+        Qs = o; o += p;
+        cxxs = o; o += n * n;
+        cxus = o; o += n * m;
+        cuus = o; o += m * m;
+        Quxs = o; o += m * n;
+        Quxrs = o; o += m * n;
+        Quus = o; o += m * m;
+        QuuFs = o; o += m * m;
+        Ks = o; o += m * n;
+        ks = o; o += m;
+        Ts = o; o += m * n;
+        Quuks = o; o += m;
+        o = (o + 1) & ~1;
+        cbuf = o; o += 2 * TC * (n + m + (lims ? m : 0));   // double-buffered cx|cu|u chunks
+        total = (o + 1) & ~1;
+    }
+};
+
+template <int NS, int MS, bool FXTV, bool CTV, bool LIMS>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (a.active && a.active[b] == 0) return;
+    const int n = NS ? NS : a.n, m = MS ? MS : a.m, N = a.N, p = n + m;
+    constexpr int NMAX = NS ? NS : DDP_MAX_N_GENERIC;
+    constexpr int MM = MS ? MS : DDP_MAX_M;
+    constexpr int PMAX = NMAX + MM;
+    constexpr int R1 = cdiv(NMAX * PMAX, DDP_WAVE);                 // W elements per lane
+    constexpr int RT = cdiv(NMAX * (NMAX + 1) / 2, DDP_WAVE);       // Qxx upper-triangle elements per lane
+    constexpr int RU = cdiv(MM * PMAX, DDP_WAVE);                   // u-row elements per lane
+    constexpr int RN = cdiv(NMAX * NMAX, DDP_WAVE);
+    constexpr int RC = cdiv(TC * (NMAX + 2 * MM), DDP_WAVE);        // chunk elements per lane
+
+    extern __shared__ double lds[];
+    const BPLds L(n, m, LIMS);
+    double *Fs = lds + L.Fs, *Vs = lds + L.Vs, *vs = lds + L.vs, *Ws = lds + L.Ws, *Qs = lds + L.Qs,
+           *cxxs = lds + L.cxxs, *cxus = lds + L.cxus, *cuus = lds + L.cuus, *Quxs = lds + L.Quxs,
+           *Quxrs = lds + L.Quxrs, *Quus = lds + L.Quus, *QuuFs = lds + L.QuuFs, *Ks = lds + L.Ks,
+           *ks = lds + L.ks, *Ts = lds + L.Ts, *Quuks = lds + L.Quuks, *cbuf = lds + L.cbuf;
+
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    const double *cx = a.cx + (size_t)n * N * b, *cu = a.cu + (size_t)m * N * b;
+    const double *ug = LIMS ? a.u + (size_t)m * N * b : nullptr;
+    const double *fx = a.fx + (a.fx_batched ? nn * (FXTV ? N : 1) * b : 0);
+    const double *fu = a.fu + (a.fx_batched ? nm * (FXTV ? N : 1) * b : 0);
+    const double *cxx = a.cxx + (a.cost_batched ? nn * (CTV ? N : 1) * b : 0);
+    const double *cxu = a.cxu + (a.cost_batched ? nm * (CTV ? N : 1) * b : 0);
+    const double *cuu = a.cuu + (a.cost_batched ? mm * (CTV ? N : 1) * b : 0);
+    double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b, *Quug = a.Quu + mm * N * b,
+           *Vxg = a.Vx + (size_t)n * N * b, *Vxxg = a.Vxx + nn * N * b;
+    const double lam = a.lambda[b];
+    const int regType = a.regType;
+    bool nolims = true;
+    double limlo[MM], limhi[MM];
+    if (LIMS) {
+        nolims = a.lims[0] > a.lims[m];                             // backward_pass.jl:31
+#pragma unroll
+        for (int q = 0; q < MM; ++q) {
+            limlo[q] = (q < m) ? a.lims[q] : 0.0;
+            limhi[q] = (q < m) ? a.lims[q + m] : 0.0;
+        }
+    }
+    const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};       // boxQP.jl:30-35
+
+    // ---- per-lane element assignments (loop invariant)
+    int w_v[R1], w_f[R1];                 // P1: LDS offsets of the V column and F column of W element
+    for (int r = 0; r < R1; ++r) {
+        const int e = lane + DDP_WAVE * r;
+        w_v[r] = (e % n) * n;
+        w_f[r] = (e / n) * n;
+    }
+    int t_i[RT], t_j[RT];                 // P2/P4: (i <= j) of the Qxx / Vxx upper-triangle element
+    const int ntri = n * (n + 1) / 2;
+    for (int r = 0; r < RT; ++r) {
+        const int e = lane + DDP_WAVE * r;
+        int j = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (j * (j + 1) / 2 > e) --j;
+        while ((j + 1) * (j + 2) / 2 <= e) ++j;
+        t_j[r] = j;
+        t_i[r] = e - j * (j + 1) / 2;
+    }
+    const int chunk_len = n + m + (LIMS ? m : 0);     // doubles per time step in a chunk
+
+    // chunk loader: chunk c holds time steps [c*TC, c*TC+TC) of cx | cu | u, time-major per stream
+    auto chunk_elem = [&](int c, int e) -> double {   // e in [0, TC*chunk_len)
+        const int t0 = c * TC;
+        if (e < TC * n) {
+            const int t = t0 + e / n;
+            return t < N ? cx[(size_t)t0 * n + e] : 0.0;
+        }
+        e -= TC * n;
+        if (e < TC * m) {
+            const int t = t0 + e / m;
+            return t < N ? cu[(size_t)t0 * m + e] : 0.0;
+        }
+        e -= TC * m;
+        const int t = t0 + e / m;
+        return (LIMS && t < N) ? ug[(size_t)t0 * m + e] : 0.0;
+    };
+
+    // ---- terminal step (backward_pass.jl:234-236 / :197-199) and loop-invariant operands
+    for (int e = lane; e < n * n; e += DDP_WAVE) {
+        const double v = cxx[(CTV ? nn * (N - 1) : 0) + e];
+        Vs[e] = v;
+        Vxxg[nn * (N - 1) + e] = v;
+        if (!CTV) cxxs[e] = v;
+    }
+    for (int e = lane; e < n; e += DDP_WAVE) {
+        const double v = cx[(size_t)n * (N - 1) + e];
+        vs[e] = v;
+        Vxg[(size_t)n * (N - 1) + e] = v;
+    }
+    for (int e = lane; e < m * m; e += DDP_WAVE) {
+        const double v = cuu[(CTV ? mm * (N - 1) : 0) + e];
+        Quug[mm * (N - 1) + e] = v;
+        if (!CTV) cuus[e] = v;
+    }
+    for (int e = lane; e < m * n; e += DDP_WAVE) {
+        Kg[nm * (N - 1) + e] = 0.0;
+        if (!CTV) cxus[e] = cxu[e];
+    }
+    for (int e = lane; e < m; e += DDP_WAVE) { kg[(size_t)m * (N - 1) + e] = 0.0; ks[e] = 0.0; }
+    if (!FXTV) {
+        for (int e = lane; e < n * n; e += DDP_WAVE) Fs[e] = fx[e];
+        for (int e = lane; e < n * m; e += DDP_WAVE) Fs[n * n + e] = fu[e];
+    }
+    double dV0 = 0.0, dV1 = 0.0;
+    if (N < 2) {
+        if (lane == 0) { a.dV[2 * b] = 0.0; a.dV[2 * b + 1] = 0.0; a.diverge[b] = 0; }
+        return;
+    }
+    // first step's operands straight to LDS, next chunk / next step into registers
+    double pfc[RC];
+    {
+        const int c0 = (N - 2) / TC;
+        for (int e = lane; e < TC * chunk_len; e += DDP_WAVE) cbuf[(c0 & 1) * TC * chunk_len + e] = chunk_elem(c0, e);
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const int e = lane + DDP_WAVE * r;
+            pfc[r] = (c0 > 0 && e < TC * chunk_len) ? chunk_elem(c0 - 1, e) : 0.0;
+        }
+    }
+    double pfF[FXTV ? R1 : 1], pfxx[CTV ? RN : 1], pfxu[CTV ? RU : 1], pfuu[CTV ? 1 : 1];
+    if (FXTV) {
+        const int i0 = N - 2;
+        for (int e = lane; e < n * n; e += DDP_WAVE) Fs[e] = fx[nn * i0 + e];
+        for (int e = lane; e < n * m; e += DDP_WAVE) Fs[n * n + e] = fu[nm * i0 + e];
+    }
+    if (CTV) {
+        const int i0 = N - 2;
+        for (int e = lane; e < n * n; e += DDP_WAVE) cxxs[e] = cxx[nn * i0 + e];
+        for (int e = lane; e < n * m; e += DDP_WAVE) cxus[e] = cxu[nm * i0 + e];
+        for (int e = lane; e < m * m; e += DDP_WAVE) cuus[e] = cuu[mm * i0 + e];
+    }
+    __syncthreads();
+
+    int diverge = 0;
+    for (int i = N - 2; i >= 0; --i) {
+        const int cc = i / TC;
+        const double *cb = cbuf + (cc & 1) * TC * chunk_len;
+        const double *cxi = cb + (i - cc * TC) * n;
+        const double *cui = cb + TC * n + (i - cc * TC) * m;
+        const double *ui = cb + TC * (n + m) + (i - cc * TC) * m;
+
+        // ---- issue next step's time-varying operands (land while this step computes)
+        if (FXTV && i > 0) {
+#pragma unroll
+            for (int r = 0; r < R1; ++r) {
+                const int e = lane + DDP_WAVE * r;
+                if (e < n * p) pfF[r] = (e < n * n) ? fx[nn * (i - 1) + e] : fu[nm * (i - 1) + (e - n * n)];
+            }
+        }
+        if (CTV && i > 0) {
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                const int e = lane + DDP_WAVE * r;
+                if (e < n * n) pfxx[r] = cxx[nn * (i - 1) + e];
+            }
+#pragma unroll
+            for (int r = 0; r < RU; ++r) {
+                const int e = lane + DDP_WAVE * r;
+                if (e < n * m) pfxu[r] = cxu[nm * (i - 1) + e];
+            }
+            if (lane < m * m) pfuu[0] = cuu[mm * (i - 1) + lane];
+        }
+
+        // ================= P1: W = Vxx·F,  Qs = [cx;cu] + F'Vx ==================================
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+            const int e = lane + DDP_WAVE * r;
+            if (e < n * p) {
+                const double *vc = Vs + w_v[r], *fc = Fs + w_f[r];
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < NMAX; ++l)
+                    if (l < n) s += vc[l] * fc[l];
+                Ws[e] = s;
+            }
+        }
+        {
+            const int e = DDP_WAVE - 1 - lane;        // high lanes: idle in the last W round
+            for (int j = e; j < p; j += DDP_WAVE) {
+                const double *fc = Fs + j * n;
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < NMAX; ++l)
+                    if (l < n) s += fc[l] * vs[l];
+                Qs[j] = (j < n ? cxi[j] : cui[j - n]) + s;       // backward_pass.jl:240-241
+            }
+        }
+        __syncthreads();
+
+        // ================= P2: Qxx (registers), Qux, Quu and regularised variants ================
+        double qxx[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int e = lane + DDP_WAVE * r;
+            qxx[r] = 0.0;
+            if (e < ntri) {
+                const double *fc = Fs + t_i[r] * n, *wc = Ws + t_j[r] * n;
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < NMAX; ++l)
+                    if (l < n) s += fc[l] * wc[l];
+                qxx[r] = cxxs[t_i[r] + n * t_j[r]] + s;          // backward_pass.jl:244
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RU; ++r) {
+            const int e = (DDP_WAVE - 1 - lane) + DDP_WAVE * r;
+            if (e < m * p) {
+                const int q = e % m, j = e / m;
+                const double *fc = Fs + (n + q) * n, *wc = Ws + j * n, *fj = Fs + j * n;
+                double s = 0.0, sr = 0.0;
+#pragma unroll
+                for (int l = 0; l < NMAX; ++l)
+                    if (l < n) { s += fc[l] * wc[l]; sr += fc[l] * fj[l]; }
+                if (j < n) {                                     // Qux, Qux_reg  (:242,246)
+                    const double c = cxus[j + n * q];
+                    Quxs[q + m * j] = c + s;
+                    Quxrs[q + m * j] = c + (regType == 2 ? s + lam * sr : s);
+                } else {                                         // Quu, QuuF     (:243,247)
+                    const int bb = j - n;
+                    const double c = cuus[q + m * bb];
+                    Quus[q + m * bb] = c + s;
+                    QuuFs[q + m * bb] = c + (regType == 2 ? s + lam * sr : s) + ((regType == 1 && q == bb) ? lam : 0.0);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ================= P3: gains (backward_pass.jl:30-62) =====================================
+        double H[MM * MM], R[MM * MM], kk[MM];
+        unsigned clamped = 0u;
+#pragma unroll
+        for (int c2 = 0; c2 < MM; ++c2)
+#pragma unroll
+            for (int r2 = 0; r2 < MM; ++r2) H[r2 + MM * c2] = (r2 < m && c2 < m) ? QuuFs[r2 + m * c2] : 0.0;
+        int fail;
+        if (!LIMS || nolims) {
+            fail = chol_masked<MM>(m, H, 0u, R);                 // cholesky(Hermitian(QuuF)), :35
+#pragma unroll
+            for (int q = 0; q < MM; ++q) kk[q] = (q < m) ? Qs[n + q] : 0.0;
+            chol_solve<MM>(m, R, kk);
+#pragma unroll
+            for (int q = 0; q < MM; ++q) kk[q] = -kk[q];         // k_i = -(R\Qu), :41
+        } else {
+            double g[MM], lo[MM], up[MM], x0[MM];
+#pragma unroll
+            for (int q = 0; q < MM; ++q) {
+                const double uq = (q < m) ? ui[q] : 0.0;
+                g[q] = (q < m) ? Qs[n + q] : 0.0;
+                lo[q] = limlo[q] - uq;                           // :45-46
+                up[q] = limhi[q] - uq;
+                x0[q] = (q < m) ? ks[q] : 0.0;                   // k[:,min(i+1,N-1)], :49 (Q9)
+            }
+            int iters;
+            const int result = boxqp_dev<MM>(m, H, g, lo, up, x0, qpo, kk, R, clamped, iters);
+            fail = (result < 1);                                 // :53
+        }
+        if (fail) {                                              // wave-uniform: diverge = i (:37-38,54-55)
+            diverge = i + 1;
+            // Quu[:,:,i] was already assigned by the reference before the failure
+            for (int e = lane; e < m * m; e += DDP_WAVE) Quug[mm * i + e] = Quus[e];
+            for (size_t e = lane; e < nm * (i + 1); e += DDP_WAVE) Kg[e] = 0.0;
+            for (size_t e = lane; e < (size_t)m * (i + 1); e += DDP_WAVE) kg[e] = 0.0;
+            for (size_t e = lane; e < (size_t)n * (i + 1); e += DDP_WAVE) Vxg[e] = 0.0;
+            for (size_t e = lane; e < nn * (i + 1); e += DDP_WAVE) Vxxg[e] = 0.0;
+            for (size_t e = lane; e < mm * i; e += DDP_WAVE) Quug[e] = 0.0;
+            break;
+        }
+        if (lane < n) {                                          // K_i column `lane`
+            double col[MM];
+#pragma unroll
+            for (int q = 0; q < MM; ++q) col[q] = (q < m && !((clamped >> q) & 1u)) ? Quxrs[q + m * lane] : 0.0;
+            chol_solve<MM>(m, R, col);                           // :42 / :59
+#pragma unroll
+            for (int q = 0; q < MM; ++q) col[q] = ((clamped >> q) & 1u) ? 0.0 : -col[q];
+#pragma unroll
+            for (int q = 0; q < MM; ++q) {
+                if (q < m) {
+                    double t = Quxs[q + m * lane];               // T = Quu·K + Qux
+#pragma unroll
+                    for (int q2 = 0; q2 < MM; ++q2)
+                        if (q2 < m) t += Quus[q + m * q2] * col[q2];
+                    Ks[q + m * lane] = col[q];
+                    Ts[q + m * lane] = t;
+                }
+            }
+        } else if (lane == n) {                                  // k_i, Quu·k, dV (:64-68)
+            double kQu = 0.0, kQuuk = 0.0;
+#pragma unroll
+            for (int q = 0; q < MM; ++q) {
+                if (q < m) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int q2 = 0; q2 < MM; ++q2)
+                        if (q2 < m) t += Quus[q + m * q2] * kk[q2];
+                    Quuks[q] = t;
+                    ks[q] = kk[q];
+                    kQu += kk[q] * Qs[n + q];
+                    kQuuk += kk[q] * t;
+                }
+            }
+            dV0 += kQu;
+            dV1 += 0.5 * kQuuk;
+        }
+        __syncthreads();
+
+        // ================= P4: value update (:69-76), stores, operand hand-over ====================
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int e = lane + DDP_WAVE * r;
+            if (e < ntri) {
+                const int ii = t_i[r], jj = t_j[r];
+                double mij = qxx[r], mji = qxx[r];
+#pragma unroll
+                for (int q = 0; q < MM; ++q) {
+                    if (q < m) {
+                        const double Ki = Ks[q + m * ii], Kj = Ks[q + m * jj];
+                        mij += Ki * Ts[q + m * jj] + Quxs[q + m * ii] * Kj;
+                        mji += Kj * Ts[q + m * ii] + Quxs[q + m * jj] * Ki;
+                    }
+                }
+                const double v = (mij + mji) / 2;                // :71-72
+                Vs[ii + n * jj] = v;
+                Vs[jj + n * ii] = v;
+                Vxxg[nn * i + ii + n * jj] = v;
+                Vxxg[nn * i + jj + n * ii] = v;
+            }
+        }
+        for (int j = DDP_WAVE - 1 - lane; j < n; j += DDP_WAVE) {   // Vx_i (:69)
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int q = 0; q < MM; ++q) {
+                if (q < m) {
+                    s1 += Ks[q + m * j] * Quuks[q];
+                    s2 += Ks[q + m * j] * Qs[n + q];
+                    s3 += Quxs[q + m * j] * ks[q];
+                }
+            }
+            const double v = ((Qs[j] + s1) + s2) + s3;
+            vs[j] = v;
+            Vxg[(size_t)n * i + j] = v;
+        }
+        for (int e = lane; e < m * n; e += DDP_WAVE) Kg[nm * i + e] = Ks[e];      // :75-76
+        if (lane < m) kg[(size_t)m * i + lane] = ks[lane];
+        if (lane < m * m) Quug[mm * i + lane] = Quus[lane];
+        // hand the prefetched operands of step i-1 to LDS (their last readers were P1/P2)
+        if (FXTV && i > 0) {
+#pragma unroll
+            for (int r = 0; r < R1; ++r) {
+                const int e = lane + DDP_WAVE * r;
+                if (e < n * p) Fs[e] = pfF[r];
+            }
+        }
+        if (CTV && i > 0) {
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                const int e = lane + DDP_WAVE * r;
+                if (e < n * n) cxxs[e] = pfxx[r];
+            }
+#pragma unroll
+            for (int r = 0; r < RU; ++r) {
+                const int e = lane + DDP_WAVE * r;
+                if (e < n * m) cxus[e] = pfxu[r];
+            }
+            if (lane < m * m) cuus[lane] = pfuu[0];
+        }
+        if (i > 0 && i == cc * TC) {                             // leaving chunk cc: publish cc-1, fetch cc-2
+            double *nb = cbuf + ((cc - 1) & 1) * TC * chunk_len;
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                const int e = lane + DDP_WAVE * r;
+                if (e < TC * chunk_len) nb[e] = pfc[r];
+            }
+            if (cc >= 2) {
+#pragma unroll
+                for (int r = 0; r < RC; ++r) {
+                    const int e = lane + DDP_WAVE * r;
+                    if (e < TC * chunk_len) pfc[r] = chunk_elem(cc - 2, e);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == n) { a.dV[2 * b] = dV0; a.dV[2 * b + 1] = dV1; }
+    if (lane == 0) a.diverge[b] = diverge;
+}
+
+template <int NS, int MS>
+int launch_nm(ddp_handle h, const ddp_bp_desc *d, const BPArgs &a)
+{
+    const BPLds L(d->n, d->m, d->has_lims != 0);
+    const size_t shmem = (size_t)L.total * sizeof(double);
+    const dim3 grid(d->B), block(DDP_WAVE);
+    const int key = (d->fx_tv ? 4 : 0) | (d->cost_tv ? 2 : 0) | (d->has_lims ? 1 : 0);
+#define DDP_BP_CASE(K_, FX_, C_, L_)                                                                 \
+    case K_:                                                                                         \
+        hipLaunchKernelGGL((back_pass_kernel<NS, MS, FX_, C_, L_>), grid, block, shmem, h->stream, a); \
+        break;
+    switch (key) {
+        DDP_BP_CASE(0, false, false, false)
+        DDP_BP_CASE(1, false, false, true)
+        DDP_BP_CASE(2, false, true, false)
+        DDP_BP_CASE(3, false, true, true)
+        DDP_BP_CASE(4, true, false, false)
+        DDP_BP_CASE(5, true, false, true)
+        DDP_BP_CASE(6, true, true, false)
+        DDP_BP_CASE(7, true, true, true)
+    }
+#undef DDP_BP_CASE
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+}   // namespace
+
+int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                         const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                         const double *fu, const double *lambda, const double *lims, const double *u,
+                         const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                         double *Vxx, double *dV, int32_t *diverge)
+{
+    DDP_CHECK(d->n >= 1 && d->m >= 1 && d->N >= 1 && d->B >= 1, "back_pass: bad sizes n=%d m=%d N=%d B=%d", d->n, d->m, d->N, d->B);
+    DDP_CHECK(d->regType == 1 || d->regType == 2, "back_pass: regType must be 1 or 2 (got %d)", d->regType);
+    DDP_CHECK(!d->has_lims || (lims && u), "back_pass: has_lims needs lims and u");
+    DDP_CHECK(d->m <= DDP_MAX_M, "back_pass: m=%d exceeds DDP_MAX_M=%d", d->m, DDP_MAX_M);
+    BPArgs a;
+    a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;
+    a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.regType = d->regType;
+    a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu;
+    a.lambda = lambda; a.lims = lims; a.u = u; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    if (d->n == 10 && d->m == 2) return launch_nm<10, 2>(h, d, a);
+    if (d->n == 4 && d->m == 1) return launch_nm<4, 1>(h, d, a);
+    if (d->n == 6 && d->m == 3) return launch_nm<6, 3>(h, d, a);
+    DDP_CHECK(d->n <= DDP_MAX_N_GENERIC, "back_pass: n=%d has no kernel (compiled: (10,2),(4,1),(6,3), generic n<=%d)", d->n, DDP_MAX_N_GENERIC);
+    return launch_nm<0, 0>(h, d, a);
+}

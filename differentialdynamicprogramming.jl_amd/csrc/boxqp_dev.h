@@ -1,0 +1,195 @@
+// boxqp_dev.h — device-side box-constrained QP (projected Newton), src/boxQP.jl:29-188.
+//
+// Every lane of the calling wavefront runs the SAME solve on the SAME data (operands come from
+// LDS broadcasts), so all branches are wave-uniform and no cross-lane traffic is needed; for the
+// m <= 8 of the hot path a lane-parallel factorisation would cost more in shuffles than it saves.
+//
+// H[free,free] is never gathered: the Cholesky runs on the full m x m matrix with clamped
+// rows/columns replaced by identity ("masked" factorisation).  For the free indices this performs
+// exactly the arithmetic of cholesky(H[free,free]) (the extra terms are exact zeros), keeps every
+// loop bound static, and therefore keeps H, R and the vectors in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct QPOptsDev {
+    int    maxIter;
+    double minGrad, minRelImprove, stepDec, minStep, Armijo;
+};
+
+__device__ __forceinline__ double ddp_clamp(double x, double lo, double hi)
+{   // Base.clamp: NaN passes through
+    return x > hi ? hi : (x < lo ? lo : x);
+}
+
+// Upper Cholesky of H with rows/cols in `clamped` replaced by identity; reads the upper triangle
+// (LAPACK potrf 'U' / cholesky(Hermitian(.))).  Returns 0 ok, j+1 on a non-positive pivot.
+template <int MM>
+__device__ __forceinline__ int chol_masked(int m, const double (&H)[MM * MM], unsigned clamped,
+                                           double (&R)[MM * MM])
+{
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        if (j < m) {
+            const bool cj = (clamped >> j) & 1u;
+            double ajj = cj ? 1.0 : H[j + MM * j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) ajj -= R[k + MM * j] * R[k + MM * j];
+            if (!(ajj > 0.0) && fail == 0) fail = j + 1;
+            ajj = sqrt(ajj);
+            R[j + MM * j] = ajj;
+#pragma unroll
+            for (int i = j + 1; i < MM; ++i) {
+                if (i < m) {
+                    const bool ci = (clamped >> i) & 1u;
+                    double s = (cj || ci) ? 0.0 : H[j + MM * i];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) s -= R[k + MM * j] * R[k + MM * i];
+                    R[j + MM * i] = s / ajj;
+                }
+            }
+        }
+    }
+    return fail;
+}
+
+// solve (R'R) b = b in place (potrs)
+template <int MM>
+__device__ __forceinline__ void chol_solve(int m, const double (&R)[MM * MM], double (&b)[MM])
+{
+#pragma unroll
+    for (int i = 0; i < MM; ++i) {
+        if (i < m) {
+            double s = b[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= R[k + MM * i] * b[k];
+            b[i] = s / R[i + MM * i];
+        }
+    }
+#pragma unroll
+    for (int i = MM - 1; i >= 0; --i) {
+        if (i < m) {
+            double s = b[i];
+#pragma unroll
+            for (int k = i + 1; k < MM; ++k)
+                if (k < m) s -= R[i + MM * k] * b[k];
+            b[i] = s / R[i + MM * i];
+        }
+    }
+}
+
+template <int MM>
+__device__ __forceinline__ double qp_value(int m, const double (&H)[MM * MM], const double (&g)[MM],
+                                           const double (&x)[MM])
+{   // (x'g + 0.5x'H*x)[1]  — boxQP.jl:63,141,146
+    double xg = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+        if (i < m) xg += x[i] * g[i];
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        if (j < m) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < m) t += (0.5 * x[i]) * H[i + MM * j];
+            q += t * x[j];
+        }
+    }
+    return xg + q;
+}
+
+// Returns `result` (boxQP.jl:172-179; 0 also for the swallowed PosDefException,
+// backward_pass.jl:48-52).  On return x is the solution, `clamped` the bit mask of clamped
+// coordinates belonging to the returned factor R (quirk Q12: on result 4 both are from the
+// previous iteration), `iters` the final value of `iter`.
+template <int MM>
+__device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], const double (&g)[MM],
+                                         const double (&lower)[MM], const double (&upper)[MM],
+                                         const double (&x0)[MM], const QPOptsDev &o,
+                                         double (&x)[MM], double (&R)[MM * MM], unsigned &clamped,
+                                         int &iters)
+{
+    const unsigned all = (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
+    double grad[MM], search[MM], xc[MM];
+    int    result = 0, iter = 1;
+    double oldvalue = 0.0, value;
+    clamped = 0u;
+#pragma unroll
+    for (int i = 0; i < MM * MM; ++i) R[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < MM; ++i) x[i] = (i < m) ? ddp_clamp(x0[i], lower[i], upper[i]) : 0.0;   // :58
+    value = qp_value<MM>(m, H, g, x);                                                          // :63
+
+    while (iter <= o.maxIter) {                                                                // :71
+        if (result != 0) break;
+        if (iter > 1 && (oldvalue - value) < o.minRelImprove * fabs(oldvalue)) { result = 4; break; }
+        oldvalue = value;
+        unsigned newc = 0u;
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {                                                         // :85-95
+            if (i < m) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < MM; ++j)
+                    if (j < m) s += H[i + MM * j] * x[j];
+                grad[i] = g[i] + s;
+                const bool c = ((x[i] == lower[i]) && (grad[i] > 0)) || ((x[i] == upper[i]) && (grad[i] < 0));
+                newc |= (c ? 1u : 0u) << i;
+            } else {
+                grad[i] = 0.0;
+            }
+        }
+        const unsigned oldc = clamped;
+        clamped = newc;
+        if (clamped == all) { result = 6; break; }                                             // :98-101
+        if (iter == 1 || oldc != clamped) {                                                    // :104-117
+            if (chol_masked<MM>(m, H, clamped, R) != 0) { result = 0; break; }                 // throw -> 0
+        }
+        double gn = 0.0;                                                                       // :120-124
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+            if (i < m && !((clamped >> i) & 1u)) gn += grad[i] * grad[i];
+        if (sqrt(gn) < o.minGrad) { result = 5; break; }
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {                                                         // :127-129
+            if (i < m) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < MM; ++j)
+                    if (j < m && ((clamped >> j) & 1u)) s += H[i + MM * j] * x[j];
+                search[i] = ((clamped >> i) & 1u) ? 0.0 : (g[i] + s);
+            } else {
+                search[i] = 0.0;
+            }
+        }
+        chol_solve<MM>(m, R, search);
+        double sdotg = 0.0;
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {
+            if (i < m) {
+                search[i] = ((clamped >> i) & 1u) ? 0.0 : (-search[i] - x[i]);
+                sdotg += search[i] * grad[i];                                                  // :132
+            }
+        }
+        if (sdotg >= 0) break;                                                                 // :133-135
+        double step = 1.0, vc;                                                                 // :138-151
+#pragma unroll
+        for (int i = 0; i < MM; ++i) xc[i] = (i < m) ? ddp_clamp(x[i] + step * search[i], lower[i], upper[i]) : 0.0;
+        vc = qp_value<MM>(m, H, g, xc);
+        while ((vc - oldvalue) / (step * sdotg) < o.Armijo) {
+            step = step * o.stepDec;
+#pragma unroll
+            for (int i = 0; i < MM; ++i) xc[i] = (i < m) ? ddp_clamp(x[i] + step * search[i], lower[i], upper[i]) : 0.0;
+            vc = qp_value<MM>(m, H, g, xc);
+            if (step < o.minStep) { result = 2; break; }
+        }
+#pragma unroll
+        for (int i = 0; i < MM; ++i) x[i] = xc[i];                                             // :161-163
+        value = vc;
+        iter += 1;
+    }
+    if (iter == o.maxIter) result = 1;                                                         // :167-169
+    iters = iter;
+    return result;
+}

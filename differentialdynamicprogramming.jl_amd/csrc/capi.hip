@@ -1,0 +1,376 @@
+// capi.hip — handle, memory/event helpers, host-pointer flavours and the standalone batched boxQP
+// of the C ABI declared in include/ddp_amd.h.
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+#include "ddp_internal.h"
+#include "boxqp_dev.h"
+
+static thread_local char g_err[1024] = "";
+
+void ddp_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char *ddp_last_error(void) { return g_err; }
+const char *ddp_version(void) { return "ddp_amd 0.1.0 (gfx950, fp64)"; }
+
+int ddp_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int ddp_create(int device, ddp_handle *out)
+{
+    DDP_CHECK(out, "ddp_create: out is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    DDP_CHECK(e == hipSuccess && c > 0, "ddp_create: no HIP device available (%s) — libddp_amd has no CPU fallback",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    DDP_CHECK(device >= 0 && device < c, "ddp_create: device %d out of range [0,%d)", device, c);
+    DDP_HIP(hipSetDevice(device));
+    ddp_handle h = new ddp_handle_s();
+    h->device = device;
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    h->h_pinned = nullptr;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        ddp_set_error("ddp_create: hipStreamCreate failed");
+        return -2;
+    }
+    if (hipHostMalloc((void **)&h->h_pinned, 256) != hipSuccess) h->h_pinned = nullptr;
+    *out = h;
+    return 0;
+}
+
+int ddp_destroy(ddp_handle h)
+{
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (h->scratch) hipFree(h->scratch);
+    if (h->h_pinned) hipHostFree(h->h_pinned);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int ddp_sync(ddp_handle h)
+{
+    DDP_CHECK(h, "ddp_sync: null handle");
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+void *ddp_stream(ddp_handle h) { return h ? (void *)h->stream : nullptr; }
+
+int ddp_malloc(ddp_handle h, size_t bytes, void **dptr)
+{
+    DDP_CHECK(h && dptr, "ddp_malloc: null argument");
+    DDP_HIP(hipSetDevice(h->device));
+    DDP_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+    return 0;
+}
+int ddp_free(ddp_handle h, void *dptr)
+{
+    DDP_CHECK(h, "ddp_free: null handle");
+    if (dptr) { DDP_HIP(hipStreamSynchronize(h->stream)); DDP_HIP(hipFree(dptr)); }
+    return 0;
+}
+int ddp_memcpy_h2d(ddp_handle h, void *dst, const void *src, size_t bytes)
+{
+    DDP_CHECK(h, "ddp_memcpy_h2d: null handle");
+    DDP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int ddp_memcpy_d2h(ddp_handle h, void *dst, const void *src, size_t bytes)
+{
+    DDP_CHECK(h, "ddp_memcpy_d2h: null handle");
+    DDP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int ddp_memset(ddp_handle h, void *dst, int value, size_t bytes)
+{
+    DDP_CHECK(h, "ddp_memset: null handle");
+    DDP_HIP(hipMemsetAsync(dst, value, bytes, h->stream));
+    return 0;
+}
+int ddp_event_create(ddp_handle h, void **ev)
+{
+    DDP_CHECK(h && ev, "ddp_event_create: null argument");
+    hipEvent_t e;
+    DDP_HIP(hipEventCreate(&e));
+    *ev = (void *)e;
+    return 0;
+}
+int ddp_event_destroy(ddp_handle h, void *ev)
+{
+    (void)h;
+    if (ev) DDP_HIP(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+int ddp_event_record(ddp_handle h, void *ev)
+{
+    DDP_CHECK(h && ev, "ddp_event_record: null argument");
+    DDP_HIP(hipEventRecord((hipEvent_t)ev, h->stream));
+    return 0;
+}
+int ddp_event_elapsed_ms(ddp_handle h, void *start, void *stop, float *ms)
+{
+    DDP_CHECK(h && start && stop && ms, "ddp_event_elapsed_ms: null argument");
+    DDP_HIP(hipEventSynchronize((hipEvent_t)stop));
+    DDP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+
+}   // extern "C"
+
+int ddp_scratch(ddp_handle h, size_t bytes, void **out)
+{
+    if (bytes > h->scratch_bytes) {
+        DDP_HIP(hipStreamSynchronize(h->stream));
+        if (h->scratch) DDP_HIP(hipFree(h->scratch));
+        h->scratch = nullptr;
+        h->scratch_bytes = 0;
+        DDP_HIP(hipMalloc(&h->scratch, bytes));
+        h->scratch_bytes = bytes;
+    }
+    *out = h->scratch;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bump allocator over the handle's scratch for the host-pointer flavours
+namespace {
+struct Arena {
+    ddp_handle h;
+    char *base = nullptr;
+    size_t off = 0, cap = 0;
+    std::vector<std::pair<void *, std::pair<const void *, size_t>>> ups;     // dst, (src, bytes)
+    std::vector<std::pair<void *, std::pair<void *, size_t>>> downs;          // host dst, (dev src, bytes)
+    static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+    size_t need = 0;
+    void want(size_t bytes) { need += al(bytes); }
+    int commit()
+    {
+        void *p;
+        int rc = ddp_scratch(h, need + 256, &p);
+        if (rc) return rc;
+        base = (char *)p; cap = need + 256; off = 0;
+        return 0;
+    }
+    void *take(size_t bytes) { void *p = base + off; off += al(bytes); return p; }
+    template <class T> const T *in(const T *host, size_t count)
+    {
+        if (!host) return nullptr;
+        void *d = take(count * sizeof(T));
+        ups.push_back({d, {host, count * sizeof(T)}});
+        return (const T *)d;
+    }
+    template <class T> T *outp(T *host, size_t count)
+    {
+        if (!host) return nullptr;
+        void *d = take(count * sizeof(T));
+        downs.push_back({host, {d, count * sizeof(T)}});
+        return (T *)d;
+    }
+    int upload()
+    {
+        for (auto &u : ups) DDP_HIP(hipMemcpyAsync(u.first, u.second.first, u.second.second, hipMemcpyHostToDevice, h->stream));
+        return 0;
+    }
+    int download()
+    {
+        for (auto &d : downs) DDP_HIP(hipMemcpyAsync(d.first, d.second.first, d.second.second, hipMemcpyDeviceToHost, h->stream));
+        DDP_HIP(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+};
+}   // namespace
+
+extern "C" {
+
+int ddp_back_pass_f64_dev(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                          const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                          const double *fu, const double *lambda, const double *lims, const double *u,
+                          const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                          double *Vxx, double *dV, int32_t *diverge)
+{
+    DDP_CHECK(h && d, "back_pass: null handle/descriptor");
+    DDP_CHECK(cx && cu && cxx && cxu && cuu && fx && fu && lambda, "back_pass: null input pointer");
+    DDP_CHECK(K && k && Quu && Vx && Vxx && dV && diverge, "back_pass: null output pointer");
+    return ddp_launch_back_pass(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+}
+
+int ddp_back_pass_f64(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                      const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                      const double *fu, const double *lambda, const double *lims, const double *u,
+                      double *K, double *k, double *Quu, double *Vx, double *Vxx, double *dV,
+                      int32_t *diverge)
+{
+    DDP_CHECK(h && d, "back_pass: null handle/descriptor");
+    const size_t n = d->n, m = d->m, N = d->N, B = d->B;
+    const size_t fxc = (d->fx_tv ? N : 1) * (d->fx_batched ? B : 1), cc = (d->cost_tv ? N : 1) * (d->cost_batched ? B : 1);
+    const size_t sizes_in[] = {n * N * B, m * N * B, n * n * cc, n * m * cc, m * m * cc, n * n * fxc, n * m * fxc, B, 2 * m, m * N * B};
+    const size_t sizes_out[] = {m * n * N * B, m * N * B, m * m * N * B, n * N * B, n * n * N * B, 2 * B};
+    Arena A; A.h = h;
+    for (size_t s : sizes_in) A.want(s * 8);
+    for (size_t s : sizes_out) A.want(s * 8);
+    A.want(B * 4);
+    int rc = A.commit();
+    if (rc) return rc;
+    const double *dcx = A.in(cx, sizes_in[0]), *dcu = A.in(cu, sizes_in[1]), *dcxx = A.in(cxx, sizes_in[2]),
+                 *dcxu = A.in(cxu, sizes_in[3]), *dcuu = A.in(cuu, sizes_in[4]), *dfx = A.in(fx, sizes_in[5]),
+                 *dfu = A.in(fu, sizes_in[6]), *dlam = A.in(lambda, sizes_in[7]),
+                 *dlims = d->has_lims ? A.in(lims, sizes_in[8]) : nullptr, *du = d->has_lims ? A.in(u, sizes_in[9]) : nullptr;
+    double *dK = A.outp(K, sizes_out[0]), *dk = A.outp(k, sizes_out[1]), *dQuu = A.outp(Quu, sizes_out[2]),
+           *dVx = A.outp(Vx, sizes_out[3]), *dVxx = A.outp(Vxx, sizes_out[4]), *ddV = A.outp(dV, sizes_out[5]);
+    int32_t *ddiv = A.outp(diverge, B);
+    if ((rc = A.upload())) return rc;
+    rc = ddp_back_pass_f64_dev(h, d, dcx, dcu, dcxx, dcxu, dcuu, dfx, dfu, dlam, dlims, du, nullptr, dK, dk, dQuu, dVx, dVxx, ddV, ddiv);
+    if (rc) return rc;
+    return A.download();
+}
+
+int ddp_forward_pass_f64(ddp_handle h, const ddp_problem *p, const double *K, const double *k,
+                         const double *x0, const double *u, const double *x, const double *alpha,
+                         int nalpha, const double *lims, double *xnew, double *unew, double *cnew,
+                         double *csum)
+{
+    DDP_CHECK(h && p, "forward_pass: null handle/problem");
+    DDP_CHECK(nalpha >= 1 && nalpha <= 16, "forward_pass: nalpha=%d out of [1,16]", nalpha);
+    const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p), na = nalpha;
+    const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? B : 1);
+    Arena A; A.h = h;
+    const size_t tot = m * n * N * B + m * N * B + n * B + m * N * B + n * N * B + 2 * m + n * n * dc + n * m * dc + n * n + m * m +
+                       (n * N + m * N + CL + 1) * B * na;
+    A.want(tot * 8 + 32 * 256);
+    int rc = A.commit();
+    if (rc) return rc;
+    ddp_problem pd = *p;
+    if (p->kind == DDP_PROBLEM_LQ) { pd.A = A.in(p->A, n * n * dc); pd.Bm = A.in(p->Bm, n * m * dc); }
+    pd.Q = A.in(p->Q, n * n); pd.R = A.in(p->R, m * m);
+    const double *dK = A.in(K, m * n * N * B), *dk = A.in(k, m * N * B), *dx0 = A.in(x0, n * B), *du = A.in(u, m * N * B),
+                 *dx = A.in(x, n * N * B), *dl = A.in(lims, 2 * m);
+    double *dxn = A.outp(xnew, n * N * B * na), *dun = A.outp(unew, m * N * B * na), *dcn = A.outp(cnew, CL * B * na),
+           *dcs = A.outp(csum, B * na);
+    // outputs the caller does not want still need device storage
+    if (!dxn) dxn = (double *)A.take(n * N * B * na * 8);
+    if (!dun) dun = (double *)A.take(m * N * B * na * 8);
+    if (!dcn) dcn = (double *)A.take(CL * B * na * 8);
+    if (!dcs) dcs = (double *)A.take(B * na * 8);
+    if ((rc = A.upload())) return rc;
+    rc = ddp_forward_pass_f64_dev(h, &pd, dK, dk, dx0, du, dx, alpha, nalpha, dl, nullptr, dxn, dun, dcn, dcs);
+    if (rc) return rc;
+    return A.download();
+}
+
+}   // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// standalone batched boxQP (src/boxQP.jl:29-188): one lane per problem
+namespace {
+template <int MM>
+__global__ __launch_bounds__(DDP_WAVE) void boxqp_kernel(int m, int count, const double *Hg, const double *gg,
+                                                         const double *log_, const double *upg, const double *x0g,
+                                                         QPOptsDev o, double *xg, int32_t *resg, double *Hfg,
+                                                         uint8_t *freeg)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    double H[MM * MM], R[MM * MM], g[MM], lo[MM], up[MM], x0[MM], x[MM];
+#pragma unroll
+    for (int c = 0; c < MM; ++c) {
+        g[c] = (c < m) ? gg[(size_t)m * t + c] : 0.0;
+        lo[c] = (c < m) ? log_[(size_t)m * t + c] : 0.0;
+        up[c] = (c < m) ? upg[(size_t)m * t + c] : 0.0;
+        x0[c] = (c < m) ? x0g[(size_t)m * t + c] : 0.0;
+#pragma unroll
+        for (int r = 0; r < MM; ++r) H[r + MM * c] = (r < m && c < m) ? Hg[(size_t)m * m * t + r + m * c] : 0.0;
+    }
+    unsigned clamped;
+    int iters;
+    const int res = boxqp_dev<MM>(m, H, g, lo, up, x0, o, x, R, clamped, iters);
+    resg[t] = res;
+    // compact the masked factor to the leading nfree x nfree block (the reference's Hfree)
+    int pos[MM], nf = 0;
+#pragma unroll
+    for (int c = 0; c < MM; ++c) {
+        const bool fr = (c < m) && !((clamped >> c) & 1u);
+        pos[c] = fr ? nf : -1;
+        nf += fr ? 1 : 0;
+    }
+    for (int e = 0; e < m * m; ++e) Hfg[(size_t)m * m * t + e] = 0.0;
+#pragma unroll
+    for (int c = 0; c < MM; ++c) {
+        if (c < m) {
+            xg[(size_t)m * t + c] = x[c];
+            freeg[(size_t)m * t + c] = (pos[c] >= 0) ? 1 : 0;
+#pragma unroll
+            for (int r = 0; r < MM; ++r)
+                if (r <= c && pos[r] >= 0 && pos[c] >= 0) Hfg[(size_t)m * m * t + pos[r] + m * pos[c]] = R[r + MM * c];
+        }
+    }
+}
+}   // namespace
+
+extern "C" {
+
+int ddp_boxqp_f64_dev(ddp_handle h, int m, int count, const double *H, const double *g, const double *lower,
+                      const double *upper, const double *x0, const ddp_qp_opts *opts, double *x,
+                      int32_t *result, double *Hfree, uint8_t *free_out)
+{
+    DDP_CHECK(h, "boxqp: null handle");
+    DDP_CHECK(m >= 1 && m <= DDP_MAX_M, "boxqp: m=%d out of [1,%d]", m, DDP_MAX_M);
+    DDP_CHECK(count >= 1, "boxqp: count=%d", count);
+    QPOptsDev o = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};
+    if (opts) o = {opts->maxIter, opts->minGrad, opts->minRelImprove, opts->stepDec, opts->minStep, opts->Armijo};
+    const dim3 grid((count + DDP_WAVE - 1) / DDP_WAVE), block(DDP_WAVE);
+#define DDP_QP_CASE(M_)                                                                                           \
+    case M_:                                                                                                      \
+        hipLaunchKernelGGL((boxqp_kernel<M_>), grid, block, 0, h->stream, m, count, H, g, lower, upper, x0, o, x, \
+                           result, Hfree, free_out);                                                              \
+        break;
+    switch (m) {
+        DDP_QP_CASE(1) DDP_QP_CASE(2) DDP_QP_CASE(3) DDP_QP_CASE(4)
+        DDP_QP_CASE(5) DDP_QP_CASE(6) DDP_QP_CASE(7) DDP_QP_CASE(8)
+    }
+#undef DDP_QP_CASE
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddp_boxqp_f64(ddp_handle h, int m, int count, const double *H, const double *g, const double *lower,
+                  const double *upper, const double *x0, const ddp_qp_opts *opts, double *x, int32_t *result,
+                  double *Hfree, uint8_t *free_out)
+{
+    DDP_CHECK(h, "boxqp: null handle");
+    DDP_CHECK(m >= 1 && count >= 1, "boxqp: bad sizes");
+    const size_t M = m, C = count;
+    Arena A; A.h = h;
+    A.want((2 * M * M * C + 5 * M * C) * 8 + C * 4 + M * C + 16 * 256);
+    int rc = A.commit();
+    if (rc) return rc;
+    const double *dH = A.in(H, M * M * C), *dg = A.in(g, M * C), *dlo = A.in(lower, M * C), *dup = A.in(upper, M * C),
+                 *dx0 = A.in(x0, M * C);
+    double *dx = A.outp(x, M * C), *dHf = A.outp(Hfree, M * M * C);
+    int32_t *dr = A.outp(result, C);
+    uint8_t *df = A.outp(free_out, M * C);
+    if ((rc = A.upload())) return rc;
+    rc = ddp_boxqp_f64_dev(h, m, count, dH, dg, dlo, dup, dx0, opts, dx, dr, dHf, df);
+    if (rc) return rc;
+    return A.download();
+}
+
+}   // extern "C"

@@ -1,0 +1,49 @@
+// ddp_internal.h — shared between the translation units of libddp_amd.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/ddp_amd.h"
+
+#define DDP_WAVE 64
+#define DDP_MAX_N_GENERIC 32      // run-time-sized kernels: n <= 32, m <= DDP_MAX_M
+
+struct ddp_handle_s {
+    int          device;
+    hipStream_t  stream;
+    // scratch owned by the handle (host-pointer entry points, iLQG driver)
+    void        *scratch;
+    size_t       scratch_bytes;
+    int32_t     *h_pinned;        // small pinned buffer for polling
+};
+
+void ddp_set_error(const char *fmt, ...);
+
+#define DDP_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ddp_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                          __LINE__);                                                          \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+#define DDP_CHECK(cond, ...)                                                                  \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            ddp_set_error(__VA_ARGS__);                                                       \
+            return -1;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+// grows the handle's scratch to at least `bytes` (contents not preserved)
+int ddp_scratch(ddp_handle h, size_t bytes, void **out);
+
+// kernel launchers (each in its own .hip)
+int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                         const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                         const double *fu, const double *lambda, const double *lims, const double *u,
+                         const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                         double *Vxx, double *dV, int32_t *diverge);

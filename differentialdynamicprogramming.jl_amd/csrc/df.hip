@@ -1,0 +1,291 @@
+// df.hip — derivatives along the trajectory for the registered problem families: the `df` closure that
+// STEP 1 of the reference's iteration calls (src/iLQG.jl:225-229).
+//   LQ        cx = Q x, cu = R u                                   (src/demo_linear.jl:35-41)
+//   pendcart  cx = Q (x - goal), cu = R u, and the ZoH discretisation of the continuous Jacobian by
+//             exp of the 5x5 block matrix [fxc*h fuc*h; 0]          (src/system_pendcart.jl:112-116,137-154)
+// One lane per (time step, trajectory): both are embarrassingly parallel, HBM-bound streams
+// (pendcart adds ~1.5 kflop of 5x5 Padé arithmetic per element, still far below the fp64 ridge).
+#include "ddp_internal.h"
+
+namespace {
+
+// ---- dense matrix exponential of a D x D matrix held in registers --------------------------------
+// Higham (2005) scaling & squaring with Padé 3/5/7/9/13 — the algorithm behind Julia's
+// exp(::Matrix{Float64}) (without gebal balancing, which only changes rounding).
+template <int D>
+struct Mat {
+    double a[D * D];
+    __device__ double &operator()(int r, int c) { return a[r + D * c]; }
+    __device__ double operator()(int r, int c) const { return a[r + D * c]; }
+};
+
+template <int D>
+__device__ __forceinline__ void mmul(const Mat<D> &A, const Mat<D> &B, Mat<D> &C)
+{
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += A(i, k) * B(k, j);
+            C(i, j) = s;
+        }
+}
+
+// solve A X = X in place (LU, partial pivoting; rows are swapped by value so indexing stays static)
+template <int D>
+__device__ __forceinline__ void gesv(Mat<D> &A, Mat<D> &X)
+{
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        int p = c;
+        double best = fabs(A(c, c));
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            const double v = fabs(A(r, c));
+            if (v > best) { best = v; p = r; }
+        }
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            if (p == r) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double t = A(c, j); A(c, j) = A(r, j); A(r, j) = t;
+                    t = X(c, j); X(c, j) = X(r, j); X(r, j) = t;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            const double f = A(r, c) / A(c, c);
+            A(r, c) = 0.0;
+#pragma unroll
+            for (int j = c + 1; j < D; ++j) A(r, j) -= f * A(c, j);
+#pragma unroll
+            for (int j = 0; j < D; ++j) X(r, j) -= f * X(c, j);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+        for (int r = D - 1; r >= 0; --r) {
+            double s = X(r, j);
+#pragma unroll
+            for (int c = r + 1; c < D; ++c) s -= A(r, c) * X(c, j);
+            X(r, j) = s / A(r, r);
+        }
+}
+
+template <int D>
+__device__ void expm_dev(const Mat<D> &Ain, Mat<D> &E)
+{
+    double nA = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) s += fabs(Ain(i, j));
+        nA = fmax(nA, s);
+    }
+    Mat<D> A = Ain, A2, U, V, T;
+    if (nA <= 2.1) {
+        const double C9[10] = {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.};
+        const double C7[8] = {17297280., 8648640., 1995840., 277200., 25200., 1512., 56., 1.};
+        const double C5[6] = {30240., 15120., 3360., 420., 30., 1.};
+        const double C3[4] = {120., 60., 12., 1.};
+        double C[10];
+        int nc;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) C[i] = 0.0;
+        if (nA > 0.95) { nc = 10;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) C[i] = C9[i]; }
+        else if (nA > 0.25) { nc = 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) C[i] = C7[i]; }
+        else if (nA > 0.015) { nc = 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) C[i] = C5[i]; }
+        else { nc = 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) C[i] = C3[i]; }
+        mmul<D>(A, A, A2);
+        Mat<D> P;
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) { P.a[i] = 0.0; U.a[i] = 0.0; V.a[i] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) { P(i, i) = 1.0; U(i, i) = C[1]; V(i, i) = C[0]; }
+#pragma unroll
+        for (int kk = 1; kk <= 4; ++kk) {                       // static indices keep C[] in registers
+            if (kk <= nc / 2 - 1) {
+                mmul<D>(P, A2, T);
+                P = T;
+#pragma unroll
+                for (int i = 0; i < D * D; ++i) { U.a[i] += C[2 * kk + 1] * P.a[i]; V.a[i] += C[2 * kk] * P.a[i]; }
+            }
+        }
+        mmul<D>(A, U, T);
+        U = T;
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) { E.a[i] = V.a[i] + U.a[i]; T.a[i] = V.a[i] - U.a[i]; }
+        gesv<D>(T, E);
+    } else {
+        const double CC[14] = {64764752532480000., 32382376266240000., 7771770303897600., 1187353796428800.,
+                               129060195264000., 10559470521600., 670442572800., 33522128640., 1323241920.,
+                               40840800., 960960., 16380., 182., 1.};
+        const double s = log2(nA / 5.4);
+        int si = 0;
+        if (s > 0) {
+            si = (int)ceil(s);
+            const double sc = ldexp(1.0, si);
+#pragma unroll
+            for (int i = 0; i < D * D; ++i) A.a[i] /= sc;
+        }
+        Mat<D> A4, A6, P;
+        mmul<D>(A, A, A2); mmul<D>(A2, A2, A4); mmul<D>(A2, A4, A6);
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) P.a[i] = CC[13] * A6.a[i] + CC[11] * A4.a[i] + CC[9] * A2.a[i];
+        mmul<D>(A6, P, T);
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) T.a[i] += CC[7] * A6.a[i] + CC[5] * A4.a[i] + CC[3] * A2.a[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) T(i, i) += CC[1];
+        mmul<D>(A, T, U);
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) P.a[i] = CC[12] * A6.a[i] + CC[10] * A4.a[i] + CC[8] * A2.a[i];
+        mmul<D>(A6, P, V);
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) V.a[i] += CC[6] * A6.a[i] + CC[4] * A4.a[i] + CC[2] * A2.a[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) V(i, i) += CC[0];
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) { E.a[i] = V.a[i] + U.a[i]; T.a[i] = V.a[i] - U.a[i]; }
+        gesv<D>(T, E);
+        for (int q = 0; q < si; ++q) { mmul<D>(E, E, T); E = T; }
+    }
+}
+
+__global__ void df_lq_kernel(int n, int m, int N, int B, const double *Q, const double *R, const double *x,
+                             const double *u, const int32_t *active, double *cx, double *cu)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;     // column index over (time, batch)
+    if (t >= (long)N * B) return;
+    const int b = (int)(t / N);
+    if (active && active[b] == 0) return;
+    const double *xc = x + (size_t)n * t, *uc = u + (size_t)m * t;
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += Q[i + n * j] * xc[j];
+        cx[(size_t)n * t + i] = s;
+    }
+    for (int i = 0; i < m; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) {
+            double uj = uc[j];
+            if (uj != uj) uj = 0.0;                                   // u[isnan.(u)] .= 0
+            s += R[i + m * j] * uj;
+        }
+        cu[(size_t)m * t + i] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void df_pendcart_kernel(int N, int B, double g, double l, double h, double d,
+                                                         double g0, double g1, double g2, double g3, const double *Q,
+                                                         const double *R, const double *x, const double *u,
+                                                         const int32_t *active, double *cx, double *cu, double *fx,
+                                                         double *fu)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * B) return;
+    const int b = (int)(t / N);
+    if (active && active[b] == 0) return;
+    const double goal[4] = {g0, g1, g2, g3};
+    double xv[4], dx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xv[i] = x[4 * t + i]; dx[i] = xv[i] - goal[i]; }
+    double uu = u[t];
+    if (uu != uu) uu = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += Q[i + 4 * j] * dx[j];
+        cx[4 * t + i] = s;                                            // system_pendcart.jl:113
+    }
+    cu[t] = R[0] * uu;                                                // :114
+    Mat<5> M, E;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) M.a[i] = 0.0;
+    const double sn = sin(xv[0]), cs = cos(xv[0]);
+    M(0, 1) = 1.0 * h;                                                // fxc*h, fuc*h  (:130-148)
+    M(1, 0) = (-g / l * cs - uu / l * sn) * h;
+    M(1, 1) = (-d) * h;
+    M(2, 3) = 1.0 * h;
+    M(1, 4) = (cs / l) * h;
+    M(3, 4) = 1.0 * h;
+    expm_dev<5>(M, E);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fx[16 * t + r + 4 * c] = E(r, c);    // :149
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fu[4 * t + r] = E(r, 4);                  // :150
+}
+
+}   // namespace
+
+extern "C" {
+
+int ddp_df_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
+                   double *cx, double *cu, double *fx, double *fu)
+{
+    DDP_CHECK(h && p && x && u && cx && cu, "df: null argument");
+    const long cols = (long)p->N * p->B;
+    if (p->kind == DDP_PROBLEM_LQ) {
+        const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
+        hipLaunchKernelGGL(df_lq_kernel, grid, block, 0, h->stream, p->n, p->m, p->N, p->B, p->Q, p->R, x, u, active, cx, cu);
+    } else if (p->kind == DDP_PROBLEM_PENDCART) {
+        DDP_CHECK(p->n == 4 && p->m == 1, "df: pendcart needs n=4, m=1");
+        DDP_CHECK(fx && fu, "df: pendcart needs fx and fu outputs");
+        const dim3 grid((unsigned)((cols + 63) / 64)), block(64);
+        hipLaunchKernelGGL(df_pendcart_kernel, grid, block, 0, h->stream, p->N, p->B, p->g, p->l, p->h, p->d, p->goal[0],
+                           p->goal[1], p->goal[2], p->goal[3], p->Q, p->R, x, u, active, cx, cu, fx, fu);
+    } else {
+        DDP_CHECK(false, "df: unknown problem kind %d", p->kind);
+    }
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddp_df_f64(ddp_handle h, const ddp_problem *p, const double *x, const double *u, double *cx, double *cu,
+               double *fx, double *fu)
+{
+    DDP_CHECK(h && p && x && u && cx && cu, "df: null argument");
+    const size_t n = p->n, m = p->m, N = p->N, B = p->B;
+    const bool pend = p->kind == DDP_PROBLEM_PENDCART;
+    const size_t bytes = ((n + m) * N * B * 2 + n * n + m * m + (pend ? (n * n + n * m) * N * B : 0)) * 8 + 16 * 256;
+    void *base;
+    int rc = ddp_scratch(h, bytes, &base);
+    if (rc) return rc;
+    char *pp = (char *)base;
+    auto take = [&](size_t cnt) { double *r = (double *)pp; pp += ((cnt * 8 + 255) & ~(size_t)255); return r; };
+    double *dx = take(n * N * B), *du = take(m * N * B), *dcx = take(n * N * B), *dcu = take(m * N * B), *dQ = take(n * n),
+           *dR = take(m * m), *dfx = pend ? take(n * n * N * B) : nullptr, *dfu = pend ? take(n * m * N * B) : nullptr;
+    DDP_HIP(hipMemcpyAsync(dx, x, n * N * B * 8, hipMemcpyHostToDevice, h->stream));
+    DDP_HIP(hipMemcpyAsync(du, u, m * N * B * 8, hipMemcpyHostToDevice, h->stream));
+    DDP_HIP(hipMemcpyAsync(dQ, p->Q, n * n * 8, hipMemcpyHostToDevice, h->stream));
+    DDP_HIP(hipMemcpyAsync(dR, p->R, m * m * 8, hipMemcpyHostToDevice, h->stream));
+    ddp_problem pd = *p;
+    pd.Q = dQ; pd.R = dR;
+    rc = ddp_df_f64_dev(h, &pd, dx, du, nullptr, dcx, dcu, dfx, dfu);
+    if (rc) return rc;
+    DDP_HIP(hipMemcpyAsync(cx, dcx, n * N * B * 8, hipMemcpyDeviceToHost, h->stream));
+    DDP_HIP(hipMemcpyAsync(cu, dcu, m * N * B * 8, hipMemcpyDeviceToHost, h->stream));
+    if (pend && fx) DDP_HIP(hipMemcpyAsync(fx, dfx, n * n * N * B * 8, hipMemcpyDeviceToHost, h->stream));
+    if (pend && fu) DDP_HIP(hipMemcpyAsync(fu, dfu, n * m * N * B * 8, hipMemcpyDeviceToHost, h->stream));
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,261 @@
+// forward_pass.hip — batched closed-loop rollout / line-search candidates for gfx950.
+//
+// Replaces  forward_pass(traj_new,x0,u,x,α,f,costfun,lims,diff)  (src/forward_pass.jl:9-33) for the
+// registered problem families (the Julia closures f / costfun cannot run on the device):
+//   LQ        f: src/demo_linear.jl:42-46,  costfun: src/demo_linear.jl:49
+//   pendcart  f: src/system_pendcart.jl:83-89, costfun: src/system_pendcart.jl:97-106
+// All nalpha step sizes of the serial backtracking search (src/iLQG.jl:267-281) are rolled out
+// concurrently; the caller picks the FIRST α (list order) that passes the acceptance test, which is
+// what the serial loop returns.
+//
+// Mapping: a group of G lanes (G = 4/16/32/64 >= n) owns one (trajectory, α) rollout, 64/G rollouts
+// per wavefront.  Lane j of a group holds x̂_j; per time step the state is exchanged through LDS once
+// (one wave-level hand-off), every lane forms the m controls redundantly (so no second exchange is
+// needed), then lane j forms row j of the dynamics.  The step-(i+1) operands K,k,x,u are fetched while
+// step i computes.  The time loop is a strict dependency chain: throughput comes from the
+// (trajectory, α) batch, not from the horizon.
+#include "ddp_internal.h"
+
+namespace {
+
+struct FPArgs {
+    int n, m, N, B, nalpha;
+    int dyn_tv, dyn_batched, has_policy, has_lims;
+    const double *A, *Bm, *Q, *R, *K, *k, *x0, *u, *x, *lims;
+    const int32_t *active;
+    double alpha[16];
+    double g, l, h, d, goal[4];
+    double *xnew, *unew, *cnew, *csum;
+};
+
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, G);
+    return v;
+}
+
+template <int KIND, int NS, int MS, int G>
+__global__ __launch_bounds__(DDP_WAVE) void forward_pass_kernel(FPArgs a)
+{
+    constexpr int NMAX = NS ? NS : G;
+    constexpr int MM = MS ? MS : DDP_MAX_M;
+    constexpr bool PF = NS != 0;          // register prefetch of K_i, x_i only for compiled sizes
+    constexpr int KP = PF ? MM * NMAX : 1, XP = PF ? NMAX : 1;
+    constexpr int GPW = DDP_WAVE / G;                         // rollouts per wavefront
+    const int n = NS ? NS : a.n, m = MS ? MS : a.m, N = a.N, B = a.B;
+    const int lane = threadIdx.x, grp = lane / G, jl = lane % G;
+    const long total = (long)B * a.nalpha;
+    long rho = (long)blockIdx.x * GPW + grp;
+    const bool valid = rho < total;
+    if (!valid) rho = total - 1;                              // keep the wave converged; stores are masked
+    const int b = (int)(rho % B), ai = (int)(rho / B);
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    const double alpha = a.alpha[ai];
+    const int CL = (KIND == DDP_PROBLEM_PENDCART) ? N + 1 : N;
+
+    __shared__ double xs[GPW][G];
+
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    const double *ug = a.u + (size_t)m * N * b;
+    const double *xg = a.has_policy ? a.x + (size_t)n * N * b : nullptr;
+    const double *Kg = a.has_policy ? a.K + nm * N * b : nullptr;
+    const double *kg = a.has_policy ? a.k + (size_t)m * N * b : nullptr;
+    double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai);
+    double *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
+    double *co = a.cnew + (size_t)CL * ((size_t)b + (size_t)B * ai);
+
+    // loop-invariant rows (LTI): row jl of A, B, Q
+    double Arow[NMAX], Brow[MM], Qrow[NMAX], Rm[MM * MM], lo[MM], hi[MM];
+    const double *Ab = nullptr, *Bb = nullptr;
+    if (KIND == DDP_PROBLEM_LQ) {
+        Ab = a.A + (a.dyn_batched ? nn * (a.dyn_tv ? N : 1) * b : 0);
+        Bb = a.Bm + (a.dyn_batched ? nm * (a.dyn_tv ? N : 1) * b : 0);
+    }
+#pragma unroll
+    for (int l = 0; l < NMAX; ++l) {
+        const bool in = (jl < n && l < n);
+        Arow[l] = (KIND == DDP_PROBLEM_LQ && !a.dyn_tv && in) ? Ab[jl + n * l] : 0.0;
+        Qrow[l] = in ? a.Q[jl + n * l] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < MM; ++q) {
+        Brow[q] = (KIND == DDP_PROBLEM_LQ && !a.dyn_tv && jl < n && q < m) ? Bb[jl + n * q] : 0.0;
+        lo[q] = (a.has_lims && q < m) ? a.lims[q] : 0.0;
+        hi[q] = (a.has_lims && q < m) ? a.lims[q + m] : 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < MM; ++q2) Rm[q + MM * q2] = (q < m && q2 < m) ? a.R[q + m * q2] : 0.0;
+    }
+
+    double xh = (jl < n) ? a.x0[(size_t)n * b + jl] : 0.0;
+    double csum = 0.0;
+
+    // operands of step i, fetched one step ahead
+    double uc[MM], kc[MM], Kc[KP], xc[XP];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int q = 0; q < MM; ++q) {
+            uc[q] = (q < m) ? ug[(size_t)m * i + q] : 0.0;
+            kc[q] = (a.has_policy && q < m) ? kg[(size_t)m * i + q] : 0.0;
+        }
+        if (PF && a.has_policy) {
+#pragma unroll
+            for (int l = 0; l < NMAX; ++l) {
+                xc[l] = (l < n) ? xg[(size_t)n * i + l] : 0.0;
+#pragma unroll
+                for (int q = 0; q < MM; ++q) Kc[q + MM * l] = (q < m && l < n) ? Kg[nm * i + q + m * l] : 0.0;
+            }
+        }
+        if (KIND == DDP_PROBLEM_LQ && a.dyn_tv) {
+#pragma unroll
+            for (int l = 0; l < NMAX; ++l) Arow[l] = (jl < n && l < n) ? Ab[nn * i + jl + n * l] : 0.0;
+#pragma unroll
+            for (int q = 0; q < MM; ++q) Brow[q] = (jl < n && q < m) ? Bb[nm * i + jl + n * q] : 0.0;
+        }
+    };
+
+    double un[MM], kn[MM], Kn[KP], xn_[XP], An[NMAX], Bn[MM];
+    fetch(0);
+    for (int i = 0; i < N; ++i) {
+        // stash step i's operands, start fetching step i+1 (lands during the dependent chain below)
+#pragma unroll
+        for (int q = 0; q < MM; ++q) { un[q] = uc[q]; kn[q] = kc[q]; Bn[q] = Brow[q]; }
+#pragma unroll
+        for (int l = 0; l < NMAX; ++l) {
+            An[l] = Arow[l];
+            if (PF) {
+                xn_[l] = xc[l];
+#pragma unroll
+                for (int q = 0; q < MM; ++q) Kn[q + MM * l] = Kc[q + MM * l];
+            }
+        }
+        if (i + 1 < N) fetch(i + 1);
+
+        xs[grp][jl] = xh;
+        __syncthreads();
+        double xv[NMAX];
+#pragma unroll
+        for (int l = 0; l < NMAX; ++l) xv[l] = (l < n) ? xs[grp][l] : 0.0;
+
+        // ---- controls (forward_pass.jl:17-24), every lane of the group redundantly
+        double uu[MM];
+#pragma unroll
+        for (int q = 0; q < MM; ++q) {
+            double v = un[q];
+            if (a.has_policy) {
+                v += kn[q] * alpha;                                  // unew .+= k*α
+                double s = 0.0;
+#pragma unroll
+                for (int l = 0; l < NMAX; ++l) {
+                    if (PF) s += Kn[q + MM * l] * (xv[l] - xn_[l]);
+                    else if (l < n && q < m) s += Kg[nm * i + q + m * l] * (xv[l] - xg[(size_t)n * i + l]);
+                }
+                v += s;                                              // unew .+= K*dx
+            }
+            if (a.has_lims) v = clampd(v, lo[q], hi[q]);
+            if (v != v) v = 0.0;                                     // u[isnan.(u)] .= 0 inside f
+            uu[q] = (q < m) ? v : 0.0;
+        }
+        // ---- dynamics row jl and this lane's share of the cost
+        double xnext = 0.0, cpart = 0.0;
+        if (KIND == DDP_PROBLEM_LQ) {
+            double s = 0.0, t = 0.0, qx = 0.0;
+#pragma unroll
+            for (int l = 0; l < NMAX; ++l) { s += An[l] * xv[l]; qx += Qrow[l] * xv[l]; }
+#pragma unroll
+            for (int q = 0; q < MM; ++q) t += Bn[q] * uu[q];
+            xnext = s + t;                                           // A*x + B*u
+            cpart = 0.5 * xh * qx;                                   // .5 x.*(Q*x), row jl
+            if (jl == 0) {
+                double ru = 0.0;
+#pragma unroll
+                for (int q = 0; q < MM; ++q) {
+                    double r = 0.0;
+#pragma unroll
+                    for (int q2 = 0; q2 < MM; ++q2) r += Rm[q + MM * q2] * uu[q2];
+                    ru += uu[q] * r;
+                }
+                cpart += 0.5 * ru;
+            }
+        } else {
+            const double gl = a.g / a.l, h = a.h;
+            if (jl == 0) xnext = xv[0] + h * xv[1];
+            else if (jl == 1) xnext = xv[1] + h * (-gl * sin(xv[0]) + uu[0] / a.l * cos(xv[0]) - a.d * xv[1]);
+            else if (jl == 2) xnext = xv[2] + h * xv[3];
+            else xnext = xv[3] + h * uu[0];
+            double qd = 0.0;
+#pragma unroll
+            for (int l = 0; l < NMAX; ++l) qd += Qrow[l] * (xv[l] - a.goal[l < 4 ? l : 0]);
+            cpart = 0.5 * (xh - a.goal[jl < 4 ? jl : 0]) * qd;
+            if (jl == 0) cpart += 0.5 * uu[0] * Rm[0] * uu[0];
+        }
+        const double ci = group_sum<G>(cpart);
+        if (act) {
+            if (jl < n) xo[(size_t)n * i + jl] = xh;
+            if (jl < m) {
+                double v = uu[0];
+#pragma unroll
+                for (int q = 1; q < MM; ++q) v = (jl == q) ? uu[q] : v;
+                uo[(size_t)m * i + jl] = v;
+            }
+            if (jl == 0) co[i] = ci;
+        }
+        csum += ci;
+        if (KIND == DDP_PROBLEM_PENDCART && i == N - 1) {            // c[end] re-counts x[:,N] with u = 0
+            const double cend = group_sum<G>(cpart - ((jl == 0) ? 0.5 * uu[0] * Rm[0] * uu[0] : 0.0));
+            if (act && jl == 0) co[N] = cend;
+            csum += cend;
+        }
+        if (i < N - 1) xh = xnext;                                   // f is also called at i == N, result discarded
+    }
+    if (act && jl == 0) a.csum[(size_t)b + (size_t)B * ai] = csum;
+}
+
+template <int KIND, int NS, int MS, int G>
+int launch_fp(ddp_handle h, const FPArgs &a)
+{
+    const long total = (long)a.B * a.nalpha;
+    const int gpw = DDP_WAVE / G;
+    const dim3 grid((unsigned)((total + gpw - 1) / gpw)), block(DDP_WAVE);
+    hipLaunchKernelGGL((forward_pass_kernel<KIND, NS, MS, G>), grid, block, 0, h->stream, a);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+}   // namespace
+
+int ddp_cost_len(const ddp_problem *p) { return p->kind == DDP_PROBLEM_PENDCART ? p->N + 1 : p->N; }
+
+int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K, const double *k,
+                             const double *x0, const double *u, const double *x, const double *alpha,
+                             int nalpha, const double *lims, const int32_t *active, double *xnew,
+                             double *unew, double *cnew, double *csum)
+{
+    DDP_CHECK(h && p, "forward_pass: null handle/problem");
+    DDP_CHECK(nalpha >= 1 && nalpha <= 16, "forward_pass: nalpha=%d out of [1,16]", nalpha);
+    DDP_CHECK((K == nullptr) == (k == nullptr), "forward_pass: K and k must both be given or both NULL");
+    DDP_CHECK(!K || x, "forward_pass: a non-empty policy needs the nominal trajectory x");
+    DDP_CHECK(p->m <= DDP_MAX_M && p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d unsupported (n<=%d, m<=%d)", p->n, p->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
+    FPArgs a;
+    a.n = p->n; a.m = p->m; a.N = p->N; a.B = p->B; a.nalpha = nalpha;
+    a.dyn_tv = p->dyn_tv; a.dyn_batched = p->dyn_batched; a.has_policy = K != nullptr; a.has_lims = lims != nullptr;
+    a.A = p->A; a.Bm = p->Bm; a.Q = p->Q; a.R = p->R; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.lims = lims;
+    a.active = active;
+    for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
+    a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
+    for (int i = 0; i < 4; ++i) a.goal[i] = p->goal[i];
+    a.xnew = xnew; a.unew = unew; a.cnew = cnew; a.csum = csum;
+    if (p->kind == DDP_PROBLEM_PENDCART) {
+        DDP_CHECK(p->n == 4 && p->m == 1, "forward_pass: pendcart needs n=4, m=1");
+        return launch_fp<DDP_PROBLEM_PENDCART, 4, 1, 4>(h, a);
+    }
+    DDP_CHECK(p->kind == DDP_PROBLEM_LQ, "forward_pass: unknown problem kind %d", p->kind);
+    if (p->n == 10 && p->m == 2) return launch_fp<DDP_PROBLEM_LQ, 10, 2, 16>(h, a);
+    if (p->n == 4 && p->m == 1) return launch_fp<DDP_PROBLEM_LQ, 4, 1, 4>(h, a);
+    if (p->n == 6 && p->m == 3) return launch_fp<DDP_PROBLEM_LQ, 6, 3, 8>(h, a);
+    if (p->n <= 16) return launch_fp<DDP_PROBLEM_LQ, 0, 0, 16>(h, a);
+    return launch_fp<DDP_PROBLEM_LQ, 0, 0, 32>(h, a);
+}

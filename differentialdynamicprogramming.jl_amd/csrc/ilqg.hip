@@ -1,0 +1,361 @@
+// ilqg.hip — device-resident iLQG iteration for registered problem families.
+//
+// Replaces the outer loop of  iLQG(f,costfun,df,x0,u0; ...)  (src/iLQG.jl:143-341).  Every trajectory
+// of the batch is an independent solve with its own scalar state machine (λ, dλ, iter, accepted_iter,
+// status) held in device memory; one "global iteration" runs, for the trajectories that need it,
+//   STEP 1  df            (df.hip)                    iLQG.jl:225-229
+//   STEP 2  back_pass     (back_pass.hip)             iLQG.jl:235-251   (a diverged trajectory only
+//                                                     updates λ here and retries next global iteration)
+//           g_norm / gradient exit                    iLQG.jl:254-261
+//   STEP 3  all-α line-search rollouts (forward_pass.hip), first α in list order that passes  :264-283
+//   STEP 4  accept / reject, λ schedule, termination  iLQG.jl:293-323
+// The host only launches kernels and polls one counter (number of running trajectories) per global
+// iteration.  The λ-schedule quirks of the reference are kept: the increase uses the OLD dλ
+// (tuple assignment, :246,:313), the decrease the NEW one (:299-300), λ never drops below λmin.
+#include <vector>
+#include "ddp_internal.h"
+
+namespace {
+
+struct Traj {           // per-trajectory scalar state (structure of arrays in one allocation)
+    double *lam, *dlam, *gnorm, *csum;
+    int32_t *status, *iter, *acc, *nbp, *nfp, *flg, *run, *dodf, *dofwd, *div0;
+};
+
+struct Opt {
+    double lfac, lmax, lmin, tol_fun, tol_grad, rrmin;
+    int max_iter, nalpha;
+    double alpha[16];
+};
+
+__global__ void init_state_kernel(int B, double lam0, double dlam0, Traj s)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    s.lam[b] = lam0; s.dlam[b] = dlam0; s.gnorm[b] = 0.0; s.csum[b] = 0.0;
+    s.status[b] = DDP_EXIT_RUNNING; s.iter[b] = 1; s.acc[b] = 1; s.nbp[b] = 0; s.nfp[b] = 0;
+    s.flg[b] = 1; s.run[b] = 1; s.dodf[b] = 1; s.dofwd[b] = 0; s.div0[b] = 1;
+}
+
+// u_scaled = α·u0 for the initial rollout (iLQG.jl:185)
+__global__ void scale_kernel(size_t per, int B, double a, const double *u0, const int32_t *act, double *out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per * B) return;
+    if (act[t / per]) out[t] = a * u0[t];
+}
+
+// initial rollout check: all(abs.(x) .< 1e8)  (iLQG.jl:187) — one wave per trajectory
+__global__ __launch_bounds__(64) void init_check_kernel(int n, int m, int N, int CL, const double *xc, const double *uc,
+                                                        const double *cc, const double *csum, Traj s, double *x, double *u,
+                                                        double *cost)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!s.div0[b]) return;
+    const double *xb = xc + (size_t)n * N * b;
+    int bad = 0;
+    for (size_t e = lane; e < (size_t)n * N; e += 64) bad |= !(fabs(xb[e]) < 1e8);
+    bad = __any(bad);
+    if (bad) return;
+    for (size_t e = lane; e < (size_t)n * N; e += 64) x[(size_t)n * N * b + e] = xb[e];
+    for (size_t e = lane; e < (size_t)m * N; e += 64) u[(size_t)m * N * b + e] = uc[(size_t)m * N * b + e];
+    for (size_t e = lane; e < (size_t)CL; e += 64) cost[(size_t)CL * b + e] = cc[(size_t)CL * b + e];
+    if (lane == 0) { s.div0[b] = 0; s.csum[b] = csum[b]; }
+}
+
+__global__ void count_ok_kernel(int B, Traj s, int *counter)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && !s.div0[b]) atomicAdd(counter, 1);
+}
+
+__global__ void init_finish_kernel(int B, Traj s, int *counter)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (s.div0[b]) { s.status[b] = DDP_EXIT_INIT_DIVERGED; s.run[b] = 0; s.dodf[b] = 0; }   // iLQG.jl:205-210
+    else atomicAdd(counter, 1);
+}
+
+// after back_pass: λ update on divergence, g_norm, gradient exit  (iLQG.jl:244-261) — one wave per trajectory
+__global__ __launch_bounds__(64) void post_bp_kernel(int m, int N, Opt o, const int32_t *diverge, const double *k,
+                                                     const double *u, Traj s)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!s.run[b]) return;
+    // g_norm = mean(maximum(abs.(k) ./ (abs.(u) .+ 1), dims=1))   (:256)
+    const double *kb = k + (size_t)m * N * b, *ub = u + (size_t)m * N * b;
+    double acc = 0.0;
+    for (int t = lane; t < N; t += 64) {
+        double mx = 0.0;
+        for (int a = 0; a < m; ++a) {
+            const double r = fabs(kb[(size_t)m * t + a]) / (fabs(ub[(size_t)m * t + a]) + 1.0);
+            if (a == 0 || r > mx || r != r) mx = r;
+        }
+        acc += mx;
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane != 0) return;
+    const double g_norm = acc / N;
+    s.gnorm[b] = g_norm;
+    s.nbp[b] += 1;
+    double lam = s.lam[b], dlam = s.dlam[b];
+    int dofwd = 0, status = DDP_EXIT_RUNNING;
+    if (diverge[b] > 0) {
+        const double dl = dlam;                                       // tuple assignment (:246)
+        dlam = fmax(dl * o.lfac, o.lfac);
+        lam = fmax(lam * dl, o.lmin);
+        if (lam > o.lmax) {
+            // inner loop left with back_pass_done == false: no line search, the "no step" branch raises
+            // λ once more and terminates (:311-322)
+            const double dl2 = dlam;
+            dlam = fmax(dl2 * o.lfac, o.lfac);
+            lam = fmax(lam * dl2, o.lmin);
+            status = DDP_EXIT_LAMBDA;
+        }
+        // else: retry the backward pass with the larger λ in the next global iteration (`continue`)
+    } else {
+        if (g_norm < o.tol_grad && lam < 1e-5) status = DDP_EXIT_GRAD;    // :258-261
+        else dofwd = 1;
+    }
+    s.lam[b] = lam; s.dlam[b] = dlam;
+    s.dofwd[b] = dofwd;
+    s.dodf[b] = 0;
+    if (status != DDP_EXIT_RUNNING) { s.status[b] = status; s.run[b] = 0; }
+}
+
+// STEP 3 selection + STEP 4 (iLQG.jl:267-331) — one wave per trajectory
+__global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, int CL, Opt o, const double *dV,
+                                                    const double *xnew, const double *unew, const double *cnew,
+                                                    const double *csumnew, Traj s, double *x, double *u, double *cost,
+                                                    double *k, int trace_cap, double *trace_cost, int *counter)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!s.run[b]) return;
+    if (!s.dofwd[b]) {            // diverged back_pass, retrying: nothing to do this round
+        if (lane == 0) atomicAdd(counter, 1);
+        return;
+    }
+    const double c0 = s.csum[b], dV0 = dV[2 * b], dV1 = dV[2 * b + 1];
+    int sel = -1;
+    double dcost = 0.0;
+    for (int ai = 0; ai < o.nalpha; ++ai) {                            // serial order of the reference
+        const double a = o.alpha[ai];
+        dcost = c0 - csumnew[(size_t)b + (size_t)B * ai];
+        const double expected = -a * (dV0 + a * dV1);
+        double z;
+        if (expected > 0) z = dcost / expected;
+        else z = (dcost > 0) ? 1.0 : ((dcost < 0) ? -1.0 : dcost);    // sign(Δcost) (NaN stays NaN)
+        if (z > o.rrmin) { sel = ai; break; }
+    }
+    double lam = s.lam[b], dlam = s.dlam[b];
+    int status = DDP_EXIT_RUNNING, acc = s.acc[b];
+    if (sel >= 0) {                                                    // :293-310
+        dlam = fmin(dlam / o.lfac, 1.0 / o.lfac);
+        lam = fmax(lam * dlam, o.lmin);
+        const size_t src = (size_t)b + (size_t)B * sel;
+        for (size_t e = lane; e < (size_t)n * N; e += 64) x[(size_t)n * N * b + e] = xnew[(size_t)n * N * src + e];
+        for (size_t e = lane; e < (size_t)m * N; e += 64) {
+            const double v = unew[(size_t)m * N * src + e];
+            u[(size_t)m * N * b + e] = v;
+            k[(size_t)m * N * b + e] = v;                              // traj_new.k = copy(u)  (:303)
+        }
+        for (size_t e = lane; e < (size_t)CL; e += 64) cost[(size_t)CL * b + e] = cnew[(size_t)CL * src + e];
+        if (dcost < o.tol_fun) status = DDP_EXIT_COST;                 // :306-309
+        else acc += 1;
+    } else {                                                           // :311-323
+        const double dl = dlam;
+        dlam = fmax(dl * o.lfac, o.lfac);
+        lam = fmax(lam * dl, o.lmin);
+        if (lam > o.lmax) status = DDP_EXIT_LAMBDA;
+    }
+    if (lane != 0) return;
+    s.nfp[b] += (sel >= 0) ? sel + 1 : o.nalpha;
+    s.lam[b] = lam; s.dlam[b] = dlam; s.acc[b] = acc;
+    if (sel >= 0) { s.csum[b] = csumnew[(size_t)b + (size_t)B * sel]; s.flg[b] = 1; }
+    if (status == DDP_EXIT_RUNNING) {
+        const int it = s.iter[b];
+        if (trace_cost && it - 1 < trace_cap) trace_cost[(size_t)trace_cap * b + (it - 1)] = s.csum[b];   // :329
+        s.iter[b] = it + 1;
+        if (acc > o.max_iter) status = DDP_EXIT_MAXITER;               // while accepted_iter <= max_iter (:222)
+    }
+    if (status != DDP_EXIT_RUNNING) { s.status[b] = status; s.run[b] = 0; s.dodf[b] = 0; }
+    else { s.dodf[b] = (sel >= 0) ? 1 : 0; atomicAdd(counter, 1); }
+    s.dofwd[b] = 0;
+}
+
+__global__ void stats_kernel(int B, Traj s, double *stats)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double *r = stats + (size_t)DDP_ILQG_NSTATS * b;
+    r[0] = s.status[b]; r[1] = s.iter[b]; r[2] = s.acc[b]; r[3] = s.nbp[b]; r[4] = s.nfp[b];
+    r[5] = s.lam[b]; r[6] = s.gnorm[b]; r[7] = s.csum[b];
+}
+
+}   // namespace
+
+extern "C" {
+
+void ddp_ilqg_default_opts(ddp_ilqg_opts *o)
+{   // iLQG.jl:143-163
+    o->lambda = 1.0; o->dlambda = 1.0; o->lambda_factor = 1.6; o->lambda_max = 1e10; o->lambda_min = 1e-6;
+    o->tol_fun = 1e-7; o->tol_grad = 1e-4; o->max_iter = 500; o->regType = 1; o->reduce_ratio_min = 0.0;
+    o->n_alpha = 11;
+    for (int i = 0; i < 16; ++i) o->alpha[i] = i < 11 ? pow(10.0, -3.0 * i / 10.0) : 0.0;
+}
+
+int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, const double *x0, const double *u0,
+                     const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx,
+                     double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+{
+    DDP_CHECK(h && p && x0 && u0 && x && u && K && k && Quu && Vx && Vxx && cost && stats, "ilqg: null argument");
+    ddp_ilqg_opts od;
+    if (!oo) { ddp_ilqg_default_opts(&od); oo = &od; }
+    DDP_CHECK(oo->n_alpha >= 1 && oo->n_alpha <= 16, "ilqg: n_alpha=%d out of [1,16]", oo->n_alpha);
+    const size_t n = p->n, m = p->m, N = p->N, B = p->B, na = oo->n_alpha, CL = ddp_cost_len(p);
+    const bool pend = p->kind == DDP_PROBLEM_PENDCART;
+
+    // ---- workspace (device): derivatives, candidates, scalar state
+    size_t bytes = 0;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t s_cx = al(n * N * B * 8), s_cu = al(m * N * B * 8), s_fx = pend ? al(n * n * N * B * 8) : 0,
+                 s_fu = pend ? al(n * m * N * B * 8) : 0, s_xn = al(n * N * B * na * 8), s_un = al(m * N * B * na * 8),
+                 s_cn = al(CL * B * na * 8), s_cs = al(B * na * 8), s_dV = al(2 * B * 8), s_div = al(B * 4),
+                 s_cxu = al(n * m * 8), s_us = al(m * N * B * 8), s_d = al(B * 8), s_i = al(B * 4);
+    bytes = s_cx + s_cu + s_fx + s_fu + s_xn + s_un + s_cn + s_cs + s_dV + s_div + s_cxu + s_us + 4 * s_d + 10 * s_i + 256;
+    void *base;
+    int rc = ddp_scratch(h, bytes, &base);
+    if (rc) return rc;
+    char *pp = (char *)base;
+    auto take = [&](size_t b) { void *r = pp; pp += b; return r; };
+    double *cx = (double *)take(s_cx), *cu = (double *)take(s_cu), *fxw = pend ? (double *)take(s_fx) : nullptr,
+           *fuw = pend ? (double *)take(s_fu) : nullptr, *xn = (double *)take(s_xn), *un = (double *)take(s_un),
+           *cn = (double *)take(s_cn), *cs = (double *)take(s_cs), *dV = (double *)take(s_dV);
+    int32_t *div = (int32_t *)take(s_div);
+    double *cxu = (double *)take(s_cxu), *us = (double *)take(s_us);
+    Traj s;
+    s.lam = (double *)take(s_d); s.dlam = (double *)take(s_d); s.gnorm = (double *)take(s_d); s.csum = (double *)take(s_d);
+    s.status = (int32_t *)take(s_i); s.iter = (int32_t *)take(s_i); s.acc = (int32_t *)take(s_i); s.nbp = (int32_t *)take(s_i);
+    s.nfp = (int32_t *)take(s_i); s.flg = (int32_t *)take(s_i); s.run = (int32_t *)take(s_i); s.dodf = (int32_t *)take(s_i);
+    s.dofwd = (int32_t *)take(s_i); s.div0 = (int32_t *)take(s_i);
+    int *counter = (int *)take(256);
+    DDP_CHECK(h->h_pinned, "ilqg: pinned poll buffer missing");
+
+    Opt o;
+    o.lfac = oo->lambda_factor; o.lmax = oo->lambda_max; o.lmin = oo->lambda_min; o.tol_fun = oo->tol_fun;
+    o.tol_grad = oo->tol_grad; o.rrmin = oo->reduce_ratio_min; o.max_iter = oo->max_iter; o.nalpha = (int)na;
+    for (int i = 0; i < 16; ++i) o.alpha[i] = oo->alpha[i];
+
+    hipStream_t st = h->stream;
+    const unsigned gB = (unsigned)((B + 255) / 256);
+    hipLaunchKernelGGL(init_state_kernel, dim3(gB), dim3(256), 0, st, (int)B, oo->lambda, oo->dlambda, s);
+    DDP_HIP(hipMemsetAsync(cxu, 0, n * m * 8, st));
+    DDP_HIP(hipMemsetAsync(K, 0, m * n * N * B * 8, st));
+    DDP_HIP(hipMemsetAsync(k, 0, m * N * B * 8, st));
+    DDP_HIP(hipMemsetAsync(Quu, 0, m * m * N * B * 8, st));
+    DDP_HIP(hipMemsetAsync(Vx, 0, n * N * B * 8, st));
+    DDP_HIP(hipMemsetAsync(Vxx, 0, n * n * N * B * 8, st));
+    DDP_HIP(hipMemsetAsync(x, 0, n * N * B * 8, st));
+    DDP_HIP(hipMemsetAsync(u, 0, m * N * B * 8, st));
+    DDP_HIP(hipMemsetAsync(cost, 0, CL * B * 8, st));
+    if (trace_cost && trace_cap > 0) DDP_HIP(hipMemsetAsync(trace_cost, 0, (size_t)trace_cap * B * 8, st));
+
+    // ---- initial trajectory (iLQG.jl:181-192): first α for which the open-loop rollout of α·u0 stays bounded
+    const double one = 1.0;
+    for (size_t ai = 0; ai < na; ++ai) {
+        const size_t tot = m * N * B;
+        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m * N, (int)B, oo->alpha[ai], u0,
+                           s.div0, us);
+        rc = ddp_forward_pass_f64_dev(h, p, nullptr, nullptr, x0, us, nullptr, &one, 1, lims, s.div0, xn, un, cn, cs);
+        if (rc) return rc;
+        hipLaunchKernelGGL(init_check_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, xn, un, cn, cs, s,
+                           x, u, cost);
+        // most batches are done after the first α; poll only if there are more candidates to try
+        if (ai + 1 < na) {
+            DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
+            hipLaunchKernelGGL(count_ok_kernel, dim3(gB), dim3(256), 0, st, (int)B, s, counter);
+            DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
+            DDP_HIP(hipStreamSynchronize(st));
+            if (h->h_pinned[0] == (int)B) break;
+        }
+    }
+    DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
+    hipLaunchKernelGGL(init_finish_kernel, dim3(gB), dim3(256), 0, st, (int)B, s, counter);
+    DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
+    DDP_HIP(hipStreamSynchronize(st));
+    int running = h->h_pinned[0];
+
+    ddp_bp_desc d;
+    d.n = (int)n; d.m = (int)m; d.N = (int)N; d.B = (int)B;
+    d.fx_tv = pend ? 1 : p->dyn_tv; d.fx_batched = pend ? 1 : p->dyn_batched;
+    d.cost_tv = 0; d.cost_batched = 0; d.regType = oo->regType; d.has_lims = lims != nullptr;
+    const double *fx = pend ? fxw : p->A, *fu = pend ? fuw : p->Bm;
+
+    int git = 0;
+    const long hard_cap = 4L * oo->max_iter + 1000;      // every global iteration advances iter or λ of each running trajectory
+    while (running > 0 && git < hard_cap) {
+        rc = ddp_df_f64_dev(h, p, x, u, s.dodf, cx, cu, fxw, fuw);                                  // STEP 1
+        if (rc) return rc;
+        rc = ddp_launch_back_pass(h, &d, cx, cu, p->Q, cxu, p->R, fx, fu, s.lam, lims, u, s.run, K, k, Quu, Vx, Vxx, dV, div);   // STEP 2
+        if (rc) return rc;
+        hipLaunchKernelGGL(post_bp_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)m, (int)N, o, div, k, u, s);
+        rc = ddp_forward_pass_f64_dev(h, p, K, k, x0, u, x, o.alpha, (int)na, lims, s.dofwd, xn, un, cn, cs);   // STEP 3
+        if (rc) return rc;
+        DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
+        hipLaunchKernelGGL(accept_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)B, (int)CL, o, dV, xn,
+                           un, cn, cs, s, x, u, cost, k, trace_cap, trace_cost, counter);            // STEP 4
+        DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
+        DDP_HIP(hipStreamSynchronize(st));
+        running = h->h_pinned[0];
+        ++git;
+    }
+    hipLaunchKernelGGL(stats_kernel, dim3(gB), dim3(256), 0, st, (int)B, s, stats);
+    DDP_HIP(hipGetLastError());
+    DDP_HIP(hipStreamSynchronize(st));
+    if (global_iters) *global_iters = git;
+    return 0;
+}
+
+int ddp_ilqg_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, const double *x0, const double *u0,
+                 const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                 double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+{
+    DDP_CHECK(h && p && x0 && u0, "ilqg: null argument");
+    const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p);
+    const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? B : 1);
+    // the driver uses the handle's scratch itself, so the host flavour owns separate allocations
+    struct Buf { void *d; void *hdst; size_t bytes; };
+    std::vector<Buf> bufs;
+    bool failed = false;
+    auto dev = [&](const void *src, void *dst, size_t bytes) -> void * {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) { failed = true; return nullptr; }
+        if (src && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) failed = true;
+        bufs.push_back({d, dst, bytes});
+        return d;
+    };
+    ddp_problem pd = *p;
+    if (p->kind == DDP_PROBLEM_LQ) { pd.A = (double *)dev(p->A, nullptr, n * n * dc * 8); pd.Bm = (double *)dev(p->Bm, nullptr, n * m * dc * 8); }
+    pd.Q = (double *)dev(p->Q, nullptr, n * n * 8);
+    pd.R = (double *)dev(p->R, nullptr, m * m * 8);
+    double *dx0 = (double *)dev(x0, nullptr, n * B * 8), *du0 = (double *)dev(u0, nullptr, m * N * B * 8),
+           *dl = lims ? (double *)dev(lims, nullptr, 2 * m * 8) : nullptr;
+    double *dx = (double *)dev(nullptr, x, n * N * B * 8), *du = (double *)dev(nullptr, u, m * N * B * 8),
+           *dK = (double *)dev(nullptr, K, m * n * N * B * 8), *dk = (double *)dev(nullptr, k, m * N * B * 8),
+           *dQuu = (double *)dev(nullptr, Quu, m * m * N * B * 8), *dVx = (double *)dev(nullptr, Vx, n * N * B * 8),
+           *dVxx = (double *)dev(nullptr, Vxx, n * n * N * B * 8), *dcost = (double *)dev(nullptr, cost, CL * B * 8),
+           *dstats = (double *)dev(nullptr, stats, DDP_ILQG_NSTATS * B * 8),
+           *dtr = (trace_cost && trace_cap > 0) ? (double *)dev(nullptr, trace_cost, (size_t)trace_cap * B * 8) : nullptr;
+    int rc = failed ? -2 : 0;
+    if (failed) ddp_set_error("ilqg: device allocation / upload failed");
+    if (!rc) rc = ddp_ilqg_f64_dev(h, &pd, o, dx0, du0, dl, dx, du, dK, dk, dQuu, dVx, dVxx, dcost, dstats, trace_cap, dtr, global_iters);
+    if (!rc)
+        for (auto &bf : bufs)
+            if (bf.hdst && hipMemcpyAsync(bf.hdst, bf.d, bf.bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = -2;
+    hipStreamSynchronize(h->stream);
+    for (auto &bf : bufs) hipFree(bf.d);
+    return rc;
+}
+
+}   // extern "C"

@@ -1,0 +1,203 @@
+/*
+ * ddp_amd.h — C ABI of libddp_amd.so: the MI355X (gfx950) implementation of the iLQG hot path of
+ * baggepinnen/DifferentialDynamicProgramming.jl v0.5.0 (back_pass / boxQP / forward_pass and the
+ * iLQG iteration around them), batched over B independent trajectories.
+ *
+ * The reference has no FFI for this path (it is plain Julia); each entry point below replaces the
+ * Julia function cited next to it and is what a Julia `@ccall` wrapper (INTEGRATION.md,
+ * differentialdynamicprogramming.jl_amd/julia/DDPAmd.jl) or any other host binds.
+ *
+ * Conventions
+ *  - every array is fp64, Julia column-major, batch index slowest:  K[m,n,N,B]  is  B  copies of the
+ *    reference's  K[m,n,N]  back to back, so B == 1 accepts the reference's arrays unchanged;
+ *  - `_dev` entry points take DEVICE pointers (caller-owned, never freed here) and are asynchronous
+ *    on the handle's HIP stream; the plain entry points take HOST pointers, copy H2D, run, copy D2H
+ *    and synchronise;
+ *  - return value: 0 = ok, < 0 = argument or HIP error (text via ddp_last_error()).  Numerical failure
+ *    is NOT an error: it is reported per trajectory in `diverge` (backward_pass.jl:37-38,53-56) and
+ *    `result` (boxQP.jl:172-179) exactly like the reference;
+ *  - one handle = one HIP stream + scratch; a handle is not thread-safe, distinct handles are.
+ *  - there is NO CPU fallback: without a gfx950 device ddp_create() fails.
+ */
+#ifndef DDP_AMD_H
+#define DDP_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ddp_handle_s *ddp_handle;
+
+/* ---- library / handle --------------------------------------------------------------------- */
+const char *ddp_last_error(void);
+const char *ddp_version(void);
+int  ddp_device_count(void);
+int  ddp_create(int device, ddp_handle *out);
+int  ddp_destroy(ddp_handle h);
+int  ddp_sync(ddp_handle h);
+void *ddp_stream(ddp_handle h);                 /* the hipStream_t of the handle */
+/* device memory helpers for hosts without their own allocator (the Julia wrapper, tests) */
+int  ddp_malloc(ddp_handle h, size_t bytes, void **dptr);
+int  ddp_free(ddp_handle h, void *dptr);
+int  ddp_memcpy_h2d(ddp_handle h, void *dst, const void *src, size_t bytes);   /* synchronous */
+int  ddp_memcpy_d2h(ddp_handle h, void *dst, const void *src, size_t bytes);   /* synchronous */
+int  ddp_memset(ddp_handle h, void *dst, int value, size_t bytes);             /* async on stream */
+/* HIP events on the handle's stream (bench.py's per-kernel timing) */
+int  ddp_event_create(ddp_handle h, void **ev);
+int  ddp_event_destroy(ddp_handle h, void *ev);
+int  ddp_event_record(ddp_handle h, void *ev);
+int  ddp_event_elapsed_ms(ddp_handle h, void *start, void *stop, float *ms);   /* syncs on `stop` */
+
+/* ---- back_pass — replaces back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u) ---------------
+ * reference: src/backward_pass.jl:217-252 (LTI), :162-177 (LTV, time-invariant cost),
+ *            :179-215 (LTV, time-varying cost), shared tail @end_backward_pass :28-79,
+ *            called from src/iLQG.jl:237.                                                        */
+typedef struct {
+    int n, m, N, B;        /* state dim, control dim, time steps (= size(u,2)), batch              */
+    int fx_tv;             /* 0: fx[n,n], fu[n,m]           1: fx[n,n,N], fu[n,m,N]                */
+    int fx_batched;        /* 0: one fx/fu shared by the batch   1: one per trajectory (batch slowest) */
+    int cost_tv;           /* 0: cxx[n,n], cxu[n,m], cuu[m,m]    1: [..,N]                          */
+    int cost_batched;      /* as fx_batched for cxx/cxu/cuu                                         */
+    int regType;           /* 1 or 2 (backward_pass.jl:245-247)                                     */
+    int has_lims;          /* 0: `lims == []`   1: lims[m,2] given (the lims[1,1] > lims[1,2] test of
+                              backward_pass.jl:31 is applied on the device as well)                 */
+} ddp_bp_desc;
+
+/* inputs : cx[n,N,B] cu[m,N,B]  cxx/cxu/cuu/fx/fu per the flags  lambda[B]  lims[m,2] (shared) u[m,N,B]
+ *          `active` (may be NULL): int32[B]; trajectories with active[b]==0 are skipped entirely
+ * outputs: K[m,n,N,B] k[m,N,B] Quu[m,m,N,B] Vx[n,N,B] Vxx[n,n,N,B] dV[2,B] diverge int32[B]
+ *          (diverge: 0 ok, else the 1-based failing time index; outputs earlier in time than the
+ *          failing step are zero like the reference's zero-initialised arrays)                     */
+int ddp_back_pass_f64_dev(ddp_handle h, const ddp_bp_desc *d,
+                          const double *cx, const double *cu, const double *cxx, const double *cxu,
+                          const double *cuu, const double *fx, const double *fu,
+                          const double *lambda, const double *lims, const double *u,
+                          const int32_t *active,
+                          double *K, double *k, double *Quu, double *Vx, double *Vxx, double *dV,
+                          int32_t *diverge);
+int ddp_back_pass_f64(ddp_handle h, const ddp_bp_desc *d,
+                      const double *cx, const double *cu, const double *cxx, const double *cxu,
+                      const double *cuu, const double *fx, const double *fu,
+                      const double *lambda, const double *lims, const double *u,
+                      double *K, double *k, double *Quu, double *Vx, double *Vxx, double *dV,
+                      int32_t *diverge);
+
+/* ---- boxQP — replaces boxQP(H,g,lower,upper,x0) ------------------------------------------------
+ * reference: src/boxQP.jl:29-188, called from src/backward_pass.jl:49.
+ * `count` independent problems of dimension m (m <= DDP_MAX_M):
+ * H[m,m,count] g/lower/upper/x0[m,count] -> x[m,count] result int32[count]
+ * Hfree[m,m,count] (leading nfree x nfree block = upper Cholesky factor of H[free,free])
+ * free uint8[m,count].                                                                             */
+#define DDP_MAX_M 8
+typedef struct {
+    int    maxIter;        /* 100   */
+    double minGrad;        /* 1e-8  */
+    double minRelImprove;  /* 1e-8  */
+    double stepDec;        /* 0.6   */
+    double minStep;        /* 1e-22 */
+    double Armijo;         /* 0.1   */
+} ddp_qp_opts;
+int ddp_boxqp_f64_dev(ddp_handle h, int m, int count, const double *H, const double *g,
+                      const double *lower, const double *upper, const double *x0,
+                      const ddp_qp_opts *opts /* NULL = defaults */,
+                      double *x, int32_t *result, double *Hfree, uint8_t *free_out);
+int ddp_boxqp_f64(ddp_handle h, int m, int count, const double *H, const double *g,
+                  const double *lower, const double *upper, const double *x0,
+                  const ddp_qp_opts *opts,
+                  double *x, int32_t *result, double *Hfree, uint8_t *free_out);
+
+/* ---- forward_pass — replaces forward_pass(traj_new,x0,u,x,α,f,costfun,lims,diff) ----------------
+ * reference: src/forward_pass.jl:9-33, called from src/iLQG.jl:185,268.
+ * The user closures f / costfun cannot run on the GPU; registered problem families stand in:
+ *   DDP_PROBLEM_LQ        x+ = A x + B u,  cost_i = .5 x_i'Q x_i + .5 u_i'R u_i
+ *                         (src/demo_linear.jl:42-49; cost returned per time step, the sum is the
+ *                          reference's scalar)
+ *   DDP_PROBLEM_PENDCART  explicit-Euler pendulum on a cart (src/system_pendcart.jl:83-89) with
+ *                         cost vector of length N+1 (src/system_pendcart.jl:97-106)               */
+enum { DDP_PROBLEM_LQ = 0, DDP_PROBLEM_PENDCART = 1 };
+typedef struct {
+    int kind;
+    int n, m, N, B;
+    /* LQ */
+    const double *A;       /* [n,n] | [n,n,N] | [n,n,B] | [n,n,N,B] per dyn_tv / dyn_batched        */
+    const double *Bm;      /* [n,m] ...                                                              */
+    int dyn_tv, dyn_batched;
+    const double *Q;       /* [n,n] (shared)                                                         */
+    const double *R;       /* [m,m] (shared)                                                         */
+    /* pendcart (n = 4, m = 1; Q [4,4], R [1,1] above) */
+    double g, l, h, d;
+    double goal[4];
+} ddp_problem;
+
+/* cost vector length per trajectory: LQ -> N, pendcart -> N+1 */
+int ddp_cost_len(const ddp_problem *p);
+
+/* All `nalpha` step sizes are rolled out concurrently (one work-group slice per (trajectory, α)).
+ * inputs : K[m,n,N,B], k[m,N,B] (both NULL = empty policy, forward_pass.jl:17), x0[n,B], u[m,N,B],
+ *          x[n,N,B] (may be NULL with an empty policy), alpha[nalpha] (HOST pointer, <= 16 values),
+ *          lims[m,2] or NULL, active int32[B] or NULL
+ * outputs: xnew[n,N,B,nalpha], unew[m,N,B,nalpha], cnew[CL,B,nalpha], csum[B,nalpha] (= sum(cnew))  */
+int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p,
+                             const double *K, const double *k, const double *x0, const double *u,
+                             const double *x, const double *alpha, int nalpha, const double *lims,
+                             const int32_t *active,
+                             double *xnew, double *unew, double *cnew, double *csum);
+int ddp_forward_pass_f64(ddp_handle h, const ddp_problem *p,
+                         const double *K, const double *k, const double *x0, const double *u,
+                         const double *x, const double *alpha, int nalpha, const double *lims,
+                         double *xnew, double *unew, double *cnew, double *csum);
+
+/* ---- df of the registered families (the `df` closure; STEP 1 of src/iLQG.jl:225-229) -------------
+ * LQ: cx = Q x, cu = R u (src/demo_linear.jl:35-41).  pendcart: also fx[4,4,N,B], fu[4,1,N,B] by
+ * exp of the 5x5 block matrix (src/system_pendcart.jl:137-154).  fx/fu may be NULL for LQ.         */
+int ddp_df_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u,
+                   const int32_t *active, double *cx, double *cu, double *fx, double *fu);
+int ddp_df_f64(ddp_handle h, const ddp_problem *p, const double *x, const double *u,
+               double *cx, double *cu, double *fx, double *fu);
+
+/* ---- iLQG — replaces iLQG(f,costfun,df,x0,u0; lims, ...) for registered families ----------------
+ * reference: src/iLQG.jl:143-341.  Every trajectory of the batch runs its own iLQG (own λ, dλ,
+ * line search, termination) with state resident on the device; the host only launches kernels
+ * and polls one counter per iteration.                                                            */
+typedef struct {
+    double lambda, dlambda, lambda_factor, lambda_max, lambda_min;   /* 1, 1, 1.6, 1e10, 1e-6 */
+    double tol_fun, tol_grad;                                        /* 1e-7, 1e-4            */
+    int    max_iter;                                                 /* 500                   */
+    int    regType;                                                  /* 1                     */
+    double reduce_ratio_min;                                         /* 0                     */
+    int    n_alpha;                                                  /* 11                    */
+    double alpha[16];                                                /* 10^linspace(0,-3,11)  */
+} ddp_ilqg_opts;
+void ddp_ilqg_default_opts(ddp_ilqg_opts *o);
+
+enum {
+    DDP_EXIT_RUNNING       = 0,
+    DDP_EXIT_GRAD          = 1,   /* SUCCESS: gradient norm < tol_grad   (iLQG.jl:258-261) */
+    DDP_EXIT_COST          = 2,   /* SUCCESS: cost change < tol_fun      (iLQG.jl:306-309) */
+    DDP_EXIT_LAMBDA        = 3,   /* EXIT: lambda > lambda_max           (iLQG.jl:319-322) */
+    DDP_EXIT_MAXITER       = 4,   /* while condition exhausted           (iLQG.jl:222)     */
+    DDP_EXIT_INIT_DIVERGED = -1   /* initial control sequence diverged   (iLQG.jl:205-210) */
+};
+
+/* per-trajectory summary, one row per trajectory: stats[8,B] =
+ *   [status, iter, accepted_iter, n_backpass, n_forward, lambda, g_norm, sum(cost)]               */
+#define DDP_ILQG_NSTATS 8
+/* host-pointer flavour. inputs x0[n,B], u0[m,N,B], lims[m,2] or NULL.
+ * outputs x[n,N,B] u[m,N,B] K[m,n,N,B] k[m,N,B] (quirk: after an accepted step L.k is the control
+ * sequence, iLQG.jl:303) Quu[m,m,N,B] Vx[n,N,B] Vxx[n,n,N,B] cost[CL,B] stats[8,B];
+ * trace_cost (may be NULL) [trace_cap,B]: sum(cost) after every iteration (trace(:cost,...)).
+ * `global_iters` (may be NULL) receives the number of batch-level iterations executed.           */
+int ddp_ilqg_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
+                 const double *x0, const double *u0, const double *lims,
+                 double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                 double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
+                     const double *x0, const double *u0, const double *lims,
+                     double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                     double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
