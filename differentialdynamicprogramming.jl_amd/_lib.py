@@ -19,7 +19,7 @@ u8p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
 
 EXPORTS = [
-    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_destroy", "ddp_sync", "ddp_stream",
+    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_stream",
     "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_memset",
     "ddp_event_create", "ddp_event_destroy", "ddp_event_record", "ddp_event_elapsed_ms",
     "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
@@ -87,9 +87,13 @@ def check(rc):
 class Handle:
     """One HIP stream + scratch on one device (ddp_create / ddp_destroy)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """`stream`: optional raw hipStream_t (int) to adopt, e.g. torch.cuda.current_stream().cuda_stream"""
         self._h = vp()
-        check(lib().ddp_create(int(device), C.byref(self._h)))
+        if stream is None:
+            check(lib().ddp_create(int(device), C.byref(self._h)))
+        else:
+            check(lib().ddp_create_with_stream(int(device), vp(stream), C.byref(self._h)))
         self.device = device
 
     def close(self):

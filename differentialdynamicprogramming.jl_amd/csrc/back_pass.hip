@@ -21,6 +21,7 @@
 // Global traffic per step: reads cx_i,cu_i (+u_i with limits, + fx_i,fu_i / cxx_i,cxu_i,cuu_i when
 // time-varying), writes K_i,k_i,Vx_i,Vxx_i,Quu_i — the algorithmic bytes of SURVEY.md §8(d).
 // cx/cu/u are prefetched in chunks of TC time steps, time-varying operands one step ahead.
+#include <stdlib.h>
 #include "ddp_internal.h"
 #include "boxqp_dev.h"
 
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
         for (int e = lane; e < n * m; e += DDP_WAVE) cxus[e] = cxu[nm * i0 + e];
         for (int e = lane; e < m * m; e += DDP_WAVE) cuus[e] = cuu[mm * i0 + e];
     }
-    __syncthreads();
+    wave_sync();
 
     int diverge = 0;
     for (int i = N - 2; i >= 0; --i) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
                 Qs[j] = (j < n ? cxi[j] : cui[j - n]) + s;       // backward_pass.jl:240-241
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // ================= P2: Qxx (registers), Qux, Quu and regularised variants ================
         double qxx[RT];
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // ================= P3: gains (backward_pass.jl:30-62) =====================================
         double H[MM * MM], R[MM * MM], kk[MM];
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
             dV0 += kQu;
             dV1 += 0.5 * kQuuk;
         }
-        __syncthreads();
+        wave_sync();
 
         // ================= P4: value update (:69-76), stores, operand hand-over ====================
 #pragma unroll
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     if (lane == n) { a.dV[2 * b] = dV0; a.dV[2 * b + 1] = dV1; }
     if (lane == 0) a.diverge[b] = diverge;
@@ -473,6 +474,7 @@ int launch_nm(ddp_handle h, const ddp_bp_desc *d, const BPArgs &a)
         break;
     switch (key) {
         DDP_BP_CASE(0, false, false, false)
+#ifndef DDP_FAST_BUILD
         DDP_BP_CASE(1, false, false, true)
         DDP_BP_CASE(2, false, true, false)
         DDP_BP_CASE(3, false, true, true)
@@ -480,6 +482,7 @@ int launch_nm(ddp_handle h, const ddp_bp_desc *d, const BPArgs &a)
         DDP_BP_CASE(5, true, false, true)
         DDP_BP_CASE(6, true, true, false)
         DDP_BP_CASE(7, true, true, true)
+#endif
     }
 #undef DDP_BP_CASE
     DDP_HIP(hipGetLastError());
@@ -498,6 +501,12 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     DDP_CHECK(d->regType == 1 || d->regType == 2, "back_pass: regType must be 1 or 2 (got %d)", d->regType);
     DDP_CHECK(!d->has_lims || (lims && u), "back_pass: has_lims needs lims and u");
     DDP_CHECK(d->m <= DDP_MAX_M, "back_pass: m=%d exceeds DDP_MAX_M=%d", d->m, DDP_MAX_M);
+    // DDP_BACKPASS=general forces the general kernel (A/B timing, tests of both code paths)
+    static const bool force_general = [] { const char *e = getenv("DDP_BACKPASS"); return e && e[0] == 'g'; }();
+    if (!force_general) {
+        const int rc = ddp_launch_back_pass_fast(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) return rc;
+    }
     BPArgs a;
     a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;
     a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.regType = d->regType;
@@ -505,8 +514,12 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     a.lambda = lambda; a.lims = lims; a.u = u; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     if (d->n == 10 && d->m == 2) return launch_nm<10, 2>(h, d, a);
+#ifndef DDP_FAST_BUILD
     if (d->n == 4 && d->m == 1) return launch_nm<4, 1>(h, d, a);
     if (d->n == 6 && d->m == 3) return launch_nm<6, 3>(h, d, a);
     DDP_CHECK(d->n <= DDP_MAX_N_GENERIC, "back_pass: n=%d has no kernel (compiled: (10,2),(4,1),(6,3), generic n<=%d)", d->n, DDP_MAX_N_GENERIC);
     return launch_nm<0, 0>(h, d, a);
+#else
+    DDP_CHECK(false, "back_pass: DDP_FAST_BUILD only has the (10,2) LTI kernel");
+#endif
 }

@@ -28,7 +28,7 @@ int ddp_device_count(void)
     return c;
 }
 
-int ddp_create(int device, ddp_handle *out)
+static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out)
 {
     DDP_CHECK(out, "ddp_create: out is NULL");
     int c = 0;
@@ -42,7 +42,10 @@ int ddp_create(int device, ddp_handle *out)
     h->scratch = nullptr;
     h->scratch_bytes = 0;
     h->h_pinned = nullptr;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    h->owns_stream = !adopt;
+    if (adopt) {
+        h->stream = (hipStream_t)ext_stream;
+    } else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         ddp_set_error("ddp_create: hipStreamCreate failed");
         return -2;
@@ -52,6 +55,9 @@ int ddp_create(int device, ddp_handle *out)
     return 0;
 }
 
+int ddp_create(int device, ddp_handle *out) { return create_impl(device, nullptr, false, out); }
+int ddp_create_with_stream(int device, void *hip_stream, ddp_handle *out) { return create_impl(device, hip_stream, true, out); }
+
 int ddp_destroy(ddp_handle h)
 {
     if (!h) return 0;
@@ -59,7 +65,7 @@ int ddp_destroy(ddp_handle h)
     hipStreamSynchronize(h->stream);
     if (h->scratch) hipFree(h->scratch);
     if (h->h_pinned) hipHostFree(h->h_pinned);
-    hipStreamDestroy(h->stream);
+    if (h->owns_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }

@@ -12,6 +12,7 @@
 struct ddp_handle_s {
     int          device;
     hipStream_t  stream;
+    bool         owns_stream;
     // scratch owned by the handle (host-pointer entry points, iLQG driver)
     void        *scratch;
     size_t       scratch_bytes;
@@ -47,3 +48,25 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
                          const double *fu, const double *lambda, const double *lims, const double *u,
                          const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                          double *Vxx, double *dV, int32_t *diverge);
+// LDS-lean kernel for the unconstrained m=2 shapes; returns 1 when the shape has no fast kernel
+int ddp_launch_back_pass_fast(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                              const double *fu, const double *lambda, const int32_t *active, double *K,
+                              double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
+
+// one-lane-per-rollout forward pass + separate cost kernel; returns 1 when the shape has no such kernel
+int ddp_launch_forward_lane(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
+                            const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
+                            const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);
+
+// Hand-off between the lanes of ONE wavefront through LDS.  The kernels that use it run one wave per
+// work-group, so no s_barrier is needed: LDS operations of a wave execute in issue order, the only
+// requirements are (a) the compiler must not move LDS accesses across the hand-off and (b) nothing may
+// wait on outstanding GLOBAL stores/loads here (__syncthreads() would emit s_waitcnt vmcnt(0) and stall
+// every hand-off on the HBM round trip of the step's output stores).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

@@ -14,6 +14,7 @@
 // needed), then lane j forms row j of the dynamics.  The step-(i+1) operands K,k,x,u are fetched while
 // step i computes.  The time loop is a strict dependency chain: throughput comes from the
 // (trajectory, α) batch, not from the horizon.
+#include <stdlib.h>
 #include "ddp_internal.h"
 
 namespace {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pass_kernel(FPArgs a)
         if (i + 1 < N) fetch(i + 1);
 
         xs[grp][jl] = xh;
-        __syncthreads();
+        wave_sync();
         double xv[NMAX];
 #pragma unroll
         for (int l = 0; l < NMAX; ++l) xv[l] = (l < n) ? xs[grp][l] : 0.0;
@@ -239,6 +240,12 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     DDP_CHECK((K == nullptr) == (k == nullptr), "forward_pass: K and k must both be given or both NULL");
     DDP_CHECK(!K || x, "forward_pass: a non-empty policy needs the nominal trajectory x");
     DDP_CHECK(p->m <= DDP_MAX_M && p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d unsupported (n<=%d, m<=%d)", p->n, p->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
+    // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
+    static const bool force_group = [] { const char *e = getenv("DDP_FORWARD"); return e && e[0] == 'g'; }();
+    if (!force_group) {
+        const int rc = ddp_launch_forward_lane(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
+        if (rc <= 0) return rc;
+    }
     FPArgs a;
     a.n = p->n; a.m = p->m; a.N = p->N; a.B = p->B; a.nalpha = nalpha;
     a.dyn_tv = p->dyn_tv; a.dyn_batched = p->dyn_batched; a.has_policy = K != nullptr; a.has_lims = lims != nullptr;

@@ -34,6 +34,9 @@ const char *ddp_last_error(void);
 const char *ddp_version(void);
 int  ddp_device_count(void);
 int  ddp_create(int device, ddp_handle *out);
+/* adopt a caller-owned hipStream_t (e.g. the host framework's current stream) instead of creating one;
+ * the stream is not destroyed by ddp_destroy() */
+int  ddp_create_with_stream(int device, void *hip_stream, ddp_handle *out);
 int  ddp_destroy(ddp_handle h);
 int  ddp_sync(ddp_handle h);
 void *ddp_stream(ddp_handle h);                 /* the hipStream_t of the handle */
