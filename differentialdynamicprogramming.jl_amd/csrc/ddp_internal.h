@@ -54,8 +54,8 @@ int ddp_launch_back_pass_fast(ddp_handle h, const ddp_bp_desc *d, const double *
                               const double *fu, const double *lambda, const int32_t *active, double *K,
                               double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
 
-// one-lane-per-rollout forward pass + separate cost kernel; returns 1 when the shape has no such kernel
-int ddp_launch_forward_lane(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
+// 16-lane DPP-row forward pass + separate cost kernel; returns 1 when the shape has no such kernel
+int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
                             const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
                             const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);
 

@@ -243,7 +243,7 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
     static const bool force_group = [] { const char *e = getenv("DDP_FORWARD"); return e && e[0] == 'g'; }();
     if (!force_group) {
-        const int rc = ddp_launch_forward_lane(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
+        const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rc <= 0) return rc;
     }
     FPArgs a;

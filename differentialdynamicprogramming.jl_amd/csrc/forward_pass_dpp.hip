@@ -1,0 +1,334 @@
+// forward_pass_dpp.hip — closed-loop rollout with one 16-lane DPP row per (trajectory, α) rollout.
+//
+// Same arithmetic as forward_pass.hip / src/forward_pass.jl:9-33; what changes is how the state is
+// exchanged.  gfx90a+ (and gfx950) can broadcast one lane of every 16-lane row INSIDE a double-precision
+// FMA:   v_fmac_f64_dpp  acc, src0, src1  row_newbcast:l   ==   acc += src0[lane l of my row] * src1
+// at the issue cost of a plain v_fmac_f64 (profiles/microbench/dpp_fma_bench.hip: 2.45 vs 2.63 ns per
+// wave-instruction).  With lane j of a row holding x̂_j and row j of A, the matrix-vector product
+//   x̂⁺_j = Σ_l A[j,l]·x̂_l   is n such instructions — no LDS, no hand-off, no separate broadcast moves.
+// The feedback term K·dx is formed the same way from per-lane products K[a,j]·dx_j (so K_i is read with one
+// coalesced 16-byte load per lane).  Four rollouts share a wavefront.  The per-step cost is off the
+// dependency chain and needs the full x'Qx product, so a separate (time x batch)-parallel kernel evaluates
+// it afterwards from xnew/unew (cost_kernel below).
+#include <stdlib.h>
+#include "ddp_internal.h"
+
+namespace {
+
+struct FDArgs {
+    int N, B, nalpha;
+    int dyn_tv, dyn_batched, has_policy, has_lims;
+    const double *A, *Bm, *K, *k, *x0, *u, *x, *lims;
+    const int32_t *active;
+    double alpha[16];
+    double g, l, h, d;
+    double *xnew, *unew;
+};
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
+
+// acc += src0[lane L of this 16-lane row] * src1
+template <int L>
+__device__ __forceinline__ void fmac_bc(double &acc, double src0, double src1)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src0), "v"(src1), "n"(L));
+}
+// a VGPR written by a VALU instruction needs 2 wait states before a DPP instruction reads it; the hazard
+// recogniser does not look inside inline asm, so freshly produced DPP sources pass through this fence
+__device__ __forceinline__ void dpp_fence(double &v) { asm volatile("s_nop 1" : "+v"(v)); }
+__device__ __forceinline__ void dpp_fence(double &a, double &b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void dpp_fence(double &a, double &b, double &c) { asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c)); }
+
+template <int L>
+__device__ __forceinline__ double row_bcast(double x) { return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + L, 0xf, 0xf, false); }
+
+// s += Σ_{l<NN} src[lane l] * w[l]   (two interleaved accumulators halve the dependent chain)
+template <int NN, int L = 0>
+struct RowDot {
+    static __device__ __forceinline__ void run(double &s0, double &s1, double src, const double (&w)[NN])
+    {
+        if constexpr (L < NN) {
+            if constexpr (L % 2 == 0) fmac_bc<L>(s0, src, w[L]); else fmac_bc<L>(s1, src, w[L]);
+            RowDot<NN, L + 1>::run(s0, s1, src, w);
+        }
+    }
+};
+// s += Σ_{l<NN} src[lane l]
+template <int NN, int L = 0>
+struct RowSum {
+    static __device__ __forceinline__ void run(double &s0, double &s1, double src, double one)
+    {
+        if constexpr (L < NN) {
+            if constexpr (L % 2 == 0) fmac_bc<L>(s0, src, one); else fmac_bc<L>(s1, src, one);
+            RowSum<NN, L + 1>::run(s0, s1, src, one);
+        }
+    }
+};
+
+template <int KIND, int NS, int MS, bool POLICY, bool LIMS>
+__global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
+{
+    constexpr int n = NS, m = MS, G = 16, GPW = DDP_WAVE / G;
+    static_assert(NS <= G && MS <= G, "state must fit one DPP row");
+    const int N = a.N, B = a.B;
+    const int lane = threadIdx.x, grp = lane / G, j = lane % G;
+    const long total = (long)B * a.nalpha;
+    long rho = (long)blockIdx.x * GPW + grp;
+    const bool valid = rho < total;
+    if (!valid) rho = total - 1;                                // keep all lanes alive (DPP reads every lane)
+    const int b = (int)(rho % B), ai = (int)(rho / B);
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    const double alpha = a.alpha[ai];
+    const bool inx = j < n, inu = j < m;
+    const int jx = inx ? j : 0, ju = inu ? j : 0;
+
+    constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    const double *ug = a.u + (size_t)m * N * b;
+    const double *xg = POLICY ? a.x + (size_t)n * N * b : nullptr;
+    const double *Kg = POLICY ? a.K + nm * N * b : nullptr;
+    const double *kg = POLICY ? a.k + (size_t)m * N * b : nullptr;
+    double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai);
+    double *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
+    const double *Ab = nullptr, *Bb = nullptr;
+    if (KIND == DDP_PROBLEM_LQ) {
+        Ab = a.A + (a.dyn_batched ? nn * (a.dyn_tv ? N : 1) * b : 0);
+        Bb = a.Bm + (a.dyn_batched ? nm * (a.dyn_tv ? N : 1) * b : 0);
+    }
+    // row j of A and B (zero rows for the idle lanes j >= n, so their x̂ stays 0)
+    double Arow[n], Brow[m];
+    auto load_dyn = [&](int i) {
+        if (KIND == DDP_PROBLEM_LQ) {
+            const size_t oa = a.dyn_tv ? nn * i : 0, ob = a.dyn_tv ? nm * i : 0;
+            const double z = inx ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = 0; l < n; ++l) Arow[l] = z * Ab[oa + jx + n * l];
+#pragma unroll
+            for (int q = 0; q < m; ++q) Brow[q] = z * Bb[ob + jx + n * q];
+        }
+    };
+    load_dyn(0);
+    double lo[m], hi[m];
+#pragma unroll
+    for (int q = 0; q < m; ++q) { lo[q] = LIMS ? a.lims[q] : 0.0; hi[q] = LIMS ? a.lims[q + m] : 0.0; }
+    double one = 1.0;
+    asm volatile("" : "+v"(one));                               // keep 1.0 in a VGPR (DPP src1 must be a VGPR)
+
+    double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0;           // x̂_j
+
+    // one predicated store per step: lane j < n writes xnew[j,i], lanes n..n+m-1 write unew[j-n,i]
+    const bool st_u = j >= n && j < n + m;
+    const bool st_on = act && (inx || st_u);
+    double *st_base = st_u ? uo + (j - n) : xo + jx;
+    const unsigned st_stride = (st_u ? m : n) * (unsigned)sizeof(double);
+
+    // Loads are UNCONDITIONAL (clamped lane index): a load inside an exec-masked branch makes the compiler
+    // drain all outstanding loads (s_waitcnt vmcnt(0)) at the join and would serialise the prefetch ring.
+    struct Ops { double u[m], k[m], K[m], x; };                 // ū_i, k_i (row-uniform), K_i[:, j], x_i[j]
+    auto fetch = [&](int i, Ops &o) {
+#pragma unroll
+        for (int q = 0; q < m; ++q) o.u[q] = ug[(size_t)m * i + q];
+        if (POLICY) {
+#pragma unroll
+            for (int q = 0; q < m; ++q) {
+                o.k[q] = kg[(size_t)m * i + q];
+                o.K[q] = Kg[nm * i + q + m * jx];
+            }
+            o.x = xg[(size_t)n * i + jx];
+        }
+    };
+    auto step = [&](int i, const Ops &o, bool advance) {
+        // ---- controls (forward_pass.jl:17-24): u = ū + α k + K (x̂ - x), clamp, NaN -> 0 (inside f)
+        double uu[m];
+        if (POLICY) {
+            double pr[m];
+            const double dx = xh - o.x;
+#pragma unroll
+            for (int q = 0; q < m; ++q) pr[q] = o.K[q] * dx;
+            if constexpr (m == 2) dpp_fence(pr[0], pr[1]);
+            else {
+#pragma unroll
+                for (int q = 0; q < m; ++q) dpp_fence(pr[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < m; ++q) {
+                double s0 = o.u[q] + o.k[q] * alpha, s1 = 0.0;            // unew .+= k*α, then .+= K*dx
+                RowSum<n>::run(s0, s1, pr[q], one);
+                uu[q] = s0 + s1;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < m; ++q) uu[q] = o.u[q];
+        }
+#pragma unroll
+        for (int q = 0; q < m; ++q) {
+            if (LIMS) uu[q] = clampd(uu[q], lo[q], hi[q]);
+            if (uu[q] != uu[q]) uu[q] = 0.0;
+        }
+        {
+            double v = xh;
+#pragma unroll
+            for (int q = 0; q < m; ++q) v = (j == n + q) ? uu[q] : v;
+            if (st_on) *(double *)((char *)st_base + (size_t)i * st_stride) = v;
+        }
+        // ---- dynamics (f is also called at i == N in the reference, its result is discarded)
+        if (advance) {
+            double xp;
+            if (KIND == DDP_PROBLEM_LQ) {
+                if (a.dyn_tv) load_dyn(i);
+                double s0 = 0.0, s1 = 0.0, t = 0.0;
+                RowDot<n>::run(s0, s1, xh, Arow);                        // Σ_l A[j,l] x̂_l
+#pragma unroll
+                for (int q = 0; q < m; ++q) t += Brow[q] * uu[q];
+                xp = (s0 + s1) + t;                                      // A*x + B*u
+            } else {                                                     // system_pendcart.jl:83-89
+                const double x0v = row_bcast<0>(xh), x1v = row_bcast<1>(xh), x3v = row_bcast<3>(xh);
+                const double gl = a.g / a.l, h = a.h;
+                const double f1 = x1v + h * (-gl * sin(x0v) + uu[0] / a.l * cos(x0v) - a.d * x1v);
+                xp = (j == 0) ? x0v + h * x1v : (j == 1) ? f1 : (j == 2) ? xh + h * x3v : x3v + h * uu[0];
+                xp = inx ? xp : 0.0;
+            }
+            xh = xp;
+            dpp_fence(xh);
+        }
+    };
+    dpp_fence(xh);
+    // A time step is ~60 instructions (~0.15 us) but an HBM load takes ~1 us: the operands of step i+D are
+    // requested while step i runs (ring of D register sets, loop unrolled by D so every slot is a fixed
+    // register).  The main loop is branch-free; the last < 2D steps run in a guarded copy.
+    constexpr int D = 8;
+    Ops ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d < N ? d : N - 1, ring[d]);
+    int i0 = 0;
+    for (; i0 + 2 * D <= N; i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            step(i0 + d, ring[d], true);
+            fetch(i0 + d + D, ring[d]);
+        }
+    }
+    for (; i0 < N; i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = i0 + d;
+            if (i < N) {
+                step(i, ring[d], i < N - 1);
+                fetch(i + D < N ? i + D : N - 1, ring[d]);
+            }
+        }
+    }
+}
+
+// ---- per-step cost + its sum: one wave per rollout, lanes over time (costfun of the registered families)
+//   LQ        c_i = .5 x_i'Q x_i + .5 u_i'R u_i                      (src/demo_linear.jl:49, split per step)
+//   pendcart  c_i = .5 ((x_i-goal)'Q(x_i-goal) + R u_i^2), c_{N+1} = .5 (x_N-goal)'Q(x_N-goal)
+//                                                                     (src/system_pendcart.jl:97-106)
+struct CostArgs {
+    int kind, n, m, N, B, nalpha;
+    const double *Q, *R;
+    const int32_t *active;
+    double goal[4];
+    const double *xnew, *unew;
+    double *cnew, *csum;
+};
+
+template <int KIND, int NS, int MS>
+__global__ __launch_bounds__(DDP_WAVE) void cost_kernel(CostArgs a)
+{
+    constexpr int n = NS, m = MS;
+    constexpr bool pend = KIND == DDP_PROBLEM_PENDCART;
+    const int N = a.N, B = a.B;
+    const long rho = blockIdx.x;
+    const int b = (int)(rho % B);
+    if (a.active && a.active[b] == 0) return;
+    const int lane = threadIdx.x;
+    const int CL = pend ? N + 1 : N;
+    const double *x = a.xnew + (size_t)n * N * rho, *u = a.unew + (size_t)m * N * rho;
+    double *c = a.cnew + (size_t)CL * rho;
+    __shared__ double qr[n * n + m * m];             // Q | R, read back as wave-uniform (broadcast) operands
+    for (int e = lane; e < n * n; e += DDP_WAVE) qr[e] = a.Q[e];
+    for (int e = lane; e < m * m; e += DDP_WAVE) qr[n * n + e] = a.R[e];
+    wave_sync();
+    const double *Q = qr, *R = qr + n * n;
+    double acc = 0.0;
+    for (int t = lane; t < CL; t += DDP_WAVE) {
+        const int tx = t < N ? t : N - 1;            // pendcart: the extra entry re-counts x[:,N] with u = 0
+        double xt[n], ut[m];
+#pragma unroll
+        for (int i = 0; i < n; ++i) xt[i] = x[(size_t)n * tx + i] - (pend ? a.goal[i & 3] : 0.0);
+#pragma unroll
+        for (int i = 0; i < m; ++i) ut[i] = u[(size_t)m * tx + i];
+        double qx = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < n; ++jj) s += Q[i + n * jj] * xt[jj];
+            qx += xt[i] * s;
+        }
+        double ru = 0.0;
+        if (t < N) {
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < m; ++jj) s += R[i + m * jj] * ut[jj];
+                ru += ut[i] * s;
+            }
+        }
+        const double ct = pend ? 0.5 * (qx + ru) : 0.5 * qx + 0.5 * ru;
+        c[t] = ct;
+        acc += ct;
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) a.csum[rho] = acc;
+}
+
+template <int KIND, int NS, int MS>
+int launch_dpp(ddp_handle h, const FDArgs &a)
+{
+    const int key = (a.has_policy ? 2 : 0) | (a.has_lims ? 1 : 0);
+    const long total = (long)a.B * a.nalpha;
+    const int gpw = DDP_WAVE / 16;
+    const dim3 grid((unsigned)((total + gpw - 1) / gpw)), block(DDP_WAVE);
+    switch (key) {
+    case 0: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, false>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, true>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, false>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, true>), grid, block, 0, h->stream, a); break;
+    }
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+}   // namespace
+
+// returns 1 when the shape has no DPP kernel (caller falls back to the group kernel), 0 launched, <0 error
+int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
+                           const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
+                           const int32_t *active, double *xnew, double *unew, double *cnew, double *csum)
+{
+    const bool lq = p->kind == DDP_PROBLEM_LQ;
+    if (!((lq && p->n == 10 && p->m == 2) || (p->kind == DDP_PROBLEM_PENDCART))) return 1;
+    FDArgs a;
+    a.N = p->N; a.B = p->B; a.nalpha = nalpha;
+    a.dyn_tv = p->dyn_tv; a.dyn_batched = p->dyn_batched; a.has_policy = K != nullptr; a.has_lims = lims != nullptr;
+    a.A = p->A; a.Bm = p->Bm; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.lims = lims; a.active = active;
+    for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
+    a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
+    a.xnew = xnew; a.unew = unew;
+    int rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1>(h, a);
+    if (rc) return rc;
+    CostArgs c;
+    c.kind = p->kind; c.n = p->n; c.m = p->m; c.N = p->N; c.B = p->B; c.nalpha = nalpha; c.Q = p->Q; c.R = p->R;
+    c.active = active;
+    for (int i = 0; i < 4; ++i) c.goal[i] = p->goal[i];
+    c.xnew = xnew; c.unew = unew; c.cnew = cnew; c.csum = csum;
+    const dim3 cgrid((unsigned)((long)p->B * nalpha)), cblock(DDP_WAVE);
+    if (lq) hipLaunchKernelGGL((cost_kernel<DDP_PROBLEM_LQ, 10, 2>), cgrid, cblock, 0, h->stream, c);
+    else hipLaunchKernelGGL((cost_kernel<DDP_PROBLEM_PENDCART, 4, 1>), cgrid, cblock, 0, h->stream, c);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
