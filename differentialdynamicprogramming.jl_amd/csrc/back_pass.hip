@@ -501,11 +501,24 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     DDP_CHECK(d->regType == 1 || d->regType == 2, "back_pass: regType must be 1 or 2 (got %d)", d->regType);
     DDP_CHECK(!d->has_lims || (lims && u), "back_pass: has_lims needs lims and u");
     DDP_CHECK(d->m <= DDP_MAX_M, "back_pass: m=%d exceeds DDP_MAX_M=%d", d->m, DDP_MAX_M);
-    // DDP_BACKPASS=general forces the general kernel (A/B timing, tests of both code paths)
-    static const bool force_general = [] { const char *e = getenv("DDP_BACKPASS"); return e && e[0] == 'g'; }();
-    if (!force_general) {
-        const int rc = ddp_launch_back_pass_fast(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
-        if (rc <= 0) return rc;
+    // Kernel choice.  Three implementations of the same arithmetic exist:
+    //   dpp     16 lanes per trajectory (back_pass_dpp.hip): fewest instructions per trajectory-step, best once the
+    //           batch gives every SIMD a few wavefronts;
+    //   fast    64 lanes per trajectory, LDS-lean (back_pass_fast.hip; n=10, m=2, no limits): shortest dependency
+    //           chain, best for small batches (one wave per SIMD or less);
+    //   general 64 lanes per trajectory, any n <= 32 / m <= 8 / limits (this file).
+    // DDP_BACKPASS=general|fast|dpp forces one (A/B timing, tests of every code path).
+    const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
+    const char force = force_env ? force_env[0] : 0;
+    if (force != 'g') {
+        if (force != 'd' && (force == 'f' || d->B < 2048)) {
+            const int rc = ddp_launch_back_pass_fast(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+            if (rc <= 0) return rc;
+        }
+        if (force != 'f') {
+            const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+            if (rc <= 0) return rc;
+        }
     }
     BPArgs a;
     a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;

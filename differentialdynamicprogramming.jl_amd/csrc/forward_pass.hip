@@ -241,7 +241,8 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     DDP_CHECK(!K || x, "forward_pass: a non-empty policy needs the nominal trajectory x");
     DDP_CHECK(p->m <= DDP_MAX_M && p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d unsupported (n<=%d, m<=%d)", p->n, p->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
     // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
-    static const bool force_group = [] { const char *e = getenv("DDP_FORWARD"); return e && e[0] == 'g'; }();
+    const char *fwd_env = getenv("DDP_FORWARD");               // read per call so tests can switch paths
+    const bool force_group = fwd_env && fwd_env[0] == 103;
     if (!force_group) {
         const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rc <= 0) return rc;

@@ -222,3 +222,79 @@ def test_full_size_c2_properties(ddp):
         assert relerr(pol.K[..., b], K) < RTOL and relerr(Vxx[..., b], vxx) < RTOL and relerr(Vx[..., b], vx) < RTOL
         xr, ur, cr = oc.forward_pass(p, (K, k), x0[:, b], u[..., b], x[..., b], 0.3, None)
         assert relerr(xn[..., b, 1], xr) < RTOL and relerr(un[..., b, 1], ur) < RTOL
+
+
+# ------------------------------------------------------------------ every kernel implementation of back_pass
+def _tv_problem(rng, n, m, N, B):
+    import scipy.linalg as sla
+    fx = np.stack([np.stack([sla.expm(0.05 * (lambda a: a - a.T)(rng.standard_normal((n, n)))) for _ in range(N)], -1) for _ in range(B)], -1)
+    fu = 0.1 * rng.standard_normal((n, m, N, B))
+    def spd(d, s):
+        a = rng.standard_normal((d, d)); return s * (a @ a.T / d + 0.5 * np.eye(d))
+    cxx = np.stack([np.stack([spd(n, 0.1) for _ in range(N)], -1) for _ in range(B)], -1)
+    cuu = np.stack([np.stack([spd(m, 0.05) for _ in range(N)], -1) for _ in range(B)], -1)
+    cxu = 0.01 * rng.standard_normal((n, m, N, B))
+    cx = 0.1 * rng.standard_normal((n, N, B)); cu = 0.1 * rng.standard_normal((m, N, B))
+    u = 0.3 * rng.standard_normal((m, N, B))
+    return cx, cu, cxx, cxu, cuu, fx, fu, u
+
+
+@pytest.mark.parametrize("impl", ["general", "fast", "dpp"])
+@pytest.mark.parametrize("variant", ["lti", "ltv", "tvcost"])
+@pytest.mark.parametrize("regType", [1, 2])
+def test_back_pass_implementations_n10m2(ddp, monkeypatch, impl, variant, regType):
+    """the three kernels (general / LDS-lean 64-lane / 16-lane DPP) on the headline shape, all dispatch variants"""
+    from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_BACKPASS", impl)
+    rng = np.random.default_rng(7)
+    n, m, N, B = 10, 2, 37, 9
+    cx, cu, cxx, cxu, cuu, fx, fu, u = _tv_problem(rng, n, m, N, B)
+    if variant == "lti":
+        fx, fu, cxx, cxu, cuu = fx[:, :, 0, 0], fu[:, :, 0, 0], cxx[:, :, 0, 0], cxu[:, :, 0, 0], cuu[:, :, 0, 0]
+    elif variant == "ltv":
+        cxx, cxu, cuu = cxx[:, :, 0, 0], cxu[:, :, 0, 0], cuu[:, :, 0, 0]
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, None, None, u)
+    assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2, 3)))
+    for b in range(B):
+        sl = lambda a, nd: a[..., b] if a.ndim == nd + 1 else a
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], sl(cxx, 3), sl(cxu, 3), sl(cuu, 3), sl(fx, 3), sl(fu, 3),
+                                                  lam[b], regType, None, None, u[..., b])
+        assert div[b] == d == 0
+        for got, ref in ((pol.K[..., b], K), (pol.k[..., b], k), (Vx[..., b], vx), (Vxx[..., b], vxx), (dV[:, b], dv), (pol.Σi[..., b], Quu)):
+            assert relerr(got, ref) < RTOL
+
+
+@pytest.mark.parametrize("impl", ["general", "dpp"])
+@pytest.mark.parametrize("name", ["bp_lti_n10m2_lims", "bp_ltv_pendcart_lims", "bp_ltv_pendcart_nolims"])
+def test_back_pass_implementations_limits(ddp, monkeypatch, impl, name):
+    monkeypatch.setenv("DDP_BACKPASS", impl)
+    g = load_golden(name)
+    d, pol, Vx, Vxx, dV = ddp.back_pass(g["cx"], g["cu"], g["cxx"], g["cxu"], g["cuu"], g["fx"], g["fu"], float(g["lam"]),
+                                        int(g["regType"]), _lims(g), g["x"], g["u"])
+    assert d == int(g["diverge"]) == 0
+    for got, key in ((pol.K, "K"), (pol.k, "k"), (Vx, "Vx"), (Vxx, "Vxx"), (dV, "dV"), (pol.Σi, "Quu")):
+        assert relerr(got, g[key]) < RTOL, (key, relerr(got, g[key]))
+
+
+@pytest.mark.parametrize("impl", ["general", "fast", "dpp"])
+def test_back_pass_divergence_per_trajectory(ddp, monkeypatch, impl):
+    """a non-PD Quu in ONE trajectory of a batch stops that trajectory only (diverge index, zeros before it)"""
+    from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_BACKPASS", impl)
+    rng = np.random.default_rng(11)
+    n, m, N, B = 10, 2, 30, 6
+    cx, cu, cxx, cxu, cuu, fx, fu, u = _tv_problem(rng, n, m, N, B)
+    cuu[:, :, 12, 3] = -np.eye(m)                      # trajectory 3 fails at step 13 (1-based)
+    cuu[:, :, 20, 5] = -np.eye(m)
+    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 1e-3, 1, None, None, u)
+    assert list(div) == [0, 0, 0, 13, 0, 21]
+    for b in range(B):
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], cxx[..., b], cxu[..., b], cuu[..., b], fx[..., b],
+                                                  fu[..., b], 1e-3, 1, None, None, u[..., b])
+        assert d == div[b]
+        for got, ref in ((pol.K[..., b], K), (pol.k[..., b], k), (Vx[..., b], vx), (Vxx[..., b], vxx), (dV[:, b], dv)):
+            assert relerr(got, ref) < RTOL
+        if d:
+            assert not pol.K[:, :, : d - 1, b].any() and not Vxx[:, :, : d - 1, b].any() and not Vx[:, : d - 1, b].any()
+            assert relerr(pol.Σi[:, :, d - 1, b], Quu[:, :, d - 1]) < RTOL
