@@ -1,0 +1,71 @@
+"""Multi-GPU use of the path: batch sharding + ONE small all-reduce.
+
+The reference solves one trajectory; a batch of independent trajectories / MPC rollouts has no coupling
+(each has its own λ schedule, line search and divergence flag), so the path shards by contiguous batch ranges,
+one process per GPU, with no data-path exchange.  The only collective is an all-reduce (RCCL on GPUs,
+gloo in the CPU tests) of a short statistics vector per outer iteration / per solve, used for batch-level
+reporting and global termination.  It is latency-bound (tens of bytes); xGMI bandwidth is irrelevant.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+STAT_NAMES = ("sum_cost", "n_traj", "n_converged", "n_lambda_exit", "n_maxiter", "n_init_diverged", "sum_iters",
+              "sum_backpass", "sum_forward", "sum_gnorm", "max_iters")
+N_SUM = 10          # the first N_SUM entries reduce with SUM, the rest with MAX
+
+
+def shard_range(B: int, rank: int, world: int):
+    """contiguous shard [lo, hi) of a batch of B trajectories for `rank` of `world` (sizes differ by at most one)"""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def stats_from_solve(stats, cost):
+    """local statistics vector from the per-trajectory summary `stats[8,B]` of ddp_ilqg_f64 (include/ddp_amd.h)
+    and the final cost vectors `cost[CL,B]`"""
+    st = np.asarray(stats, dtype=np.float64).reshape(8, -1)
+    status = st[0]
+    v = np.zeros(len(STAT_NAMES))
+    v[0] = float(np.sum(cost))
+    v[1] = st.shape[1]
+    v[2] = float(np.sum((status == 1) | (status == 2)))
+    v[3] = float(np.sum(status == 3))
+    v[4] = float(np.sum(status == 4))
+    v[5] = float(np.sum(status == -1))
+    v[6] = float(np.sum(st[1]))
+    v[7] = float(np.sum(st[3]))
+    v[8] = float(np.sum(st[4]))
+    v[9] = float(np.sum(st[6]))
+    v[10] = float(np.max(st[1])) if st.shape[1] else 0.0
+    return v
+
+
+def allreduce_stats(v, device=None):
+    """all-reduce a statistics vector over the default torch.distributed group (no-op when not initialised)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(v, dtype=np.float64)
+    t = torch.as_tensor(np.asarray(v, dtype=np.float64), device=device)
+    s, mx = t[:N_SUM].clone(), t[N_SUM:].clone()
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    return torch.cat([s, mx]).cpu().numpy()
+
+
+def solve_sharded(problem, x0, u0, *, solver=None, device=None, **kw):
+    """Every rank solves its contiguous shard of the batch (x0[n,B], u0[m,N,B]) and the ranks all-reduce the
+    statistics vector.  `solver(problem, x0_shard, u0_shard, **kw)` must return the tuple of ``iLQG``; it defaults
+    to the GPU solver of this package.  Returns ``(local_result, global_stats_dict, (lo, hi))``."""
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    B = u0.shape[2]
+    lo, hi = shard_range(B, rank, world)
+    if solver is None:
+        from . import iLQG as solver        # GPU path (raises without a GPU: no CPU fallback)
+    res = solver(problem, np.ascontiguousarray(x0[:, lo:hi]), np.ascontiguousarray(u0[:, :, lo:hi]), **kw)
+    x, u, pol, Vx, Vxx, cost, trace = res
+    g = allreduce_stats(stats_from_solve(trace["stats"], cost), device=device)
+    return res, dict(zip(STAT_NAMES, g)), (lo, hi)

@@ -1,0 +1,83 @@
+"""N>1 path on CPU: two gloo processes, each solving its shard of a batch (with the CPU oracle standing in for the
+GPU solver — the sharding / statistics / collective code is what is under test), one all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from ddp_amd import sharding
+
+
+def test_shard_range_partitions_the_batch():
+    for B in (1, 7, 8, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            got = [sharding.shard_range(B, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+            sizes = [hi - lo for lo, hi in got]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _oracle_solver(problem, x0, u0, **kw):
+    """CPU stand-in with the return convention of ddp_amd.iLQG (batched)"""
+    from oracle import oracle_ctypes as oc
+    n, B = x0.shape
+    m, N = u0.shape[:2]
+    p = oc.make_problem("lq", n, m, N, A=problem["A"], B=problem["B"], Q=problem["Q"], R=problem["R"])
+    stats = np.zeros((8, B)); costs = np.zeros((N, B))
+    for b in range(B):
+        x, u, (K, k, Quu), Vx, Vxx, cost, info = oc.ilqg(p, x0[:, b], u0[:, :, b])
+        stats[:, b] = [info["status"], info["iter"], info["accepted_iter"], info["n_backpass"], info["n_forward"], info["lam"],
+                       info["g_norm"], cost.sum()]
+        costs[:, b] = cost
+    return None, None, None, None, None, costs, dict(stats=stats)
+
+
+def _make_batch():
+    from oracle import np_restatement as npr
+    rng = np.random.default_rng(5)
+    P = npr.make_lq_problem(rng, T=60)
+    B = 5
+    x0 = np.ones((10, B)) + 0.1 * rng.standard_normal((10, B))
+    u0 = 0.1 * rng.standard_normal((2, 60, B))
+    return P, x0, u0
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, x0, u0 = _make_batch()
+    res, g, (lo, hi) = sharding.solve_sharded(P, x0, u0, solver=_oracle_solver)
+    q.put((rank, lo, hi, g))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_allreduce_matches_unsharded():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    assert (out[0][1], out[0][2], out[1][1], out[1][2]) == (0, 3, 3, 5)
+    # both ranks hold the same global statistics, equal to the unsharded solve
+    P, x0, u0 = _make_batch()
+    _, _, _, _, _, cost, tr = _oracle_solver(P, x0, u0)
+    ref = sharding.stats_from_solve(tr["stats"], cost)
+    for _, _, _, g in out:
+        got = np.array([g[k] for k in sharding.STAT_NAMES])
+        assert np.allclose(got, ref, rtol=1e-12, atol=0)
+    assert out[0][3]["n_traj"] == 5 and out[0][3]["n_converged"] == 5
