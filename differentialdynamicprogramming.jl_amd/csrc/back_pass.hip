@@ -510,7 +510,7 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     // DDP_BACKPASS=general|fast|dpp forces one (A/B timing, tests of every code path).
     const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
-    if (force != 'g') {
+    if (force != 'g' && force != 'b') {
         if (force != 'd' && (force == 'f' || d->B < 2048)) {
             const int rc = ddp_launch_back_pass_fast(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
             if (rc <= 0) return rc;
@@ -530,7 +530,11 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
 #ifndef DDP_FAST_BUILD
     if (d->n == 4 && d->m == 1) return launch_nm<4, 1>(h, d, a);
     if (d->n == 6 && d->m == 3) return launch_nm<6, 3>(h, d, a);
-    DDP_CHECK(d->n <= DDP_MAX_N_GENERIC, "back_pass: n=%d has no kernel (compiled: (10,2),(4,1),(6,3), generic n<=%d)", d->n, DDP_MAX_N_GENERIC);
+    if (d->n > DDP_MAX_N_GENERIC || force == 'b') {               // large states: 256-thread work-group per trajectory
+        const int rc = ddp_launch_back_pass_big(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) return rc;
+    }
+    DDP_CHECK(d->n <= DDP_MAX_N_GENERIC, "back_pass: n=%d m=%d has no kernel (n <= %d any m <= %d; even n <= 64 with even m <= 8)", d->n, d->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
     return launch_nm<0, 0>(h, d, a);
 #else
     DDP_CHECK(false, "back_pass: DDP_FAST_BUILD only has the (10,2) LTI kernel");

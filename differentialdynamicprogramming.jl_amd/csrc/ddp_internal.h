@@ -60,6 +60,12 @@ int ddp_launch_back_pass_dpp(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const double *fu, const double *lambda, const double *lims, const double *u,
                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge);
+// large states (even n <= 64, even m <= 8): 256-thread work-group per trajectory; returns 1 when not applicable
+int ddp_launch_back_pass_big(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const double *lambda, const double *lims, const double *u,
+                             const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                             double *Vxx, double *dV, int32_t *diverge);
 // 16-lane DPP-row forward pass + separate cost kernel; returns 1 when the shape has no such kernel
 int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
                             const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
@@ -75,6 +81,11 @@ __device__ __forceinline__ double ddp_rsqrt(double x)
     y = fma(0.5 * y, e, y);
     return y;
 }
+
+// one wave per rollout for large states (LQ family, n <= 64); returns 1 when not applicable
+int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
+                           const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
+                           const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);
 
 // Hand-off between the lanes of ONE wavefront through LDS.  The kernels that use it run one wave per
 // work-group, so no s_barrier is needed: LDS operations of a wave execute in issue order, the only

@@ -239,7 +239,12 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     DDP_CHECK(nalpha >= 1 && nalpha <= 16, "forward_pass: nalpha=%d out of [1,16]", nalpha);
     DDP_CHECK((K == nullptr) == (k == nullptr), "forward_pass: K and k must both be given or both NULL");
     DDP_CHECK(!K || x, "forward_pass: a non-empty policy needs the nominal trajectory x");
-    DDP_CHECK(p->m <= DDP_MAX_M && p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d unsupported (n<=%d, m<=%d)", p->n, p->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
+    DDP_CHECK(p->m <= DDP_MAX_M && p->n <= 64, "forward_pass: n=%d m=%d unsupported (n<=64, m<=%d)", p->n, p->m, DDP_MAX_M);
+    if (p->n > DDP_MAX_N_GENERIC || (getenv("DDP_FORWARD") && getenv("DDP_FORWARD")[0] == 'b')) {   // large states
+        const int rc = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
+        if (rc <= 0) return rc;
+        DDP_CHECK(p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d has no kernel", p->n, p->m);
+    }
     // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
     const char *fwd_env = getenv("DDP_FORWARD");               // read per call so tests can switch paths
     const bool force_group = fwd_env && fwd_env[0] == 103;

@@ -1,0 +1,131 @@
+"""Pass time (back_pass + forward_pass, one α) of the non-headline BASELINE configs with device-resident operands:
+   C3  pendcart n=4 m=1 N=600, control limits (boxQP), B=4096
+   C4  large-state LTV n=64 m=8 N=256, per-trajectory dynamics (a3 layout), B=1024 per GPU
+Prints one JSON line per config.  Informational; the graded line is bench.py's."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import ddp_amd  # noqa: E402
+from ddp_amd import _lib  # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+L = _lib.lib()
+h = ddp_amd.Handle(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+p = lambda t: C.c_void_p(t.data_ptr())
+f64 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))).to(dev)
+empty = lambda c, dt=torch.float64: torch.empty(int(c), dtype=dt, device=dev)
+
+
+def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warmup=2, gen=None):
+    CL = N + 1 if prob.kind == 1 else N
+    one = np.array([1.0])
+    dl = f64(lims) if lims is not None else None
+    dx, du, dc, dcs = empty(n * N * B), empty(m * N * B), empty(CL * B), empty(B)
+    _lib.check(L.ddp_forward_pass_f64_dev(h.raw, C.byref(prob), None, None, p(dx0), p(du0), None, _lib.ptr(one), 1, p(dl) if dl is not None else None,
+                                          None, p(dx), p(du), p(dc), p(dcs)))
+    dcx, dcu = empty(n * N * B), empty(m * N * B)
+    pend = prob.kind == 1
+    dfx = empty(n * n * N * B) if pend else None
+    dfu = empty(n * m * N * B) if pend else None
+    _lib.check(L.ddp_df_f64_dev(h.raw, C.byref(prob), p(dx), p(du), None, p(dcx), p(dcu), p(dfx) if pend else None, p(dfu) if pend else None))
+    fx, fu, fx_tv, fx_b = (dfx, dfu, 1, 1) if pend else fx_desc
+    dQ, dR = prob._Q, prob._R
+    dcxu = torch.zeros(n * m, dtype=torch.float64, device=dev)
+    dlam = torch.ones(B, dtype=torch.float64, device=dev)
+    dK, dk, dQuu, dVx, dVxx, ddV = empty(m * n * N * B), empty(m * N * B), empty(m * m * N * B), empty(n * N * B), empty(n * n * N * B), empty(2 * B)
+    ddiv = torch.zeros(B, dtype=torch.int32, device=dev)
+    dxn, dun, dcn, dcsn = empty(n * N * B), empty(m * N * B), empty(CL * B), empty(B)
+    desc = _lib.BPDesc(n, m, N, B, fx_tv, fx_b, 0, 0, regType, int(lims is not None))
+
+    def step(ev=None):
+        if ev: L.ddp_event_record(h.raw, ev[0])
+        _lib.check(L.ddp_back_pass_f64_dev(h.raw, C.byref(desc), p(dcx), p(dcu), p(dQ), p(dcxu), p(dR), p(fx), p(fu), p(dlam),
+                                           p(dl) if dl is not None else None, p(du), None, p(dK), p(dk), p(dQuu), p(dVx), p(dVxx), p(ddV), p(ddiv)))
+        if ev: L.ddp_event_record(h.raw, ev[1])
+        _lib.check(L.ddp_forward_pass_f64_dev(h.raw, C.byref(prob), p(dK), p(dk), p(dx0), p(du), p(dx), _lib.ptr(one), 1,
+                                              p(dl) if dl is not None else None, None, p(dxn), p(dun), p(dcn), p(dcsn)))
+        if ev: L.ddp_event_record(h.raw, ev[2])
+
+    for _ in range(warmup):
+        step()
+    evs = []
+    for _ in range(steps):
+        ev = [C.c_void_p() for _ in range(3)]
+        for e in ev:
+            L.ddp_event_create(h.raw, C.byref(e))
+        evs.append(ev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for ev in evs:
+        step(ev)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    bp, fp = [], []
+    for ev in evs:
+        ms = C.c_float()
+        L.ddp_event_elapsed_ms(h.raw, ev[0], ev[1], C.byref(ms)); bp.append(ms.value)
+        L.ddp_event_elapsed_ms(h.raw, ev[1], ev[2], C.byref(ms)); fp.append(ms.value)
+    tv = fx_tv
+    bp_bytes = ((n + m) + (n * n + n * m if tv else 0) + (m if lims is not None else 0) + (m * n + m + n + n * n + m * m)) * 8 * (N - 1) * B
+    fp_bytes = ((m * n + m + n + m) + (n * n + n * m if (tv and not pend) else 0) + (n + m + 1)) * 8 * N * B
+    out = {"config": name, "n": n, "m": m, "N": N, "batch": B, "iterations_per_s": round(B * steps / el, 1), "ms_per_pass_batch": round(1e3 * el / steps, 3),
+           "back_pass_ms": round(float(np.mean(bp)), 3), "forward_ms": round(float(np.mean(fp)), 3),
+           "back_pass_alg_GBs": round(bp_bytes / (np.mean(bp) * 1e-3) / 1e9, 1), "back_pass_frac_of_8TBs": round(bp_bytes / (np.mean(bp) * 1e-3) / 8e12, 4),
+           "forward_alg_GBs": round(fp_bytes / (np.mean(fp) * 1e-3) / 1e9, 1), "diverged": int(ddiv.sum().item())}
+    print(json.dumps(out))
+
+
+def c3(B=4096):
+    n, m, N = 4, 1, 600
+    prob = _lib.Problem()
+    prob.kind, prob.n, prob.m, prob.N, prob.B = 1, n, m, N, B
+    Q, R = f64(np.diag([10.0, 1, 2, 1])), f64(np.array([[1.0]]))
+    prob.Q, prob.R = Q.data_ptr(), R.data_ptr()
+    prob._Q, prob._R = Q, R
+    prob.g, prob.l, prob.h, prob.d = 9.82, 0.35, 0.01, 0.99
+    for i, v in enumerate([np.pi, 0, 0, 0]):
+        prob.goal[i] = v
+    rng = np.random.default_rng(0)
+    x0 = np.tile(np.array([np.pi - 0.6, 0, 0, 0])[:, None], (1, B)); x0[0] += rng.uniform(-0.1, 0.1, B)
+    u0 = 2.0 * np.sin(np.arange(N) / 37.0)[None, :, None] * np.ones((1, 1, B))
+    run("C3 pendcart lims", prob, n, m, N, B, f64(x0), f64(u0), 5.0 * np.array([[-1.0, 1.0]]), 2, None)
+
+
+def c4(B=1024):
+    import scipy.linalg as sla
+    n, m, N = 64, 8, 256
+    rng = np.random.default_rng(1)
+    h_ = 0.01
+    a0 = rng.standard_normal((n, n))
+    A = sla.expm(h_ * (a0 - a0.T))
+    Bm = h_ * rng.standard_normal((n, m))
+    # per-trajectory, time-varying layout (a3): fx[n,n,N,B] — built on the device to avoid a 8.6 GB host array
+    dA = f64(A).reshape(1, -1) * (1.0 + 0.01 * torch.rand(N * B, 1, dtype=torch.float64, device=dev))
+    dB = f64(Bm).reshape(1, -1) * torch.ones(N * B, 1, dtype=torch.float64, device=dev)
+    dA, dB = dA.reshape(-1).contiguous(), dB.reshape(-1).contiguous()
+    prob = _lib.Problem()
+    prob.kind, prob.n, prob.m, prob.N, prob.B = 0, n, m, N, B
+    Q, R = f64(h_ * np.eye(n)), f64(0.1 * h_ * np.eye(m))
+    prob.A, prob.Bm, prob.Q, prob.R = dA.data_ptr(), dB.data_ptr(), Q.data_ptr(), R.data_ptr()
+    prob._Q, prob._R = Q, R
+    prob.dyn_tv, prob.dyn_batched = 1, 1
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
+    u0 = 0.1 * rng.standard_normal((m, N, B))
+    run("C4 large-state LTV", prob, n, m, N, B, f64(x0), f64(u0), None, 1, (dA, dB, 1, 1), steps=5, warmup=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3", "c4"]
+    if "c3" in which:
+        c3()
+    if "c4" in which:
+        c4()
