@@ -1,0 +1,148 @@
+"""GPU edge cases of the hot path (the reference has no unit tests; these follow its semantics line by line):
+degenerate horizons, ragged batches, the no-limits quirk, infinite bounds, NaN controls, divergence bookkeeping,
+the maximum number of line-search candidates."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def ddp():
+    import ddp_amd
+    ddp_amd.default_handle()
+    return ddp_amd
+
+
+def _lq(rng, n, m, N, B):
+    from oracle import np_restatement as npr
+    P = npr.make_lq_problem(rng, n=n, m=m, T=N)
+    x = rng.standard_normal((n, N, B)); u = 0.3 * rng.standard_normal((m, N, B))
+    cx = np.einsum("ij,jtb->itb", P["Q"], x); cu = np.einsum("ij,jtb->itb", P["R"], u)
+    return P, x, u, cx, cu
+
+
+@pytest.mark.parametrize("impl", ["general", "fast", "dpp"])
+@pytest.mark.parametrize("N", [1, 2, 3, 9])
+def test_back_pass_short_horizons(ddp, monkeypatch, impl, N):
+    """N=1: only the terminal assignments (backward_pass.jl:234-236); N=2: a single Riccati step"""
+    from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_BACKPASS", impl)
+    rng = np.random.default_rng(N)
+    P, x, u, cx, cu = _lq(rng, 10, 2, N, 3)
+    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], 0.5, 1, None, x, u)
+    for b in range(3):
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], 0.5, 1,
+                                                  None, x[..., b], u[..., b])
+        assert div[b] == d == 0
+        assert np.array_equal(Vxx[:, :, N - 1, b], P["Q"]) and np.array_equal(Vx[:, N - 1, b], cx[:, N - 1, b])
+        assert not pol.K[:, :, N - 1, b].any() and not pol.k[:, N - 1, b].any()
+        for got, ref in ((pol.K[..., b], K), (pol.k[..., b], k), (Vx[..., b], vx), (Vxx[..., b], vxx), (dV[:, b], dv)):
+            assert np.max(np.abs(got - ref)) <= RTOL * max(1e-300, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("impl", ["general", "fast", "dpp"])
+@pytest.mark.parametrize("B", [1, 2, 5, 7])
+def test_back_pass_ragged_batches(ddp, monkeypatch, impl, B):
+    """batch sizes that do not fill a wavefront's four 16-lane rows"""
+    from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_BACKPASS", impl)
+    rng = np.random.default_rng(40 + B)
+    P, x, u, cx, cu = _lq(rng, 10, 2, 21, B)
+    lam = 10.0 ** rng.uniform(-3, 0, B)
+    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], lam, 2, None, x, u)
+    for b in range(B):
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], lam[b], 2,
+                                                  None, x[..., b], u[..., b])
+        assert div[b] == d == 0 and relerr(Vxx[..., b], vxx) < RTOL and relerr(pol.K[..., b], K) < RTOL and relerr(dV[:, b], dv) < RTOL
+
+
+@pytest.mark.parametrize("impl", ["general", "dpp"])
+def test_no_limits_quirk_lims11_gt_lims12(ddp, monkeypatch, impl):
+    """backward_pass.jl:31: `lims[1,1] > lims[1,2]` selects the Cholesky branch even though limits were passed"""
+    monkeypatch.setenv("DDP_BACKPASS", impl)
+    g = load_golden("bp_lti_n10m2_reg1")
+    weird = np.array([[1.0, -1.0], [-0.01, 0.01]])          # first row reversed -> "no limits"
+    d0, p0, Vx0, Vxx0, dV0 = ddp.back_pass(g["cx"], g["cu"], g["cxx"], g["cxu"], g["cuu"], g["fx"], g["fu"], 1.0, 1, None, g["x"], g["u"])
+    d1, p1, Vx1, Vxx1, dV1 = ddp.back_pass(g["cx"], g["cu"], g["cxx"], g["cxu"], g["cuu"], g["fx"], g["fu"], 1.0, 1, weird, g["x"], g["u"])
+    assert d0 == d1 == 0
+    assert relerr(p1.K, g["K"]) < RTOL and relerr(Vxx1, g["Vxx"]) < RTOL and relerr(p1.K, p0.K) < 1e-12
+
+
+def test_boxqp_infinite_bounds_and_codes(ddp):
+    from oracle import oracle_ctypes as oc
+    H = np.array([[2.0, 0.3], [0.3, 1.0]]); g = np.array([0.3, -0.2])
+    inf = np.inf * np.ones(2)
+    x, res, Hf, free = ddp.boxQP(H, g, -inf, inf, np.zeros(2))
+    xr, rr, *_ = oc.boxqp(H, g, -inf, inf, np.zeros(2))
+    assert res == rr and res >= 1 and np.allclose(x, -np.linalg.solve(H, g)) and free.all()
+    x, res, Hf, free = ddp.boxQP(np.eye(2), np.array([5.0, -5.0]), -np.ones(2), np.ones(2), np.array([-1.0, 1.0]))
+    assert res == 6 and not free.any() and Hf.size == 0 and np.array_equal(x, [-1.0, 1.0])
+    x, res, *_ = ddp.boxQP(np.array([[1.0, 0.0], [0.0, -1.0]]), np.ones(2), -np.ones(2), np.ones(2), np.zeros(2))
+    assert res == 0                                              # swallowed PosDefException (Q10)
+    x, res, *_ = ddp.boxQP(np.eye(2), np.zeros(2), -np.ones(2), np.ones(2), np.zeros(2))
+    assert res == 5
+
+
+@pytest.mark.parametrize("impl", ["dpp", "group"])
+def test_forward_pass_nan_controls_are_zeroed(ddp, monkeypatch, impl):
+    """`u[isnan.(u)] .= 0` inside f (demo_linear.jl:43) mutates unew through the view"""
+    from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_FORWARD", impl)
+    g = load_golden("fwd_lq_n10m2")
+    u = g["u"].copy(); u[0, 5] = np.nan; u[1, 17] = np.nan
+    prob = ddp.LQProblem(g["A"], g["B"], g["Q"], g["R"])
+    xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(), g["x0"], u, None, 1.0, prob, None)
+    p = oc.make_problem("lq", 10, 2, u.shape[1], A=g["A"], B=g["B"], Q=g["Q"], R=g["R"])
+    xr, ur, cr = oc.forward_pass(p, None, g["x0"], u, None, 1.0, None)
+    assert un[0, 5] == 0.0 and un[1, 17] == 0.0 and np.isfinite(xn).all()
+    assert relerr(xn, xr) < RTOL and relerr(un, ur) < RTOL and relerr(cn, cr) < RTOL
+
+
+@pytest.mark.parametrize("impl", ["dpp", "group"])
+def test_forward_pass_sixteen_alphas_and_ragged_batch(ddp, monkeypatch, impl):
+    from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_FORWARD", impl)
+    g = load_golden("fwd_lq_n10m2")
+    N = g["u"].shape[1]
+    B = 3
+    rng = np.random.default_rng(2)
+    x0 = g["x0"][:, None] + 0.1 * rng.standard_normal((10, B))
+    u = np.stack([g["u"]] * B, -1); x = np.stack([g["x"]] * B, -1)
+    K = np.stack([g["K"]] * B, -1); k = np.stack([g["k"]] * B, -1)
+    alphas = 10.0 ** np.linspace(0.2, -3, 16)
+    prob = ddp.LQProblem(g["A"], g["B"], g["Q"], g["R"])
+    xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(N, 10, 2, K, k), x0, u, x, alphas, prob, None)
+    p = oc.make_problem("lq", 10, 2, N, A=g["A"], B=g["B"], Q=g["Q"], R=g["R"])
+    for b in range(B):
+        for j in (0, 7, 15):
+            xr, ur, cr = oc.forward_pass(p, (g["K"], g["k"]), x0[:, b], g["u"], g["x"], float(alphas[j]), None)
+            assert relerr(xn[..., b, j], xr) < RTOL and relerr(un[..., b, j], ur) < RTOL and relerr(cn[..., b, j], cr) < RTOL
+
+
+def test_ilqg_initial_divergence_is_reported(ddp):
+    """iLQG.jl:205-210: an initial control sequence that blows up for every α returns `nothing` (status -1 in a batch)"""
+    n, m, N = 10, 2, 400
+    A = 1.5 * np.eye(n); Bm = np.ones((n, m)); Q = np.eye(n); R = np.eye(m)
+    prob = ddp.LQProblem(A, Bm, Q, R)
+    x0 = 1e3 * np.ones(n); u0 = np.ones((m, N))
+    assert ddp.iLQG(prob, x0, u0) is None
+    x0b = np.stack([x0, 1e-3 * np.ones(n)], 1); u0b = np.stack([u0, np.zeros((m, N))], -1)
+    out = ddp.iLQG(prob, x0b, u0b, max_iter=3)
+    assert int(out[6]["stats"][0, 0]) == -1
+
+
+def test_ilqg_lambda_exit_and_per_trajectory_status(ddp):
+    """a batch mixing an easy LQ problem with one whose back pass can never succeed (negative-definite R, λmax small)"""
+    from oracle import np_restatement as npr
+    from oracle import oracle_ctypes as oc
+    P = npr.make_lq_problem(np.random.default_rng(4), T=80)
+    prob = ddp.LQProblem(P["A"], P["B"], P["Q"], -1e3 * np.eye(2))
+    out = ddp.iLQG(prob, P["x0"], P["u0"], λmax=1e2)
+    p = oc.make_problem("lq", 10, 2, 80, A=P["A"], B=P["B"], Q=P["Q"], R=-1e3 * np.eye(2))
+    ref = oc.ilqg(p, P["x0"], P["u0"], lam_max=1e2)
+    st = out[6]["stats"][:, 0]
+    assert int(st[0]) == ref[6]["status"] == 3 and int(st[3]) == ref[6]["n_backpass"] and st[5] == ref[6]["lam"]
