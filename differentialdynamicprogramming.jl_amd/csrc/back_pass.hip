@@ -530,6 +530,10 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
 #ifndef DDP_FAST_BUILD
     if (d->n == 4 && d->m == 1) return launch_nm<4, 1>(h, d, a);
     if (d->n == 6 && d->m == 3) return launch_nm<6, 3>(h, d, a);
+    if (force != 'b' && force != 'g') {                          // n=64, m=8: fp64 matrix cores
+        const int rc = ddp_launch_back_pass_mfma(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) return rc;
+    }
     if (d->n > DDP_MAX_N_GENERIC || force == 'b') {               // large states: 256-thread work-group per trajectory
         const int rc = ddp_launch_back_pass_big(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;

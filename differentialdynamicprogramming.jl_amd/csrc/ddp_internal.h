@@ -66,6 +66,12 @@ int ddp_launch_back_pass_big(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const double *fu, const double *lambda, const double *lims, const double *u,
                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge);
+// n=64, m=8 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64); returns 1 for any other shape
+int ddp_launch_back_pass_mfma(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                              const double *fu, const double *lambda, const double *lims, const double *u,
+                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                              double *Vxx, double *dV, int32_t *diverge);
 // 16-lane DPP-row forward pass + separate cost kernel; returns 1 when the shape has no such kernel
 int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
                             const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
@@ -86,6 +92,52 @@ __device__ __forceinline__ double ddp_rsqrt(double x)
 int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
                            const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
                            const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);
+
+// Upper Cholesky of H (column-major M x M, upper triangle read) with RECIPROCAL pivots: fills the strictly upper
+// entries of R and ri[j] = 1/R[j][j].  Division-free (v_rsq_f64 + Newton), which matters where every lane repeats
+// the factorisation.  Returns 0, or j+1 for the first non-positive pivot (LAPACK potrf semantics).
+template <int M>
+__device__ __forceinline__ int ddp_chol_rinv(const double (&H)[M * M], double (&R)[M * M], double (&ri)[M])
+{
+    int fail = 0;
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+        double ajj = H[c + M * c];
+#pragma unroll
+        for (int k2 = 0; k2 < c; ++k2) ajj -= R[k2 + M * c] * R[k2 + M * c];
+        if (!(ajj > 0.0) && fail == 0) fail = c + 1;
+        ri[c] = ddp_rsqrt(ajj);
+#pragma unroll
+        for (int c2 = c + 1; c2 < M; ++c2) {
+            double s = H[c + M * c2];
+#pragma unroll
+            for (int k2 = 0; k2 < c; ++k2) s -= R[k2 + M * c] * R[k2 + M * c2];
+            R[c + M * c2] = s * ri[c];
+        }
+    }
+    return fail;
+}
+// b <- -(R'R)\b with the factor of ddp_chol_rinv
+template <int M>
+__device__ __forceinline__ void ddp_rsolve_neg(const double (&R)[M * M], const double (&ri)[M], double (&b)[M])
+{
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+        double s = b[c];
+#pragma unroll
+        for (int k2 = 0; k2 < c; ++k2) s -= R[k2 + M * c] * b[k2];
+        b[c] = s * ri[c];
+    }
+#pragma unroll
+    for (int c = M - 1; c >= 0; --c) {
+        double s = b[c];
+#pragma unroll
+        for (int k2 = c + 1; k2 < M; ++k2) s -= R[c + M * k2] * b[k2];
+        b[c] = s * ri[c];
+    }
+#pragma unroll
+    for (int c = 0; c < M; ++c) b[c] = -b[c];
+}
 
 // Hand-off between the lanes of ONE wavefront through LDS.  The kernels that use it run one wave per
 // work-group, so no s_barrier is needed: LDS operations of a wave execute in issue order, the only

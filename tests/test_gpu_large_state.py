@@ -40,11 +40,13 @@ def _problem(rng, n, m, N, B, tv_cost):
     return cx, cu, cxx, cxu, cuu, fx, fu, u
 
 
-@pytest.mark.parametrize("n,m", [(64, 8), (40, 4)])
+@pytest.mark.parametrize("n,m,impl", [(64, 8, "auto"), (64, 8, "big"), (40, 4, "auto")])   # auto at (64,8) = MFMA kernel
 @pytest.mark.parametrize("tv_cost", [False, True])
 @pytest.mark.parametrize("regType,lims", [(1, False), (2, False), (1, True)])
-def test_back_pass_large(ddp, n, m, tv_cost, regType, lims):
+def test_back_pass_large(ddp, monkeypatch, n, m, impl, tv_cost, regType, lims):
     from oracle import oracle_ctypes as oc
+    if impl != "auto":
+        monkeypatch.setenv("DDP_BACKPASS", impl)
     rng = np.random.default_rng(n + 10 * regType + tv_cost)
     N, B = 12, 3
     cx, cu, cxx, cxu, cuu, fx, fu, u = _problem(rng, n, m, N, B, tv_cost)
