@@ -12,10 +12,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libddp_amd.so")
-SOURCES = ["capi.hip", "back_pass.hip", "back_pass_fast.hip", "back_pass_dpp.hip", "back_pass_big.hip", "back_pass_mfma.hip","forward_pass.hip", "forward_pass_dpp.hip", "forward_pass_big.hip", "df.hip", "ilqg.hip"]
+SOURCES = ["capi.hip", "back_pass.hip", "back_pass_fast.hip", "back_pass_dpp.hip", "back_pass_big.hip", "back_pass_mfma.hip", "back_pass_mx.hip",
+           "forward_pass.hip", "forward_pass_dpp.hip", "forward_pass_big.hip", "df.hip", "ilqg.hip"]
 HEADERS = ["ddp_internal.h", "boxqp_dev.h", os.path.join("..", "..", "include", "ddp_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-but-set-variable", "-Wno-unused-variable"]
+
+
+# MFMA accumulators stay in the (unified) VGPR file: no v_accvgpr_read/write shuffles around every product
+EXTRA_FLAGS = {"back_pass_mx.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale(target, deps):
@@ -29,7 +34,7 @@ def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
     if _stale(obj, deps):
-        cmd = ["hipcc"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

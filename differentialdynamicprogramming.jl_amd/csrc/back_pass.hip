@@ -510,6 +510,10 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     // DDP_BACKPASS=general|fast|dpp forces one (A/B timing, tests of every code path).
     const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
+    if (force == 'x') {                                       // one 16x16 fp64 MFMA tile per trajectory (back_pass_mx.hip)
+        const int rc = ddp_launch_back_pass_mx(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) return rc;
+    }
     if (force != 'g' && force != 'b') {
         if (force != 'd' && (force == 'f' || d->B < 2048)) {
             const int rc = ddp_launch_back_pass_fast(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);

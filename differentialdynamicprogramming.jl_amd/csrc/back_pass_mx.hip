@@ -1,0 +1,370 @@
+// back_pass_mx.hip — backward pass for the unconstrained (Cholesky) path, n = 10, m = 2, on the fp64 MATRIX
+// cores: one wavefront per trajectory, every matrix of a time step lives in ONE 16x16 v_mfma_f64_16x16x4_f64
+// tile held in registers.  Same arithmetic as src/backward_pass.jl:162-252 + :28-42,:64-76.
+//
+// Why: at the BASELINE batch (1024 trajectories = one wave per SIMD) the pass is bound by the dependent
+// instruction chain of a time step, not by HBM.  The vector kernels (back_pass_fast/_dpp) spend ~300
+// instructions per step, most of them moving operands between lanes (LDS reads, DPP broadcasts, readlanes).
+// The MFMA register layouts make that movement disappear:
+//
+//   tile layouts (lane = 16*l4 + l15):   A operand: A[i = l15][k = l4]      B operand: B[k = l4][j = l15]
+//                                        accumulator register r: D[row = l4 + 4r][col = l15]
+//   Since a product sums over k, the k index may be permuted as long as A and B use the same permutation.
+//   With k = l4 + 4s for MFMA step s, accumulator register s of one product IS operand register s of the next:
+//
+//   GEMM1  W = Vxx·F + C1      A_s = Vxx (accumulator layout; Vxx is symmetric), B_s = F_s                    3 MFMA
+//   GEMM2  G = F'·W + H        A_s = F_s (the same registers), B_s = W_s (the accumulator of GEMM1)           3 MFMA
+//   VALUE  V = G + [K' Qux']·[T; K]    one k=4 MFMA: k-slices (K0,T0) (K1,T1) (Qux0,K0) (Qux1,K1)             1 MFMA
+//   where F = [fx fu] (10 x 12), H = [cxx cxu; cxu' cuu], T = Quu·K + Qux, and column 12 of the tile carries the
+//   vectors: W[:,12] := Vx (injected through C1), H[:,12] = [cx;cu], so G[:,12] = [Qx;Qu], the solve of
+//   "column 12" is k_i, and V[:,12] = Vx_i — the vector recursion costs no extra instruction.
+//   G rows 10,11 (= Qux | Quu | Qu) are replicated to all four 16-lane rows by two gfx950 row swaps
+//   (v_permlane32_swap, v_permlane16_swap), the 2x2 Quu is broadcast inside the rows by DPP, the 2x2 system is
+//   solved redundantly by every lane, so that K and T are lane-local and feed the value MFMA directly.
+//   ½(V + V') (:71-72) takes one trip through a padded LDS tile (write the accumulator, read it transposed).
+// Measured on gfx950 (profiles/microbench/chain_latency.hip): the fp64 MFMA occupies the SIMD for 64 cycles and
+// vector instructions do not overlap with it, so a step costs  7 MFMA x 64  +  ~5.5 cycles per vector instruction;
+// the kernel is therefore written to minimise the INSTRUCTION COUNT of a step (~70 vector instructions).
+#include "ddp_internal.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+struct BPXArgs {
+    int N, B;
+    int fx_batched, cost_batched;
+    const double *cx, *cu, *cxx, *cxu, *cuu, *fx, *fu, *lambda;
+    const int32_t *active;
+    double *K, *k, *Quu, *Vx, *Vxx, *dV;
+    int32_t *diverge;
+};
+
+__device__ const double mx_zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+constexpr int n = 10, m = 2, p = 12, VC = 12;      // VC: tile column that carries the vectors
+constexpr int PD = 4;                               // prefetch distance (time steps) of the streamed operands
+constexpr int TLD = 17;                             // leading dimension of the LDS transpose tile (odd: no bank conflicts)
+constexpr int TZERO = TLD * 16;                     // a cell that stays 0.0
+
+template <int L>
+__device__ __forceinline__ double row_bcast(double x) { return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + L, 0xf, 0xf, true); }
+
+__device__ __forceinline__ double rcp_nr(double x)
+{   // 1/x: hardware estimate + two Newton steps
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// x holds tile rows (8, 9, 10, 11) in the four 16-lane rows of the wave.
+//   z  <- rows (10, 11, 10, 11): "the u-row with the parity of my 16-lane row"
+//   q0 <- row 10 everywhere, q1 <- row 11 everywhere
+__device__ __forceinline__ void spread_rows23(double x, double &z, double &q0, double &q1)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const u2v a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);      // .y = rows (2,3,2,3)
+    const u2v c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const u2v e = __builtin_amdgcn_permlane16_swap(a.y, a.y, false, false);    // .x = row 2 x4, .y = row 3 x4
+    const u2v f = __builtin_amdgcn_permlane16_swap(c.y, c.y, false, false);
+    z = __hiloint2double((int)c.y, (int)a.y);
+    q0 = __hiloint2double((int)f.x, (int)e.x);
+    q1 = __hiloint2double((int)f.y, (int)e.y);
+}
+
+typedef const __attribute__((address_space(1))) double *gdp;     // explicit global loads: a FLAT load forces s_waitcnt vmcnt(0)
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn &&f)
+{
+    if constexpr (I < E) { f(IC<I>{}); static_for<I + 1, E>(f); }
+}
+
+struct Stream {          // a per-lane operand that moves by `stride` bytes per time step (0: time-invariant)
+    const char *base;
+    unsigned stride;
+    const char *cur;     // cursor of the prefetcher
+    __device__ __forceinline__ double at(int t) const { return *(gdp)(base + (size_t)stride * (unsigned)t); }
+    __device__ __forceinline__ void seek(int t) { cur = base + (size_t)stride * (unsigned)t; }
+    __device__ __forceinline__ double next() const { return *(gdp)cur; }
+    __device__ __forceinline__ void back() { cur -= stride; }
+};
+
+template <bool FXTV, bool CTV, bool REG2>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+    if (a.active && a.active[b] == 0) return;
+    const int N = a.N;
+    constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+
+    __shared__ __attribute__((aligned(16))) double lds[TLD * 16 + 16];      // transpose tile + zero cells
+
+    const double *cx = a.cx + (size_t)n * N * b, *cu = a.cu + (size_t)m * N * b;
+    const double *fx = a.fx + (a.fx_batched ? nn * (FXTV ? N : 1) * b : 0);
+    const double *fu = a.fu + (a.fx_batched ? nm * (FXTV ? N : 1) * b : 0);
+    const double *cxx = a.cxx + (a.cost_batched ? nn * (CTV ? N : 1) * b : 0);
+    const double *cxu = a.cxu + (a.cost_batched ? nm * (CTV ? N : 1) * b : 0);
+    const double *cuu = a.cuu + (a.cost_batched ? mm * (CTV ? N : 1) * b : 0);
+    double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b, *Quug = a.Quu + mm * N * b,
+           *Vxg = a.Vx + (size_t)n * N * b, *Vxxg = a.Vxx + nn * N * b;
+    const double lam = a.lambda[b];
+
+    // ---- terminal step (backward_pass.jl:234-236 / :197-199)
+    const size_t tl = (size_t)(N - 1);
+    for (int e = lane; e < n * n; e += DDP_WAVE) Vxxg[nn * tl + e] = cxx[(CTV ? nn * tl : 0) + e];
+    if (lane < n) Vxg[(size_t)n * tl + lane] = cx[(size_t)n * tl + lane];
+    if (lane < 4) Quug[mm * tl + lane] = cuu[(CTV ? mm * tl : 0) + lane];
+    if (lane < 2 * n) Kg[nm * tl + lane] = 0.0;
+    if (lane < m) kg[(size_t)m * tl + lane] = 0.0;
+    if (N < 2) {
+        if (lane == 0) { a.dV[2 * b] = 0.0; a.dV[2 * b + 1] = 0.0; a.diverge[b] = 0; }
+        return;
+    }
+    for (int e = lane; e < TLD * 16 + 16; e += DDP_WAVE) lds[e] = 0.0;
+
+    // ---- per-lane operand streams ------------------------------------------------------------------------------
+    auto h_stream = [&](int row, int col) -> Stream {       // H = [cxx cxu; cxu' cuu] (p x p), zero outside
+        if (col < p && row < p) {
+            if (row < n && col < n) return Stream{(const char *)(cxx + row + n * col), CTV ? (unsigned)(nn * 8) : 0u, nullptr};
+            if (row < n) return Stream{(const char *)(cxu + row + n * (col - n)), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
+            if (col < n) return Stream{(const char *)(cxu + col + n * (row - n)), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
+            return Stream{(const char *)(cuu + (row - n) + m * (col - n)), CTV ? (unsigned)(mm * 8) : 0u, nullptr};
+        }
+        return Stream{(const char *)mx_zero, 0u, nullptr};
+    };
+    auto f_stream = [&](int row, int col) -> Stream {       // F = [fx fu] (n x p), zero outside
+        if (row < n && col < n) return Stream{(const char *)(fx + row + n * col), FXTV ? (unsigned)(nn * 8) : 0u, nullptr};
+        if (row < n && col < p) return Stream{(const char *)(fu + row + n * (col - n)), FXTV ? (unsigned)(nm * 8) : 0u, nullptr};
+        return Stream{(const char *)mx_zero, 0u, nullptr};
+    };
+    Stream hS[3], fS[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        hS[s] = l15 == VC ? Stream{(const char *)mx_zero, 0u, nullptr} : h_stream(l4 + 4 * s, l15);   // C of GEMM2 (column VC: below)
+        fS[s] = f_stream(l4 + 4 * s, l15);
+    }
+    // the vector [cx; cu] of tile column VC: element l4 + 4s, the same address in all lanes of a 16-lane row.
+    // Elements l4, l4+4 come from cx through a wave-uniform base; element l4+8 is cx[8..9] or cu[0..1].
+    Stream v2 = l4 < 2 ? Stream{(const char *)(cx + l4 + 8), (unsigned)(n * 8), nullptr}
+                       : Stream{(const char *)(cu + (l4 - 2)), (unsigned)(m * 8), nullptr};
+
+    // ---- loop-invariant lane constants ---------------------------------------------------------------------------
+    const double mask12 = l15 == VC ? 1.0 : 0.0;
+    const bool odd = (l4 & 1) != 0, hi2 = l4 >= 2;
+    const int wr = l4 + TLD * l15;                           // accumulator register s -> tile element (l4+4s, l15)
+    const int rdT = l15 == VC ? TZERO : l15 + TLD * l4;      // its transpose (l15, l4+4s): + 4*TLD per register
+    const int rdS = l15 == VC ? 0 : 4 * TLD;
+    // Vxx | Vx ride on the same three stores: columns < n: Vxx[l4+4s, col]; column VC: Vx[l4+4s]
+    const bool v_act01 = l15 < n || l15 == VC, v_act2 = v_act01 && l4 < 2;
+    const double vscl = l15 == VC ? 1.0 : 0.5;               // registers hold V + V'; column VC holds Vx itself
+    char *vst = l15 == VC ? (char *)(Vxg + (size_t)n * (tl - 1) + l4) : (char *)(Vxxg + nn * (tl - 1) + l4 + n * (l15 < n ? l15 : 0));
+    const unsigned vst_stride = l15 == VC ? (unsigned)(n * 8) : (unsigned)(nn * 8);
+    // K | k | Quu ride on one store: lanes of rows 2,3: columns <n: K[a, col]; column VC: k[a]; columns n..n+1: Quu[a, col-n]
+    const bool quu_lane = hi2 && (l15 == n || l15 == n + 1);
+    const bool kq_act = hi2 && l15 <= VC;
+    const int a2 = hi2 ? l4 - 2 : 0;
+    char *kq = l15 < n ? (char *)(Kg + nm * (tl - 1) + a2 + m * l15)
+                       : (l15 == VC ? (char *)(kg + (size_t)m * (tl - 1) + a2) : (char *)(Quug + mm * (tl - 1) + a2 + m * (l15 < p ? l15 - n : 0)));
+    const unsigned kq_stride = l15 < n ? (unsigned)(nm * 8) : (l15 == VC ? (unsigned)(m * 8) : (unsigned)(mm * 8));
+
+    // ---- register-resident operands -------------------------------------------------------------------------------
+    double F[3], Fh[3], Hc[3];                               // F_s, ½F_s (B of GEMM1: A carries 2 Vxx), C (H)
+    double vr[PD][3], hr[CTV ? PD : 1][3], fr[FXTV ? PD : 1][3];
+    const int i0 = N - 2;
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+        const int t = i0 - j > 0 ? i0 - j : 0;
+        const double *cxt = cx + (size_t)n * t;
+        vr[j][0] = *(gdp)(cxt + l4); vr[j][1] = *(gdp)(cxt + l4 + 4); vr[j][2] = v2.at(t);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (FXTV) fr[j][s] = fS[s].at(t);
+            if (CTV) hr[j][s] = hS[s].at(t);
+        }
+    }
+    {
+        const int t = i0 - PD > 0 ? i0 - PD : 0;
+        v2.seek(t);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { hS[s].seek(t); fS[s].seek(t); }
+    }
+    if (!FXTV) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { F[s] = fS[s].at(0); Fh[s] = 0.5 * F[s]; }
+    }
+    if (!CTV) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) Hc[s] = hS[s].at(0);
+    }
+
+    // value function of the terminal step in tile layout: S = 2 Vxx, c1 = Vx in column VC
+    double S[3];
+    d4 c1;
+    {
+        const Stream hs[3] = {h_stream(l4, l15), h_stream(l4 + 4, l15), h_stream(l4 + 8, l15)};
+        double c1v[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int row = l4 + 4 * s;
+            S[s] = (l15 < n && row < n) ? 2.0 * hs[s].at((int)tl) : 0.0;
+            c1v[s] = (l15 == VC && row < n) ? cx[(size_t)n * tl + row] : 0.0;
+        }
+        c1 = d4{c1v[0], c1v[1], c1v[2], 0.0};
+    }
+    wave_sync();
+    // all set-up loads have landed: the waits inside the loop are then computed from the steady state only
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+
+    double dVa = 0.0, dVp = 0.0;                    // Σ k'Qu  and the per-row halves of Σ k'(Quu k + Qu)
+    int diverge = 0;
+    // One time step.  No exits inside: a diverged trajectory (wave-uniform) keeps stepping through garbage with its
+    // stores switched off until the loop around the step looks at `diverge` — an exit edge here would make the waits at
+    // the loop head cover the path "just refilled this ring slot -> loop head" and drain the memory queue every time.
+    auto step = [&](const int i, auto slot_c) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_c)::value;
+        const bool okp = diverge == 0;
+        // ---- operands of this step (ring slot `slot`; the slot is refilled at the END of the step, when its old
+        //      contents are dead, so that the prefetch lands in the same registers: no copies, no early waits)
+        const d4 c = d4{fma(mask12, vr[slot][0], CTV ? hr[slot][0] : Hc[0]), fma(mask12, vr[slot][1], CTV ? hr[slot][1] : Hc[1]),
+                        fma(mask12, vr[slot][2], CTV ? hr[slot][2] : Hc[2]), 0.0};
+        if (FXTV) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { F[s] = fr[slot][s]; Fh[s] = 0.5 * F[s]; }
+        }
+        // ================= GEMM1: W = Vxx·F, column VC := Vx =========================================================
+        d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], Fh[0], c1, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1], Fh[1], w, 0, 0, 0);
+        w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[2], Fh[2], w, 0, 0, 0);
+        // ================= GEMM2: G = F'W + H, column VC: [cx;cu] + F'Vx  (:203-210) ================================
+        d4 g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], w.x, c, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], w.y, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], w.z, g, 0, 0, 0);
+        // ================= gains (backward_pass.jl:30-42) =============================================================
+        double Z, Q0, Q1;                                  // G rows 10 | 11 (Qux | Quu | Qu): own-parity row, row 10, row 11
+        spread_rows23(g.z, Z, Q0, Q1);
+        double F00, F01, F11;                              // QuuF (:205-207)
+        if (REG2) {                                        // u-rows of F'(W + λF) + H: Qux_reg, QuuF
+            d4 gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], fma(lam, F[0], w.x), c, 0, 0, 0);
+            gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], fma(lam, F[1], w.y), gr, 0, 0, 0);
+            gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], fma(lam, F[2], w.z), gr, 0, 0, 0);
+            double zr;
+            spread_rows23(gr.z, zr, Q0, Q1);               // column VC of the regularised rows is still Qu (F[:,VC] = 0)
+            F00 = row_bcast<n>(Q0); F01 = row_bcast<n + 1>(Q0); F11 = row_bcast<n + 1>(Q1);
+        } else {
+            F00 = row_bcast<n>(Q0) + lam; F01 = row_bcast<n + 1>(Q0); F11 = row_bcast<n + 1>(Q1) + lam;
+        }
+        // x = -(QuuF)\b for every column b = (Q0, Q1)[:, j]: K (:42); column VC: k_i (:41).  Explicit 2x2 inverse:
+        // positive definite <=> F00 > 0 and det > 0 — the pivots of cholesky(Hermitian(QuuF)) (:35-38)
+        const double det = fma(F00, F11, -(F01 * F01));
+        const bool bad = !(F00 > 0.0) || !(det > 0.0);
+        const double nidet = -rcp_nr(det);
+        const double K0 = fma(F11, Q0, -(F01 * Q1)) * nidet;
+        const double K1 = fma(F00, Q1, -(F01 * Q0)) * nidet;
+        // my u-row: K_a, T_a = Qux_a + Quu[a,:]·K  (:64); a = parity of the 16-lane row
+        const double Ksel = odd ? K1 : K0;
+        const double Tsel = fma(row_bcast<n + 1>(Z), K1, fma(row_bcast<n>(Z), K0, Z));
+        // ================= value update (:69-72): V = G + [K' Qux']·[T; K] ===========================================
+        const double Aop = hi2 ? Z : Ksel;
+        const double Bop = hi2 ? Ksel : Tsel;
+        const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Bop, g, 0, 0, 0);
+        // ---- while the value MFMA runs: outputs that do not depend on it, bookkeeping
+        const bool badu = __builtin_amdgcn_readfirstlane((int)bad) != 0;
+        if (kq_act && okp && (quu_lane || !badu)) *(double *)kq = quu_lane ? Aop : Bop;   // (:75-76); a failing step keeps Quu_i only
+        kq -= kq_stride;
+        if (okp && !badu) {                                // column VC: k'Qu and k_a (Quu k + Qu)_a  (:68)
+            dVa = fma(K1, Q1, fma(K0, Q0, dVa));
+            dVp = fma(Ksel, Tsel, dVp);
+        }
+        if (okp && badu) diverge = i + 1;                  // diverge = i (:37-38)
+        // ---- ½(V + V') through the transpose tile; registers keep V + V' (column VC: Vx)
+        lds[wr] = v.x; lds[wr + 4] = v.y; lds[wr + 8] = v.z;
+        wave_sync();
+        S[0] = v.x + lds[rdT]; S[1] = v.y + lds[rdT + rdS]; S[2] = v.z + lds[rdT + 2 * rdS];
+        c1 = d4{S[0] * mask12, S[1] * mask12, S[2] * mask12, 0.0};
+        if (okp && !badu) {
+            if (v_act01) { *(double *)vst = vscl * S[0]; *(double *)(vst + 32) = vscl * S[1]; }
+            if (v_act2) *(double *)(vst + 64) = vscl * S[2];
+        }
+        vst -= vst_stride;
+        wave_sync();                                       // the tile is free again
+        {   // refill the ring slot with the step PD ahead (clamped: always a valid load)
+            const int tp = i - PD > 0 ? i - PD : 0;
+            const double *cxt = cx + (size_t)n * tp;
+            asm volatile("" ::: "memory");
+            vr[slot][0] = *(gdp)(cxt + l4); vr[slot][1] = *(gdp)(cxt + l4 + 4); vr[slot][2] = v2.next();
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (FXTV) fr[slot][s] = fS[s].next();
+                if (CTV) hr[slot][s] = hS[s].next();
+            }
+            if (i - PD > 0) {
+                v2.back();
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    if (FXTV) fS[s].back();
+                    if (CTV) hS[s].back();
+                }
+            }
+        }
+    };
+    int i = i0;
+    while (i >= PD - 1 && diverge == 0) {
+        static_for<0, PD>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc); });
+        i -= PD;
+    }
+    static_for<0, PD - 1>([&](auto sc) __attribute__((always_inline)) {    // the last (N-1) mod PD steps
+        if (i >= 0 && diverge == 0) { step(i, sc); --i; }
+    });
+
+    if (diverge) {   // outputs earlier in time than the failing step are zero (backward_pass.jl:226-229)
+        const size_t ie = (size_t)diverge;          // = i + 1
+        for (size_t e = lane; e < nm * ie; e += DDP_WAVE) Kg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)m * ie; e += DDP_WAVE) kg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)n * ie; e += DDP_WAVE) Vxg[e] = 0.0;
+        for (size_t e = lane; e < nn * ie; e += DDP_WAVE) Vxxg[e] = 0.0;
+        for (size_t e = lane; e < mm * (ie - 1); e += DDP_WAVE) Quug[e] = 0.0;
+    }
+    {   // dV (:68): [Σ k'Qu, ½ Σ k'Quu k];  k'Quu k = k'(Quu k + Qu) - k'Qu, the two u-rows live in lanes VC and 16+VC
+        const int plo = __builtin_amdgcn_readlane(__double2loint(dVp), 16 + VC), phi = __builtin_amdgcn_readlane(__double2hiint(dVp), 16 + VC);
+        const double kT = dVp + __hiloint2double(phi, plo);
+        if (lane == VC) { a.dV[2 * b] = dVa; a.dV[2 * b + 1] = 0.5 * (kT - dVa); }
+    }
+    if (lane == 0) a.diverge[b] = diverge;
+}
+
+template <bool REG2>
+int launch_mx(ddp_handle h, const ddp_bp_desc *d, const BPXArgs &a)
+{
+    const dim3 grid(d->B), block(DDP_WAVE);
+    const int key = (d->fx_tv ? 2 : 0) | (d->cost_tv ? 1 : 0);
+    switch (key) {
+    case 0: hipLaunchKernelGGL((back_pass_mx_kernel<false, false, REG2>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((back_pass_mx_kernel<false, true, REG2>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((back_pass_mx_kernel<true, false, REG2>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((back_pass_mx_kernel<true, true, REG2>), grid, block, 0, h->stream, a); break;
+    }
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+}   // namespace
+
+// returns 1 if this shape is not handled here, 0 launched, <0 error
+int ddp_launch_back_pass_mx(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                            const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                            const double *fu, const double *lambda, const int32_t *active, double *K,
+                            double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge)
+{
+    if (d->has_lims || d->m != 2 || d->n != 10) return 1;
+    BPXArgs a;
+    a.N = d->N; a.B = d->B; a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched;
+    a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    return d->regType == 2 ? launch_mx<true>(h, d, a) : launch_mx<false>(h, d, a);
+}

@@ -54,6 +54,12 @@ int ddp_launch_back_pass_fast(ddp_handle h, const ddp_bp_desc *d, const double *
                               const double *fu, const double *lambda, const int32_t *active, double *K,
                               double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
 
+// n=10, m=2, no limits: one wave per trajectory, all matrices of a step in one 16x16 fp64 MFMA tile; 1 = not applicable
+int ddp_launch_back_pass_mx(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                            const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                            const double *fu, const double *lambda, const int32_t *active, double *K,
+                            double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
+
 // 16-lane DPP-row backward pass (4 trajectories per wave); returns 1 when the shape has no such kernel
 int ddp_launch_back_pass_dpp(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
