@@ -44,7 +44,7 @@ struct BPXArgs {
 __device__ const double mx_zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 constexpr int n = 10, m = 2, p = 12, VC = 12;      // VC: tile column that carries the vectors
-constexpr int PD = 4;                               // prefetch distance (time steps) of the streamed operands
+constexpr int PD = 8;                               // prefetch distance (time steps) of the streamed operands
 constexpr int TLD = 17;                             // leading dimension of the LDS transpose tile (odd: no bank conflicts)
 constexpr int TZERO = TLD * 16;                     // a cell that stays 0.0
 
@@ -61,19 +61,38 @@ __device__ __forceinline__ double rcp_nr(double x)
     return y;
 }
 
-// x holds tile rows (8, 9, 10, 11) in the four 16-lane rows of the wave.
-//   z  <- rows (10, 11, 10, 11): "the u-row with the parity of my 16-lane row"
-//   q0 <- row 10 everywhere, q1 <- row 11 everywhere
-__device__ __forceinline__ void spread_rows23(double x, double &z, double &q0, double &q1)
+// z holds tile rows (10, 11, 10, 11) in the four 16-lane rows of the wave ("the u-row with the parity of my row"):
+//   q0 <- row 10 everywhere, q1 <- row 11 everywhere   (one v_permlane16_swap per dword)
+__device__ __forceinline__ void spread_pair(double z, double &q0, double &q1)
 {
-    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-    const u2v a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);      // .y = rows (2,3,2,3)
-    const u2v c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    const u2v e = __builtin_amdgcn_permlane16_swap(a.y, a.y, false, false);    // .x = row 2 x4, .y = row 3 x4
-    const u2v f = __builtin_amdgcn_permlane16_swap(c.y, c.y, false, false);
-    z = __hiloint2double((int)c.y, (int)a.y);
+    const unsigned lo = (unsigned)__double2loint(z), hi = (unsigned)__double2hiint(z);
+    const u2v e = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // .x = rows (0,0,2,2), .y = rows (1,1,3,3)
+    const u2v f = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     q0 = __hiloint2double((int)f.x, (int)e.x);
     q1 = __hiloint2double((int)f.y, (int)e.y);
+}
+
+// acc += x[lane L of my 16-lane row] * y    (v_fmac_f64_dpp: the broadcast costs nothing); RM: the 16-lane rows that take part.
+// The hazard recogniser does not look into inline asm, so the CALLER keeps two rules: (1) acc and x are never the
+// in-flight result of an MFMA (pass such a value through a real VALU instruction first: `+ 0.0`); (2) x was not written by
+// the VALU within the last two instructions — FENCE = true puts the two wait states in front when that cannot be ruled out.
+template <int L, int RM = 0xf, bool FENCE = false>
+__device__ __forceinline__ void fmac_bcast(double &acc, double x, double y)
+{
+    if (FENCE) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:%4 bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(L), "n"(RM));
+    else asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:%4 bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(L), "n"(RM));
+}
+
+// Stores of a lane subset without the compiler's save-exec / branch / restore sequence around each of them (the step is
+// issue-bound, scalar instructions count).  The wave runs with all 64 lanes enabled everywhere else in the kernel.
+__device__ __forceinline__ void store_masked(char *ptr, double a, unsigned long long lanes)
+{
+    asm volatile("s_mov_b64 exec, %2\n\tglobal_store_dwordx2 %0, %1, off\n\ts_mov_b64 exec, -1" ::"v"(ptr), "v"(a), "s"(lanes) : "memory");
+}
+__device__ __forceinline__ void store2_masked(char *ptr, double a, double b, unsigned long long lanes)
+{
+    asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, off\n\tglobal_store_dwordx2 %0, %2, off offset:32\n\ts_mov_b64 exec, -1"
+                 ::"v"(ptr), "v"(a), "v"(b), "s"(lanes) : "memory");
 }
 
 typedef const __attribute__((address_space(1))) double *gdp;     // explicit global loads: a FLAT load forces s_waitcnt vmcnt(0)
@@ -143,16 +162,23 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         if (row < n && col < p) return Stream{(const char *)(fu + row + n * (col - n)), FXTV ? (unsigned)(nm * 8) : 0u, nullptr};
         return Stream{(const char *)mx_zero, 0u, nullptr};
     };
-    Stream hS[3], fS[3];
+    // Tile rows 12..15 repeat the u-rows 10, 11, 10, 11 (F columns 12..15 of the A operand of GEMM2 repeat columns 10, 11, and
+    // so do the rows of H): accumulator register 3 of G then holds, in EVERY 16-lane row, the u-row with the parity of that row.
+    const int urow = n + (l4 & 1);
+    Stream hS[4], fS[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        hS[s] = l15 == VC ? Stream{(const char *)mx_zero, 0u, nullptr} : h_stream(l4 + 4 * s, l15);   // C of GEMM2 (column VC: below)
-        fS[s] = f_stream(l4 + 4 * s, l15);
+    for (int s = 0; s < 4; ++s) {
+        const int row = s < 3 ? l4 + 4 * s : urow;
+        hS[s] = l15 == VC ? Stream{(const char *)mx_zero, 0u, nullptr} : h_stream(row, l15);   // C of GEMM2 (column VC: below)
+        if (s < 3) fS[s] = f_stream(l4 + 4 * s, l15 < p ? l15 : n + (l15 & 1));
     }
-    // the vector [cx; cu] of tile column VC: element l4 + 4s, the same address in all lanes of a 16-lane row.
-    // Elements l4, l4+4 come from cx through a wave-uniform base; element l4+8 is cx[8..9] or cu[0..1].
-    Stream v2 = l4 < 2 ? Stream{(const char *)(cx + l4 + 8), (unsigned)(n * 8), nullptr}
-                       : Stream{(const char *)(cu + (l4 - 2)), (unsigned)(m * 8), nullptr};
+    // The vector e = [cx; cu] (p entries) of tile column VC costs ONE load per step: lane (l4, j) fetches e[j + l4], so that
+    // the entry l4 + 4s that accumulator register s wants in column VC sits in lane 4s of the same 16-lane row for EVERY
+    // row — a row broadcast folded into the multiply-add that builds the C operand (register 3: e[10 + (l4&1)] = lane 10
+    // of rows 0,1 and lane 8 of rows 2,3).
+    const int eidx = l15 + l4 < p ? l15 + l4 : p - 1;
+    Stream eS = eidx < n ? Stream{(const char *)(cx + eidx), (unsigned)(n * 8), nullptr}
+                         : Stream{(const char *)(cu + (eidx - n)), (unsigned)(m * 8), nullptr};
 
     // ---- loop-invariant lane constants ---------------------------------------------------------------------------
     const double mask12 = l15 == VC ? 1.0 : 0.0;
@@ -168,55 +194,55 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     // K | k | Quu ride on one store: lanes of rows 2,3: columns <n: K[a, col]; column VC: k[a]; columns n..n+1: Quu[a, col-n]
     const bool quu_lane = hi2 && (l15 == n || l15 == n + 1);
     const bool kq_act = hi2 && l15 <= VC;
+    const unsigned long long lanes01 = __builtin_amdgcn_ballot_w64(v_act01), lanes2k = __builtin_amdgcn_ballot_w64(hi2 ? kq_act : v_act2);
     const int a2 = hi2 ? l4 - 2 : 0;
-    char *kq = l15 < n ? (char *)(Kg + nm * (tl - 1) + a2 + m * l15)
-                       : (l15 == VC ? (char *)(kg + (size_t)m * (tl - 1) + a2) : (char *)(Quug + mm * (tl - 1) + a2 + m * (l15 < p ? l15 - n : 0)));
-    const unsigned kq_stride = l15 < n ? (unsigned)(nm * 8) : (l15 == VC ? (unsigned)(m * 8) : (unsigned)(mm * 8));
+    char *kq = !hi2 ? vst + 64
+                    : (l15 < n ? (char *)(Kg + nm * (tl - 1) + a2 + m * l15)
+                               : (l15 == VC ? (char *)(kg + (size_t)m * (tl - 1) + a2) : (char *)(Quug + mm * (tl - 1) + a2 + m * (l15 < p ? l15 - n : 0))));
+    const unsigned kq_stride = !hi2 ? vst_stride : (l15 < n ? (unsigned)(nm * 8) : (l15 == VC ? (unsigned)(m * 8) : (unsigned)(mm * 8)));
 
     // ---- register-resident operands -------------------------------------------------------------------------------
-    double F[3], Fh[3], Hc[3];                               // F_s, ½F_s (B of GEMM1: A carries 2 Vxx), C (H)
-    double vr[PD][3], hr[CTV ? PD : 1][3], fr[FXTV ? PD : 1][3];
+    const double hmask = l15 < p ? 0.5 : 0.0;
+    double F[3], Fh[3], Hc[4];                               // F_s (A of GEMM2), ½F_s without the repeated columns (B of GEMM1: A carries 2 Vxx), C (H)
+    double er[PD], hr[CTV ? PD : 1][4], fr[FXTV ? PD : 1][3];
     const int i0 = N - 2;
 #pragma unroll
     for (int j = 0; j < PD; ++j) {
         const int t = i0 - j > 0 ? i0 - j : 0;
-        const double *cxt = cx + (size_t)n * t;
-        vr[j][0] = *(gdp)(cxt + l4); vr[j][1] = *(gdp)(cxt + l4 + 4); vr[j][2] = v2.at(t);
+        er[j] = eS.at(t);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (FXTV) fr[j][s] = fS[s].at(t);
+        for (int s = 0; s < 4; ++s) {
+            if (FXTV && s < 3) fr[j][s] = fS[s].at(t);
             if (CTV) hr[j][s] = hS[s].at(t);
         }
     }
     {
         const int t = i0 - PD > 0 ? i0 - PD : 0;
-        v2.seek(t);
+        eS.seek(t);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { hS[s].seek(t); fS[s].seek(t); }
+        for (int s = 0; s < 4; ++s) { hS[s].seek(t); if (s < 3) fS[s].seek(t); }
     }
     if (!FXTV) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { F[s] = fS[s].at(0); Fh[s] = 0.5 * F[s]; }
+        for (int s = 0; s < 3; ++s) { F[s] = fS[s].at(0); Fh[s] = hmask * F[s]; }
     }
     if (!CTV) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) Hc[s] = hS[s].at(0);
+        for (int s = 0; s < 4; ++s) Hc[s] = hS[s].at(0);
     }
+    const d4 Hc4 = d4{Hc[0], Hc[1], Hc[2], Hc[3]};
 
-    // value function of the terminal step in tile layout: S = 2 Vxx, c1 = Vx in column VC
+    // value function of the terminal step in tile layout: S = 2 Vxx, column VC: Vx
     double S[3];
-    d4 c1;
     {
         const Stream hs[3] = {h_stream(l4, l15), h_stream(l4 + 4, l15), h_stream(l4 + 8, l15)};
-        double c1v[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int row = l4 + 4 * s;
-            S[s] = (l15 < n && row < n) ? 2.0 * hs[s].at((int)tl) : 0.0;
-            c1v[s] = (l15 == VC && row < n) ? cx[(size_t)n * tl + row] : 0.0;
+            S[s] = (l15 < n && row < n) ? 2.0 * hs[s].at((int)tl) : ((l15 == VC && row < n) ? cx[(size_t)n * tl + row] : 0.0);
         }
-        c1 = d4{c1v[0], c1v[1], c1v[2], 0.0};
     }
+    const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
     wave_sync();
     // all set-up loads have landed: the waits inside the loop are then computed from the steady state only
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
@@ -231,32 +257,41 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         const bool okp = diverge == 0;
         // ---- operands of this step (ring slot `slot`; the slot is refilled at the END of the step, when its old
         //      contents are dead, so that the prefetch lands in the same registers: no copies, no early waits)
-        const d4 c = d4{fma(mask12, vr[slot][0], CTV ? hr[slot][0] : Hc[0]), fma(mask12, vr[slot][1], CTV ? hr[slot][1] : Hc[1]),
-                        fma(mask12, vr[slot][2], CTV ? hr[slot][2] : Hc[2]), 0.0};
+        // C operand of GEMM2: H only.  The vector e = [cx;cu] of column VC enters later and in place: G[:,VC] is used by the
+        // u-rows (Qu, below) and, linearly, by V[:,VC] = Vx (added after the value MFMA).
+        const d4 c = CTV ? d4{hr[slot][0], hr[slot][1], hr[slot][2], hr[slot][3]} : Hc4;
+        const double e = er[slot];
         if (FXTV) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) { F[s] = fr[slot][s]; Fh[s] = 0.5 * F[s]; }
+            for (int s = 0; s < 3; ++s) { F[s] = fr[slot][s]; Fh[s] = hmask * F[s]; }
         }
-        // ================= GEMM1: W = Vxx·F, column VC := Vx =========================================================
-        d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], Fh[0], c1, 0, 0, 0);
+        // ================= GEMM1: W = Vxx·F; column VC := Vx (F[:,VC] = 0, S[:,VC] = Vx) ============================
+        d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], Fh[0], zero4, 0, 0, 0);
         w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1], Fh[1], w, 0, 0, 0);
         w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[2], Fh[2], w, 0, 0, 0);
+        const double W[3] = {fma(S[0], mask12, w.x), fma(S[1], mask12, w.y), fma(S[2], mask12, w.z)};
         // ================= GEMM2: G = F'W + H, column VC: [cx;cu] + F'Vx  (:203-210) ================================
-        d4 g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], w.x, c, 0, 0, 0);
-        g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], w.y, g, 0, 0, 0);
-        g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], w.z, g, 0, 0, 0);
+        d4 g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], W[0], c, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], W[1], g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], W[2], g, 0, 0, 0);
         // ================= gains (backward_pass.jl:30-42) =============================================================
-        double Z, Q0, Q1;                                  // G rows 10 | 11 (Qux | Quu | Qu): own-parity row, row 10, row 11
-        spread_rows23(g.z, Z, Q0, Q1);
+        double Z = g.w + 0.0;                              // G row 10 | 11 (Qux | Quu | Qu) with the parity of my 16-lane row
+        fmac_bcast<10, 0x3, true>(Z, e, mask12);                 // column VC: Qu = cu + fu'Vx   (e[10 + (l4&1)]: lane 10 of rows 0,1,
+        fmac_bcast<8, 0xc>(Z, e, mask12);                  //                               lane 8 of rows 2,3)
+        double Q0, Q1;                                     // row 10, row 11 in every lane
         double F00, F01, F11;                              // QuuF (:205-207)
-        if (REG2) {                                        // u-rows of F'(W + λF) + H: Qux_reg, QuuF
-            d4 gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], fma(lam, F[0], w.x), c, 0, 0, 0);
-            gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], fma(lam, F[1], w.y), gr, 0, 0, 0);
-            gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], fma(lam, F[2], w.z), gr, 0, 0, 0);
-            double zr;
-            spread_rows23(gr.z, zr, Q0, Q1);               // column VC of the regularised rows is still Qu (F[:,VC] = 0)
+        if (REG2) {                                        // u-rows of F'(W + λF) + H: Qux_reg, QuuF;  λF = 2λ·(½F)
+            const double lam2 = 2.0 * lam;
+            d4 gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], fma(lam2, Fh[0], W[0]), c, 0, 0, 0);
+            gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], fma(lam2, Fh[1], W[1]), gr, 0, 0, 0);
+            gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], fma(lam2, Fh[2], W[2]), gr, 0, 0, 0);
+            double Zr = gr.w + 0.0;                        // column VC of the regularised rows is still Qu (F[:,VC] = 0)
+            fmac_bcast<10, 0x3, true>(Zr, e, mask12);
+            fmac_bcast<8, 0xc>(Zr, e, mask12);
+            spread_pair(Zr, Q0, Q1);
             F00 = row_bcast<n>(Q0); F01 = row_bcast<n + 1>(Q0); F11 = row_bcast<n + 1>(Q1);
         } else {
+            spread_pair(Z, Q0, Q1);
             F00 = row_bcast<n>(Q0) + lam; F01 = row_bcast<n + 1>(Q0); F11 = row_bcast<n + 1>(Q1) + lam;
         }
         // x = -(QuuF)\b for every column b = (Q0, Q1)[:, j]: K (:42); column VC: k_i (:41).  Explicit 2x2 inverse:
@@ -268,15 +303,15 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         const double K1 = fma(F00, Q1, -(F01 * Q0)) * nidet;
         // my u-row: K_a, T_a = Qux_a + Quu[a,:]·K  (:64); a = parity of the 16-lane row
         const double Ksel = odd ? K1 : K0;
-        const double Tsel = fma(row_bcast<n + 1>(Z), K1, fma(row_bcast<n>(Z), K0, Z));
+        double Tsel = Z;
+        fmac_bcast<n, 0xf, true>(Tsel, Z, K0);
+        fmac_bcast<n + 1>(Tsel, Z, K1);
         // ================= value update (:69-72): V = G + [K' Qux']·[T; K] ===========================================
         const double Aop = hi2 ? Z : Ksel;
-        const double Bop = hi2 ? Ksel : Tsel;
+        const double Bop = hi2 ? (quu_lane ? Z : Ksel) : Tsel;   // (columns 10,11 of V are junk: their B lanes carry Quu for the store below)
         const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Bop, g, 0, 0, 0);
         // ---- while the value MFMA runs: outputs that do not depend on it, bookkeeping
-        const bool badu = __builtin_amdgcn_readfirstlane((int)bad) != 0;
-        if (kq_act && okp && (quu_lane || !badu)) *(double *)kq = quu_lane ? Aop : Bop;   // (:75-76); a failing step keeps Quu_i only
-        kq -= kq_stride;
+        const bool badu = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (okp && !badu) {                                // column VC: k'Qu and k_a (Quu k + Qu)_a  (:68)
             dVa = fma(K1, Q1, fma(K0, Q0, dVa));
             dVp = fma(Ksel, Tsel, dVp);
@@ -286,28 +321,31 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         lds[wr] = v.x; lds[wr + 4] = v.y; lds[wr + 8] = v.z;
         wave_sync();
         S[0] = v.x + lds[rdT]; S[1] = v.y + lds[rdT + rdS]; S[2] = v.z + lds[rdT + 2 * rdS];
-        c1 = d4{S[0] * mask12, S[1] * mask12, S[2] * mask12, 0.0};
-        if (okp && !badu) {
-            if (v_act01) { *(double *)vst = vscl * S[0]; *(double *)(vst + 32) = vscl * S[1]; }
-            if (v_act2) *(double *)(vst + 64) = vscl * S[2];
-        }
+        fmac_bcast<0>(S[0], e, mask12);                    // column VC: Vx += cx  (e[l4 + 4s]: lane 4s of my 16-lane row)
+        fmac_bcast<4>(S[1], e, mask12);
+        fmac_bcast<8>(S[2], e, mask12);
+        // Stores are unconditional: a diverged trajectory writes garbage into time steps that are zero-filled after the loop
+        // (behind a vmcnt(0) wait); the failing step itself leaves the Quu_i the reference returns.
+        store2_masked(vst, vscl * S[0], vscl * S[1], lanes01);
+        // rows 8, 9 of Vxx | Vx (16-lane rows 0,1) and K | k | Quu (:75-76) (rows 2,3) share one store
+        store_masked(kq, hi2 ? Bop : vscl * S[2], lanes2k);
         vst -= vst_stride;
+        kq -= kq_stride;
         wave_sync();                                       // the tile is free again
         {   // refill the ring slot with the step PD ahead (clamped: always a valid load)
             const int tp = i - PD > 0 ? i - PD : 0;
-            const double *cxt = cx + (size_t)n * tp;
             asm volatile("" ::: "memory");
-            vr[slot][0] = *(gdp)(cxt + l4); vr[slot][1] = *(gdp)(cxt + l4 + 4); vr[slot][2] = v2.next();
+            er[slot] = eS.next();
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                if (FXTV) fr[slot][s] = fS[s].next();
+            for (int s = 0; s < 4; ++s) {
+                if (FXTV && s < 3) fr[slot][s] = fS[s].next();
                 if (CTV) hr[slot][s] = hS[s].next();
             }
             if (i - PD > 0) {
-                v2.back();
+                eS.back();
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    if (FXTV) fS[s].back();
+                for (int s = 0; s < 4; ++s) {
+                    if (FXTV && s < 3) fS[s].back();
                     if (CTV) hS[s].back();
                 }
             }
@@ -324,6 +362,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
 
     if (diverge) {   // outputs earlier in time than the failing step are zero (backward_pass.jl:226-229)
         const size_t ie = (size_t)diverge;          // = i + 1
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the garbage of the steps after the failure has landed
         for (size_t e = lane; e < nm * ie; e += DDP_WAVE) Kg[e] = 0.0;
         for (size_t e = lane; e < (size_t)m * ie; e += DDP_WAVE) kg[e] = 0.0;
         for (size_t e = lane; e < (size_t)n * ie; e += DDP_WAVE) Vxg[e] = 0.0;

@@ -104,6 +104,47 @@ __global__ void probe(double *out, unsigned long long *cyc, double seed)
     for (int i = 0; i < REP / 4; ++i) { sh[lane] = x; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); x = sh[lane ^ 1] + 1.0; }
     asm volatile("" : "+v"(x));
     t1 = now(); cyc[q++] = t1 - t0;
+    // 12: shader clock vs the 100 MHz real-time counter over a long dependent chain
+    {
+        unsigned long long r0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t0 = now(); PIN();
+        for (int i = 0; i < 20000; ++i) { x = fma(x, y, z); asm volatile("" : "+v"(x)); }
+        t1 = now();
+        unsigned long long r1 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cyc[12] = t1 - t0; cyc[13] = r1 - r0;
+    }
+    // 14: dependent MFMA chain with 12 independent v_fma_f64 between consecutive MFMAs (do they hide under the MFMA?)
+    {
+        double bq[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) bq[j] = x + j;
+        t0 = now(); PIN();
+#pragma unroll
+        for (int i = 0; i < REP / 4; ++i) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, z, acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) bq[j] = fma(bq[j], y, z);
+        }
+        asm volatile("" : "+v"(acc));
+#pragma unroll
+        for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(bq[j]));
+        t1 = now(); cyc[14] = t1 - t0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) x += bq[j];
+    }
+    // 15: one 64-lane global_store_dwordx2 (per-lane 64-bit addresses, 32-byte pieces) per 8 dependent v_fma_f64
+    {
+        double *dst = out + 64 + (lane & 3) + 10 * (lane >> 2);
+        t0 = now(); PIN();
+#pragma unroll
+        for (int i = 0; i < REP / 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x = fma(x, y, z);
+            dst[160 * i] = x;
+        }
+        asm volatile("" : "+v"(x));
+        t1 = now(); cyc[15] = t1 - t0;
+    }
     // 11: empty timer
     t0 = now(); t1 = now(); cyc[q++] = t1 - t0;
     out[lane] = x + y + (double)u;
@@ -112,7 +153,8 @@ __global__ void probe(double *out, unsigned long long *cyc, double seed)
 int main()
 {
     double *o; unsigned long long *c, h[16];
-    (void)hipMalloc(&o, 64 * sizeof(double)); (void)hipMalloc(&c, sizeof(h));
+    double *obig;
+    (void)hipMalloc(&o, (64 + 160 * 20 + 200) * sizeof(double)); (void)hipMalloc(&c, sizeof(h));
     for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, o, c, 0.25);
     (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
     const char *nm[12] = {"dependent v_fma_f64", "8 independent v_fma_f64 chains", "dependent MFMA f64 16x16x4 (accumulate)",
@@ -121,5 +163,8 @@ int main()
                           "dependent f64 select (2 x v_cndmask_b32), x2", "dependent v_add_f64", "LDS write -> hand-off -> read", "timer overhead"};
     const int cnt[12] = {REP, REP, REP, REP, REP, REP, REP, REP / 2, REP, REP, REP / 4, 1};
     for (int q = 0; q < 12; ++q) printf("%-52s %8llu cycles total, %7.1f per op\n", nm[q], h[q], (double)(h[q] - h[11]) / cnt[q]);
+    printf("MFMA + 12 independent v_fma_f64: %.1f cycles per group (MFMA alone 63, 12 fma alone ~50)\n", (double)(h[14] - h[11]) / (REP / 4));
+    printf("8 dependent v_fma_f64 + 1 global_store_dwordx2: %.1f cycles per group (8 fma alone ~41)\n", (double)(h[15] - h[11]) / (REP / 4));
+    printf("s_memtime ticks %llu over %llu ticks of the 100 MHz counter -> s_memtime runs at %.1f MHz\n", h[12], h[13], 100.0 * (double)h[12] / (double)h[13]);
     return 0;
 }
