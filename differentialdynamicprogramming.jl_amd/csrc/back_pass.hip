@@ -501,21 +501,23 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     DDP_CHECK(d->regType == 1 || d->regType == 2, "back_pass: regType must be 1 or 2 (got %d)", d->regType);
     DDP_CHECK(!d->has_lims || (lims && u), "back_pass: has_lims needs lims and u");
     DDP_CHECK(d->m <= DDP_MAX_M, "back_pass: m=%d exceeds DDP_MAX_M=%d", d->m, DDP_MAX_M);
-    // Kernel choice.  Three implementations of the same arithmetic exist:
+    // Kernel choice.  Several implementations of the same arithmetic exist:
+    //   x (mx)  one 16x16 fp64 MFMA tile per trajectory, one wave each (back_pass_mx.hip; n=10, m=2, no limits): shortest
+    //           dependent chain per time step, best while the batch gives a SIMD only one or two waves (B=1024: 0.55 ms
+    //           against 0.90 ms for `fast`); measured cross-over with `dpp` between B=4096 and B=8192;
     //   dpp     16 lanes per trajectory (back_pass_dpp.hip): fewest instructions per trajectory-step, best once the
-    //           batch gives every SIMD a few wavefronts;
-    //   fast    64 lanes per trajectory, LDS-lean (back_pass_fast.hip; n=10, m=2, no limits): shortest dependency
-    //           chain, best for small batches (one wave per SIMD or less);
+    //           batch gives every SIMD a few wavefronts; also the kernel for control limits;
+    //   fast    64 lanes per trajectory, LDS-lean vector kernel (back_pass_fast.hip; n=10, m=2, no limits);
     //   general 64 lanes per trajectory, any n <= 32 / m <= 8 / limits (this file).
-    // DDP_BACKPASS=general|fast|dpp forces one (A/B timing, tests of every code path).
+    // DDP_BACKPASS=x|general|fast|dpp|big forces one (A/B timing, tests of every code path).
     const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
-    if (force == 'x') {                                       // one 16x16 fp64 MFMA tile per trajectory (back_pass_mx.hip)
+    if (force == 'x' || (force == 0 && d->B < 6144)) {
         const int rc = ddp_launch_back_pass_mx(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;
     }
     if (force != 'g' && force != 'b') {
-        if (force != 'd' && (force == 'f' || d->B < 2048)) {
+        if (force == 'f') {
             const int rc = ddp_launch_back_pass_fast(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
             if (rc <= 0) return rc;
         }
