@@ -161,6 +161,38 @@ int ddp_oracle_pass_batch_lq(const ddp_oracle_problem *p, int B,
                              double *K, double *k, double *Quu, double *Vx, double *Vxx,
                              double *dV, double *xnew, double *unew, double *cnew);
 
+/* ---- KL-constrained path (ddp_oracle_kl.c): src/backward_pass.jl:259-350, src/klutils.jl, src/forward_pass.jl:37-56,
+ *      src/iLQGkl.jl (single-constraint branch).  PARITY UNPINNED — see the header of ddp_oracle_kl.c. ------------- */
+void ddp_oracle_kl_terms(int n, int m, int T, const double *K, const double *k, const double *Sigmai,
+                         double *cx, double *cu, double *cxx, double *cxu /* [m,n,T] */, double *cuu);
+int ddp_oracle_back_pass_gps(int n, int m, int N,
+                             const double *cx, const double *cu, const double *cxx, const double *cxu, const double *cuu,
+                             const double *fx, const double *fu, const double *lims, const double *u,
+                             const double *cxkl, const double *cukl, const double *cxxkl, const double *cxukl,
+                             const double *cuukl, const double *eta, int eta_tv,
+                             double *K, double *k, double *Quu, double *Quui, double *Vx, double *Vxx, double *dV);
+void ddp_oracle_forward_covariance(int n, int m, int N, const double *fx, const double *R1,
+                                   const double *K, const double *Sigma, double *sigmanew /* [(n+m),(n+m),N] */);
+void ddp_oracle_model_covariance(int n, int m, int N, const double *fx, const double *fu, const double *x,
+                                 const double *u, double *R1);
+int ddp_oracle_kl_div_wiki(int n, int m, int T, const double *xnew, const double *xold, const double *sigmanew,
+                           const double *Kn, const double *kn, const double *Sn,
+                           const double *Kp, const double *kp, const double *Sp, const double *Sip, double *kldiv);
+int ddp_oracle_calc_eta(double *etabracket3, double divergence_mean, double kl_step);
+
+typedef struct {
+    int    status;        /* 1 SUCCESS |KL - kl_step| < 0.1 kl_step (iLQGkl.jl:169), 2 EXIT eta > eta_max (:174), 3 max_iter (:234) */
+    int    iter, n_backpass, satisfied;
+    double eta[3], divergence, g_norm, dV[2], cost0;
+} ddp_oracle_ilqgkl_result;
+
+int ddp_oracle_ilqgkl(const ddp_oracle_problem *p, const double *x0 /* [n,N] pre-rolled */, double cost0,
+                      const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                      const double *model_fx /* [n,n,N] */, const double *R1, const double *lims,
+                      double kl_step, int max_iter, const double *etabracket3, double del0,
+                      double *x, double *u, double *K, double *k, double *Quu, double *Quui,
+                      double *Vx, double *Vxx, double *cost, ddp_oracle_ilqgkl_result *res);
+
 #ifdef __cplusplus
 }
 #endif

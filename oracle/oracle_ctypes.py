@@ -45,8 +45,8 @@ class ILQGResult(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libddp_oracle.so")
-    src = os.path.join(_HERE, "ddp_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ddp_oracle.c", "ddp_oracle_kl.c", "ddp_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libddp_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -184,3 +184,96 @@ def ilqg(p, x0, u0, lims=None, trace_cap=2048, **kw):
                 n_forward=res.n_forward, lam=res.lambda_, dlam=res.dlambda, g_norm=res.g_norm,
                 dV=np.array(res.dV[:]), trace=dict(cost=trc[:tl], lam=trl[:tl], alpha=tra[:tl]))
     return x, u, (K, k, Quu), Vx, Vxx, cost, info
+
+
+# ---------------------------------------------------------------- KL-constrained path (ddp_oracle_kl.c)
+class ILQGKLResult(C.Structure):
+    _fields_ = [("status", C.c_int), ("iter", C.c_int), ("n_backpass", C.c_int), ("satisfied", C.c_int),
+                ("eta", C.c_double * 3), ("divergence", C.c_double), ("g_norm", C.c_double), ("dV", C.c_double * 2),
+                ("cost0", C.c_double)]
+
+
+def kl_terms(K, k, Sigmai):
+    K, k, Sigmai = _f(K), _f(k), _f(Sigmai)
+    m, n, T = K.shape
+    cx = np.zeros((n, T), order="F"); cu = np.zeros((m, T), order="F"); cxx = np.zeros((n, n, T), order="F")
+    cxu = np.zeros((m, n, T), order="F"); cuu = np.zeros((m, m, T), order="F")
+    lib().ddp_oracle_kl_terms(n, m, T, _p(K), _p(k), _p(Sigmai), _p(cx), _p(cu), _p(cxx), _p(cxu), _p(cuu))
+    return cx, cu, cxx, cxu, cuu
+
+
+def back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, kl_cost_terms):
+    """Same argument order as the reference (backward_pass.jl:259).  kl_cost_terms = ((cxkl,cukl,cxxkl,cxukl,cuukl), ηbracket)
+    with ηbracket a 3-vector or a [3,N] matrix.  Returns diverge, (K, k, Quui, Quu), Vx, Vxx, dV."""
+    cx, cu, cxx, cxu, cuu, fx, fu, u = map(_f, (cx, cu, cxx, cxu, cuu, fx, fu, u))
+    kl, etab = kl_cost_terms
+    kl = [_f(a) for a in kl]
+    etab = np.asarray(etab, dtype=np.float64)
+    eta = _f(etab[1] if etab.ndim == 2 else [etab[1]])
+    m, N = u.shape
+    n = fx.shape[0]
+    K = np.zeros((m, n, N), order="F"); k = np.zeros((m, N), order="F"); Quu = np.zeros((m, m, N), order="F")
+    Quui = np.zeros((m, m, N), order="F"); Vx = np.zeros((n, N), order="F"); Vxx = np.zeros((n, n, N), order="F"); dV = np.zeros(2)
+    L = None if lims is None or np.size(lims) == 0 else _f(lims)
+    lib().ddp_oracle_back_pass_gps.restype = C.c_int
+    d = lib().ddp_oracle_back_pass_gps(n, m, N, _p(cx), _p(cu), _p(cxx), _p(cxu), _p(cuu), _p(fx), _p(fu), _p(L), _p(u),
+                                       _p(kl[0]), _p(kl[1]), _p(kl[2]), _p(kl[3]), _p(kl[4]), _p(eta), int(etab.ndim == 2),
+                                       _p(K), _p(k), _p(Quu), _p(Quui), _p(Vx), _p(Vxx), _p(dV))
+    return d, (K, k, Quui, Quu), Vx, Vxx, dV
+
+
+def forward_covariance(model_fx, R1, K, Sigma):
+    model_fx, R1, K, Sigma = _f(model_fx), _f(R1), _f(K), _f(Sigma)
+    n, _, N = model_fx.shape
+    m = K.shape[0]
+    S = np.zeros((n + m, n + m, N), order="F")
+    lib().ddp_oracle_forward_covariance(n, m, N, _p(model_fx), _p(R1), _p(K), _p(Sigma), _p(S))
+    return S
+
+
+def model_covariance(fx, fu, x, u):
+    fx, fu, x, u = _f(fx), _f(fu), _f(x), _f(u)
+    n, N = x.shape
+    R1 = np.zeros((n, n), order="F")
+    lib().ddp_oracle_model_covariance(n, u.shape[0], N, _p(fx), _p(fu), _p(x), _p(u), _p(R1))
+    return R1
+
+
+def kl_div_wiki(xnew, xold, S_new, new, prev):
+    """new/prev: dicts K,k,S,Si.  Returns the clipped vector, or inf when a logdet threw."""
+    xnew, xold, S_new = _f(xnew), _f(xold), _f(S_new)
+    a = {key: _f(new[key]) for key in ("K", "k", "S")}
+    b = {key: _f(prev[key]) for key in ("K", "k", "S", "Si")}
+    m, n, T = a["K"].shape
+    out = np.zeros(T)
+    lib().ddp_oracle_kl_div_wiki.restype = C.c_int
+    threw = lib().ddp_oracle_kl_div_wiki(n, m, T, _p(xnew), _p(xold), _p(S_new), _p(a["K"]), _p(a["k"]), _p(a["S"]),
+                                         _p(b["K"]), _p(b["k"]), _p(b["S"]), _p(b["Si"]), _p(out))
+    return np.inf if threw else out
+
+
+def calc_eta(etab, divergence_mean, kl_step):
+    e = _f(etab).copy()
+    lib().ddp_oracle_calc_eta.restype = C.c_int
+    s = lib().ddp_oracle_calc_eta(_p(e), C.c_double(divergence_mean), C.c_double(kl_step))
+    return e, bool(s)
+
+
+def ilqgkl(p, x0, cost0, prev, model, kl_step=1.0, lims=None, max_iter=50, etab=(1e-8, 1.0, 1e16), del0=1e-4):
+    n, m, N = p.n, p.m, p.N
+    CL = lib().ddp_oracle_cost_len(C.byref(p))
+    x0 = _f(x0)
+    b = {key: _f(prev[key]) for key in ("K", "k", "S", "Si")}
+    mfx, R1, e = _f(model["fx"]), _f(model["R1"]), _f(etab)
+    L = None if lims is None or np.size(lims) == 0 else _f(lims)
+    x = np.zeros((n, N), order="F"); u = np.zeros((m, N), order="F"); K = np.zeros((m, n, N), order="F"); k = np.zeros((m, N), order="F")
+    Quu = np.zeros((m, m, N), order="F"); Quui = np.zeros((m, m, N), order="F"); Vx = np.zeros((n, N), order="F")
+    Vxx = np.zeros((n, n, N), order="F"); cost = np.zeros(CL)
+    res = ILQGKLResult()
+    lib().ddp_oracle_ilqgkl.restype = C.c_int
+    lib().ddp_oracle_ilqgkl(C.byref(p), _p(x0), C.c_double(cost0), _p(b["K"]), _p(b["k"]), _p(b["S"]), _p(b["Si"]), _p(mfx), _p(R1),
+                            _p(L), C.c_double(kl_step), int(max_iter), _p(e), C.c_double(del0), _p(x), _p(u), _p(K), _p(k),
+                            _p(Quu), _p(Quui), _p(Vx), _p(Vxx), _p(cost), C.byref(res))
+    info = dict(status=res.status, iter=res.iter, n_backpass=res.n_backpass, satisfied=bool(res.satisfied), eta=np.array(res.eta[:]),
+                divergence=res.divergence, g_norm=res.g_norm, dV=np.array(res.dV[:]))
+    return x, u, dict(K=K, k=k, S=Quui, Si=Quu), Vx, Vxx, cost, info
