@@ -25,12 +25,18 @@ EXPORTS = [
     "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
     "ddp_cost_len", "ddp_forward_pass_f64_dev", "ddp_forward_pass_f64", "ddp_df_f64_dev", "ddp_df_f64",
     "ddp_ilqg_default_opts", "ddp_ilqg_f64", "ddp_ilqg_f64_dev",
+    "ddp_kl_terms_f64_dev", "ddp_kl_terms_f64", "ddp_back_pass_gps_f64_dev", "ddp_back_pass_gps_f64",
+    "ddp_forward_covariance_f64_dev", "ddp_forward_covariance_f64", "ddp_kl_div_f64_dev", "ddp_kl_div_f64",
 ]
 
 
 class BPDesc(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("n", "m", "N", "B", "fx_tv", "fx_batched", "cost_tv", "cost_batched",
                                        "regType", "has_lims")]
+
+
+class KLCostTerms(C.Structure):
+    _fields_ = [("cx", vp), ("cu", vp), ("cxx", vp), ("cxu", vp), ("cuu", vp), ("eta", vp), ("eta_tv", C.c_int)]
 
 
 class QPOpts(C.Structure):

@@ -34,6 +34,10 @@ struct BPArgs {
     const int32_t *active;
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
     int32_t *diverge;
+    // KL-augmented variant (back_pass_gps, backward_pass.jl:259-350): Q• <- Q•/η + c•kl, no λ, Quui = inv(Quu)
+    const double *cxkl, *cukl, *cxxkl, *cxukl, *cuukl, *eta;
+    int eta_tv;
+    double *Quui;
 };
 
 constexpr int TC = 8;   // time steps per cx/cu/u prefetch chunk
@@ -69,7 +73,53 @@ struct BPLds {
     }
 };
 
-template <int NS, int MS, bool FXTV, bool CTV, bool LIMS>
+// inverse of the leading m x m block of H (column-major, leading dimension MM) by Gauss-Jordan elimination with partial
+// pivoting — what `inv(Quu[:,:,i])` computes (backward_pass.jl:283,346) up to rounding order; out is m x m, ld m
+template <int MM>
+__device__ void inv_small(int m, const double (&H)[MM * MM], double *out)
+{
+    double A[MM * MM], X[MM * MM];
+#pragma unroll
+    for (int c = 0; c < MM; ++c)
+#pragma unroll
+        for (int r = 0; r < MM; ++r) { A[r + MM * c] = (r < m && c < m) ? H[r + MM * c] : (r == c ? 1.0 : 0.0); X[r + MM * c] = (r == c) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int c = 0; c < MM; ++c) {
+        if (c < m) {
+            int pr = c; double best = fabs(A[c + MM * c]);
+#pragma unroll
+            for (int r = 0; r < MM; ++r) { const double v = fabs(A[r + MM * c]); if (r > c && r < m && v > best) { best = v; pr = r; } }
+#pragma unroll
+            for (int r = 0; r < MM; ++r) {
+                if (r > c && r == pr) {                              // swap rows c and pr
+#pragma unroll
+                    for (int j = 0; j < MM; ++j) {
+                        double t = A[c + MM * j]; A[c + MM * j] = A[r + MM * j]; A[r + MM * j] = t;
+                        t = X[c + MM * j]; X[c + MM * j] = X[r + MM * j]; X[r + MM * j] = t;
+                    }
+                }
+            }
+            const double piv = 1.0 / A[c + MM * c];
+#pragma unroll
+            for (int j = 0; j < MM; ++j) { A[c + MM * j] *= piv; X[c + MM * j] *= piv; }
+#pragma unroll
+            for (int r = 0; r < MM; ++r) {
+                if (r != c && r < m) {
+                    const double f = A[r + MM * c];
+#pragma unroll
+                    for (int j = 0; j < MM; ++j) { A[r + MM * j] -= f * A[c + MM * j]; X[r + MM * j] -= f * X[c + MM * j]; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MM; ++c)
+#pragma unroll
+        for (int r = 0; r < MM; ++r)
+            if (r < m && c < m) out[r + m * c] = X[r + MM * c];
+}
+
+template <int NS, int MS, bool FXTV, bool CTV, bool LIMS, bool GPS = false>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -101,8 +151,12 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
     const double *cuu = a.cuu + (a.cost_batched ? mm * (CTV ? N : 1) * b : 0);
     double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b, *Quug = a.Quu + mm * N * b,
            *Vxg = a.Vx + (size_t)n * N * b, *Vxxg = a.Vxx + nn * N * b;
-    const double lam = a.lambda[b];
-    const int regType = a.regType;
+    const double lam = GPS ? 0.0 : a.lambda[b];
+    const int regType = GPS ? 0 : a.regType;
+    const double *cxkl = GPS ? a.cxkl + (size_t)n * N * b : nullptr, *cukl = GPS ? a.cukl + (size_t)m * N * b : nullptr,
+                 *cxxkl = GPS ? a.cxxkl + nn * N * b : nullptr, *cxukl = GPS ? a.cxukl + nm * N * b : nullptr,
+                 *cuukl = GPS ? a.cuukl + mm * N * b : nullptr, *etag = GPS ? a.eta + (a.eta_tv ? (size_t)N * b : b) : nullptr;
+    double *Quuig = GPS ? a.Quui + mm * N * b : nullptr;
     bool nolims = true;
     double limlo[MM], limhi[MM];
     if (LIMS) {
@@ -164,9 +218,21 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
         Vxg[(size_t)n * (N - 1) + e] = v;
     }
     for (int e = lane; e < m * m; e += DDP_WAVE) {
-        const double v = cuu[(CTV ? mm * (N - 1) : 0) + e];
-        Quug[mm * (N - 1) + e] = v;
+        double v = cuu[(CTV ? mm * (N - 1) : 0) + e];
         if (!CTV) cuus[e] = v;
+        if (GPS) { v = v / etag[a.eta_tv ? N - 1 : 0] + cuukl[mm * (N - 1) + e]; QuuFs[e] = v; }   // :282
+        Quug[mm * (N - 1) + e] = v;
+    }
+    if (GPS) {                                                      // Quui[:,:,N] = inv(Quu[:,:,N])  (:283)
+        wave_sync();
+        if (lane == 0) {
+            double Hn[MM * MM];
+#pragma unroll
+            for (int c2 = 0; c2 < MM; ++c2)
+#pragma unroll
+                for (int r2 = 0; r2 < MM; ++r2) Hn[r2 + MM * c2] = (r2 < m && c2 < m) ? QuuFs[r2 + m * c2] : 0.0;
+            inv_small<MM>(m, Hn, Quuig + mm * (N - 1));
+        }
     }
     for (int e = lane; e < m * n; e += DDP_WAVE) {
         Kg[nm * (N - 1) + e] = 0.0;
@@ -258,7 +324,9 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
 #pragma unroll
                 for (int l = 0; l < NMAX; ++l)
                     if (l < n) s += fc[l] * vs[l];
-                Qs[j] = (j < n ? cxi[j] : cui[j - n]) + s;       // backward_pass.jl:240-241
+                double qv = (j < n ? cxi[j] : cui[j - n]) + s;   // backward_pass.jl:240-241
+                if (GPS) qv = qv / etag[a.eta_tv ? i : 0] + (j < n ? cxkl[(size_t)n * i + j] : cukl[(size_t)m * i + (j - n)]);   // :295,298
+                Qs[j] = qv;
             }
         }
         wave_sync();
@@ -276,6 +344,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
                 for (int l = 0; l < NMAX; ++l)
                     if (l < n) s += fc[l] * wc[l];
                 qxx[r] = cxxs[t_i[r] + n * t_j[r]] + s;          // backward_pass.jl:244
+                if (GPS)                                         // :299; only the symmetric part of cxxkl survives :341
+                    qxx[r] = qxx[r] / etag[a.eta_tv ? i : 0] + 0.5 * (cxxkl[nn * i + t_i[r] + n * t_j[r]] + cxxkl[nn * i + t_j[r] + n * t_i[r]]);
             }
         }
 #pragma unroll
@@ -288,7 +358,16 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
 #pragma unroll
                 for (int l = 0; l < NMAX; ++l)
                     if (l < n) { s += fc[l] * wc[l]; sr += fc[l] * fj[l]; }
-                if (j < n) {                                     // Qux, Qux_reg  (:242,246)
+                if (GPS) {                                       // Q• <- Q•/η + c•kl, no λ  (:296-297)
+                    const double et = etag[a.eta_tv ? i : 0];
+                    if (j < n) {
+                        const double v = (cxus[j + n * q] + s) / et + cxukl[nm * i + q + m * j];
+                        Quxs[q + m * j] = v; Quxrs[q + m * j] = v;
+                    } else {
+                        const int bb = j - n;
+                        Quus[q + m * bb] = (cuus[q + m * bb] + s) / et + cuukl[mm * i + q + m * bb];
+                    }
+                } else if (j < n) {                              // Qux, Qux_reg  (:242,246)
                     const double c = cxus[j + n * q];
                     Quxs[q + m * j] = c + s;
                     Quxrs[q + m * j] = c + (regType == 2 ? s + lam * sr : s);
@@ -301,6 +380,13 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
             }
         }
         wave_sync();
+        if (GPS) {                                               // Quu = .5(Quu + Quu')  (:301); it is also the matrix factorised
+            double sv = 0.0;
+            if (lane < m * m) sv = 0.5 * (Quus[lane] + Quus[(lane / m) + m * (lane % m)]);
+            wave_sync();
+            if (lane < m * m) { Quus[lane] = sv; QuuFs[lane] = sv; }
+            wave_sync();
+        }
 
         // ================= P3: gains (backward_pass.jl:30-62) =====================================
         double H[MM * MM], R[MM * MM], kk[MM];
@@ -377,6 +463,14 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
             }
             dV0 += kQu;
             dV1 += 0.5 * kQuuk;
+        }
+        if (GPS && lane == DDP_WAVE - 1) {                       // Quui[:,:,i] = inv(Quu[:,:,i])  (:346)
+            double Hq[MM * MM];
+#pragma unroll
+            for (int c2 = 0; c2 < MM; ++c2)
+#pragma unroll
+                for (int r2 = 0; r2 < MM; ++r2) Hq[r2 + MM * c2] = (r2 < m && c2 < m) ? Quus[r2 + m * c2] : 0.0;
+            inv_small<MM>(m, Hq, Quuig + mm * i);
         }
         wave_sync();
 
@@ -491,6 +585,41 @@ int launch_nm(ddp_handle h, const ddp_bp_desc *d, const BPArgs &a)
 
 }   // namespace
 
+// back_pass_gps (backward_pass.jl:259-350): run-time sizes n <= 32, m <= 8, all cost/dynamics arrays 3-D as the
+// reference's method signature requires.  Quui must be zero-filled by the caller (steps before a failure stay zero).
+int ddp_launch_back_pass_gps(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const ddp_kl_cost_terms *kl, const double *lims, const double *u,
+                             const int32_t *active, double *K, double *k, double *Quu, double *Quui, double *Vx,
+                             double *Vxx, double *dV, int32_t *diverge)
+{
+#ifndef DDP_FAST_BUILD
+    DDP_CHECK(d->n >= 1 && d->m >= 1 && d->N >= 1 && d->B >= 1, "back_pass_gps: bad sizes n=%d m=%d N=%d B=%d", d->n, d->m, d->N, d->B);
+    DDP_CHECK(d->fx_tv && d->cost_tv, "back_pass_gps: needs time-varying (3-D) fx/fu and cxx/cxu/cuu like backward_pass.jl:259");
+    DDP_CHECK(!d->has_lims || (lims && u), "back_pass_gps: has_lims needs lims and u");
+    DDP_CHECK(d->n <= DDP_MAX_N_GENERIC && d->m <= DDP_MAX_M, "back_pass_gps: n=%d m=%d has no kernel (n <= %d, m <= %d)", d->n, d->m,
+              DDP_MAX_N_GENERIC, DDP_MAX_M);
+    DDP_CHECK(kl && kl->cx && kl->cu && kl->cxx && kl->cxu && kl->cuu && kl->eta, "back_pass_gps: incomplete kl_cost_terms");
+    BPArgs a;
+    a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;
+    a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.regType = 1;
+    a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu;
+    a.lambda = nullptr; a.lims = lims; a.u = u; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    a.cxkl = kl->cx; a.cukl = kl->cu; a.cxxkl = kl->cxx; a.cxukl = kl->cxu; a.cuukl = kl->cuu; a.eta = kl->eta; a.eta_tv = kl->eta_tv;
+    a.Quui = Quui;
+    const BPLds L(d->n, d->m, d->has_lims != 0);
+    const size_t shmem = (size_t)L.total * sizeof(double);
+    const dim3 grid(d->B), block(DDP_WAVE);
+    if (d->has_lims) hipLaunchKernelGGL((back_pass_kernel<0, 0, true, true, true, true>), grid, block, shmem, h->stream, a);
+    else hipLaunchKernelGGL((back_pass_kernel<0, 0, true, true, false, true>), grid, block, shmem, h->stream, a);
+    DDP_HIP(hipGetLastError());
+    return 0;
+#else
+    DDP_CHECK(false, "back_pass_gps: not in DDP_FAST_BUILD");
+#endif
+}
+
 int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                          const double *cxx, const double *cxu, const double *cuu, const double *fx,
                          const double *fu, const double *lambda, const double *lims, const double *u,
@@ -526,7 +655,7 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
             if (rc <= 0) return rc;
         }
     }
-    BPArgs a;
+    BPArgs a = {};
     a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;
     a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.regType = d->regType;
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu;

@@ -1,0 +1,352 @@
+// kl.hip — the KL-constrained path around back_pass_gps (BASELINE config 5):
+//   ∇kl                src/klutils.jl:8-23       one lane per (time step, trajectory)
+//   forward_covariance src/forward_pass.jl:37-56 one wave per trajectory, the discrete Lyapunov chain Σ⁺ = fx Σ fx' + R1
+//   kl_div_wiki        src/klutils.jl:70-103     one wave per trajectory, lanes over time, mean over time in the wave
+// plus the C-ABI entry points of the four KL calls (the back_pass_gps kernel itself is the GPS variant of back_pass.hip).
+// None of this is on the benchmarked path; the kernels are written for clarity and coalescing, not tuned.
+#include "arena.h"
+#include "ddp_internal.h"
+
+namespace {
+
+constexpr int NMAXK = DDP_MAX_N_GENERIC, MMAXK = DDP_MAX_M;
+
+// ------------------------------------------------------------------------------------------------ ∇kl
+__global__ void kl_terms_kernel(int n, int m, long NB, const double *__restrict__ K, const double *__restrict__ k,
+                                const double *__restrict__ Si, double *__restrict__ cx, double *__restrict__ cu,
+                                double *__restrict__ cxx, double *__restrict__ cxu, double *__restrict__ cuu)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;       // flat (time, trajectory) index
+    if (t >= NB) return;
+    const size_t nm = (size_t)n * m, mm = (size_t)m * m, nn = (size_t)n * n;
+    const double *Kt = K + nm * t, *kt = k + (size_t)m * t, *S = Si + mm * t;
+    double Sik[MMAXK];
+    for (int a = 0; a < m; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < m; ++b) s += S[a + m * b] * kt[b];
+        Sik[a] = s;
+        cu[(size_t)m * t + a] = -s;                                    // cu = -Σi k   (:17)
+    }
+    for (size_t e = 0; e < mm; ++e) cuu[mm * t + e] = S[e];           // cuu = Σi     (:19)
+    for (int j = 0; j < n; ++j) {
+        double SiKj[MMAXK];
+        for (int a = 0; a < m; ++a) {
+            double s = 0.0;
+            for (int b = 0; b < m; ++b) s += S[a + m * b] * Kt[b + m * j];
+            SiKj[a] = s;
+            cxu[nm * t + a + m * j] = -s;                              // cxu = -Σi K  (:20), m x n
+        }
+        double sx = 0.0;
+        for (int a = 0; a < m; ++a) sx += Kt[a + m * j] * Sik[a];
+        cx[(size_t)n * t + j] = sx;                                    // cx = K'Σi k  (:16)
+        for (int r = 0; r < n; ++r) {                                  // cxx[:, j] = K'(Σi K[:, j])  (:18)
+            double s = 0.0;
+            for (int a = 0; a < m; ++a) s += Kt[a + m * r] * SiKj[a];
+            cxx[nn * t + r + n * j] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward_covariance
+__global__ __launch_bounds__(DDP_WAVE) void fcov_kernel(int n, int m, int N, const double *__restrict__ fx, int fx_batched,
+                                                        const double *__restrict__ R1, const double *__restrict__ K,
+                                                        const double *__restrict__ Sigma, double *__restrict__ out)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, p = n + m;
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m, pp = (size_t)p * p;
+    extern __shared__ double lds[];
+    double *S = lds, *T1 = S + nn, *F = T1 + nn, *Kl = F + nn, *KS = Kl + nm;      // Σxx, F·Σ, fx_i, K_i, K·Σ
+    const double *fxb = fx + (fx_batched ? nn * N * b : 0), *Kb = K + nm * N * b, *Sgb = Sigma + mm * N * b;
+    double *ob = out + pp * N * b;
+    for (int e = lane; e < n * n; e += DDP_WAVE) S[e] = R1[e];                    // Σ0 = R1  (:43)
+    for (size_t e = lane; e < pp * N; e += DDP_WAVE) ob[e] = 0.0;
+    wave_sync();
+    for (int i = 0; i < N; ++i) {
+        double *oi = ob + pp * i;
+        for (int e = lane; e < n * n; e += DDP_WAVE) oi[(e % n) + p * (e / n)] = S[e];        // sigmanew[ix,ix,i]
+        if (i == N - 1) break;
+        for (int e = lane; e < n * n; e += DDP_WAVE) F[e] = fxb[nn * i + e];
+        for (int e = lane; e < n * m; e += DDP_WAVE) Kl[e] = Kb[nm * i + e];
+        wave_sync();
+        for (int e = lane; e < n * n; e += DDP_WAVE) {                                        // T1 = fx·Σ
+            const int r = e % n, c = e / n;
+            double s = 0.0;
+            for (int l = 0; l < n; ++l) s += F[r + n * l] * S[l + n * c];
+            T1[e] = s;
+        }
+        for (int e = lane; e < n * m; e += DDP_WAVE) {                                        // K·Σ  (:50) and Σ·K' (:51)
+            const int a = e % m, c = e / m;
+            double s = 0.0, s2 = 0.0;
+            for (int l = 0; l < n; ++l) { s += Kl[a + m * l] * S[l + n * c]; s2 += S[c + n * l] * Kl[a + m * l]; }
+            KS[e] = s;
+            oi[(n + a) + p * c] = s;
+            oi[c + p * (n + a)] = s2;
+        }
+        wave_sync();
+        for (int e = lane; e < m * m; e += DDP_WAVE) {                                        // K Σ K' + Σ_policy  (:52)
+            const int a = e % m, bb = e / m;
+            double s = 0.0;
+            for (int l = 0; l < n; ++l) s += KS[a + m * l] * Kl[bb + m * l];
+            oi[(n + a) + p * (n + bb)] = s + Sgb[mm * i + e];
+        }
+        double nv[(NMAXK * NMAXK + DDP_WAVE - 1) / DDP_WAVE];
+#pragma unroll
+        for (int q = 0; q < (NMAXK * NMAXK + DDP_WAVE - 1) / DDP_WAVE; ++q) {                 // Σ⁺ = T1·fx' + R1  (:49)
+            const int e = lane + DDP_WAVE * q;
+            nv[q] = 0.0;
+            if (e < n * n) {
+                const int r = e % n, c = e / n;
+                double s = 0.0;
+                for (int l = 0; l < n; ++l) s += T1[r + n * l] * F[c + n * l];
+                nv[q] = s + R1[e];
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < (NMAXK * NMAXK + DDP_WAVE - 1) / DDP_WAVE; ++q) {
+            const int e = lane + DDP_WAVE * q;
+            if (e < n * n) S[e] = nv[q];
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kl_div_wiki
+// log|det A| and the sign of det A for the leading m x m block (LU with partial pivoting, like logdet of a Matrix)
+__device__ double logabsdet_small(int m, const double *Ain, int &sgn)
+{
+    double A[MMAXK * MMAXK];
+    for (int e = 0; e < m * m; ++e) A[e] = Ain[e];
+    double s = 0.0;
+    sgn = 1;
+    for (int c = 0; c < m; ++c) {
+        int pr = c; double best = fabs(A[c + m * c]);
+        for (int r = c + 1; r < m; ++r) if (fabs(A[r + m * c]) > best) { best = fabs(A[r + m * c]); pr = r; }
+        if (best == 0.0) { sgn = 0; return -INFINITY; }
+        if (pr != c) {
+            sgn = -sgn;
+            for (int j = 0; j < m; ++j) { const double t = A[c + m * j]; A[c + m * j] = A[pr + m * j]; A[pr + m * j] = t; }
+        }
+        const double d = A[c + m * c];
+        if (d < 0.0) sgn = -sgn;
+        s += log(fabs(d));
+        for (int r = c + 1; r < m; ++r) {
+            const double f = A[r + m * c] / d;
+            for (int j = c + 1; j < m; ++j) A[r + m * j] -= f * A[c + m * j];
+        }
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(DDP_WAVE) void kl_div_kernel(int n, int m, int N, const double *__restrict__ xnew,
+                                                          const double *__restrict__ xold, const double *__restrict__ sig,
+                                                          const double *__restrict__ Kn, const double *__restrict__ kn,
+                                                          const double *__restrict__ Sn, const double *__restrict__ Kp,
+                                                          const double *__restrict__ kp, const double *__restrict__ Sp,
+                                                          const double *__restrict__ Sip, double *__restrict__ kldiv,
+                                                          double *__restrict__ klmean)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, p = n + m;
+    const size_t nm = (size_t)n * m, mm = (size_t)m * m, pp = (size_t)p * p;
+    double acc = 0.0;
+    int threw = 0;
+    for (int t = lane; t < N; t += DDP_WAVE) {
+        const size_t tb = (size_t)N * b + t;
+        const double *St = sig + pp * tb, *Si = Sip + mm * tb, *Snt = Sn + mm * tb, *Spt = Sp + mm * tb;
+        const double *Knt = Kn + nm * tb, *Kpt = Kp + nm * tb;
+        double kd[MMAXK], mu[NMAXK], SKmu[MMAXK], Kmu[MMAXK];
+        for (int a = 0; a < m; ++a) kd[a] = kp[(size_t)m * tb + a] - kn[(size_t)m * tb + a];
+        for (int j = 0; j < n; ++j) mu[j] = xnew[(size_t)n * tb + j] - xold[(size_t)n * tb + j];
+        double tr1 = 0.0, q1 = 0.0;
+        for (int a = 0; a < m; ++a)
+            for (int c = 0; c < m; ++c) {
+                tr1 += Si[a + m * c] * Snt[c + m * a];                       // tr(Σip Σn)
+                q1 += kd[a] * Si[a + m * c] * kd[c];                         // k_diff'Σip k_diff
+            }
+        int sp, sn;
+        const double ldp = logabsdet_small(m, Spt, sp), ldn = logabsdet_small(m, Snt, sn);
+        if (sp < 0 || sn < 0) threw = 1;                                     // logdet throws a DomainError (:95-99)
+        double v = 0.5 * (tr1 + q1 - m + ldp - ldn);                         // :92
+        for (int a = 0; a < m; ++a) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += (Kpt[a + m * j] - Knt[a + m * j]) * mu[j];
+            Kmu[a] = s;
+        }
+        double q2 = 0.0, q3 = 0.0, tr2 = 0.0;
+        for (int a = 0; a < m; ++a) {                                        // Σip K_diff μ
+            double s = 0.0;
+            for (int c = 0; c < m; ++c) s += Si[a + m * c] * Kmu[c];
+            SKmu[a] = s;
+            q2 += Kmu[a] * s;
+            q3 += kd[a] * s;
+        }
+        for (int c = 0; c < n; ++c) {                                        // tr(K_diff'Σip K_diff Σt), Σt = sigmanew[1:n,1:n,t]
+            double SK[MMAXK];
+            for (int a = 0; a < m; ++a) {
+                double s = 0.0;
+                for (int a2 = 0; a2 < m; ++a2) s += Si[a + m * a2] * (Kpt[a2 + m * c] - Knt[a2 + m * c]);
+                SK[a] = s;
+            }
+            for (int r = 0; r < n; ++r) {
+                double s = 0.0;
+                for (int a = 0; a < m; ++a) s += (Kpt[a + m * r] - Knt[a + m * r]) * SK[a];
+                tr2 += s * St[c + p * r];
+            }
+        }
+        v += 0.5 * (q2 + tr2) + q3;                                          // :93-94
+        v = v > 0.0 ? v : 0.0;                                               // :101  (NaN -> 0 like max.(0, NaN)? no: see below)
+        kldiv[tb] = v;
+        acc += v;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off, 64); threw |= __shfl_xor(threw, off, 64); }
+    if (lane == 0) klmean[b] = threw ? INFINITY : acc / N;
+}
+
+size_t fcov_lds(int n, int m) { return ((size_t)3 * n * n + 2 * (size_t)n * m) * sizeof(double); }
+
+}   // namespace
+
+extern "C" {
+
+int ddp_kl_terms_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *K, const double *k, const double *Sigmai,
+                         double *cx, double *cu, double *cxx, double *cxu, double *cuu)
+{
+    DDP_CHECK(h && K && k && Sigmai && cx && cu && cxx && cxu && cuu, "kl_terms: null argument");
+    DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "kl_terms: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
+    const long NB = (long)N * B;
+    hipLaunchKernelGGL(kl_terms_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, h->stream, n, m, NB, K, k, Sigmai, cx, cu, cxx, cxu, cuu);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddp_back_pass_gps_f64_dev(ddp_handle h, const ddp_bp_desc *d,
+                              const double *cx, const double *cu, const double *cxx, const double *cxu, const double *cuu,
+                              const double *fx, const double *fu, const ddp_kl_cost_terms *kl,
+                              const double *lims, const double *u, const int32_t *active,
+                              double *K, double *k, double *Quu, double *Quui, double *Vx, double *Vxx, double *dV,
+                              int32_t *diverge)
+{
+    DDP_CHECK(h && d && cx && cu && cxx && cxu && cuu && fx && fu && kl && K && k && Quu && Quui && Vx && Vxx && dV && diverge,
+              "back_pass_gps: null argument");
+    DDP_HIP(hipMemsetAsync(Quui, 0, sizeof(double) * (size_t)d->m * d->m * d->N * d->B, h->stream));
+    return ddp_launch_back_pass_gps(h, d, cx, cu, cxx, cxu, cuu, fx, fu, kl, lims, u, active, K, k, Quu, Quui, Vx, Vxx, dV, diverge);
+}
+
+int ddp_forward_covariance_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *fx, int fx_batched,
+                                   const double *R1, const double *K, const double *Sigma, double *sigmanew)
+{
+    DDP_CHECK(h && fx && R1 && K && Sigma && sigmanew, "forward_covariance: null argument");
+    DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "forward_covariance: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
+    hipLaunchKernelGGL(fcov_kernel, dim3(B), dim3(DDP_WAVE), fcov_lds(n, m), h->stream, n, m, N, fx, fx_batched, R1, K, Sigma, sigmanew);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddp_kl_div_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *xnew, const double *xold,
+                       const double *sigmanew, const double *Kn, const double *kn, const double *Sn,
+                       const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                       double *kldiv, double *klmean)
+{
+    DDP_CHECK(h && xnew && xold && sigmanew && Kn && kn && Sn && Kp && kp && Sp && Sip && kldiv && klmean, "kl_div: null argument");
+    DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "kl_div: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
+    hipLaunchKernelGGL(kl_div_kernel, dim3(B), dim3(DDP_WAVE), 0, h->stream, n, m, N, xnew, xold, sigmanew, Kn, kn, Sn, Kp, kp, Sp, Sip,
+                       kldiv, klmean);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- host-pointer flavours (stage through the handle's scratch; PCIe-inclusive, for drop-in use with host arrays)
+int ddp_kl_terms_f64(ddp_handle h, int n, int m, int N, int B, const double *K, const double *k, const double *Sigmai,
+                     double *cx, double *cu, double *cxx, double *cxu, double *cuu)
+{
+    DDP_CHECK(h, "kl_terms: null handle");
+    const size_t nb = (size_t)N * B, in[] = {(size_t)m * n * nb, (size_t)m * nb, (size_t)m * m * nb},
+                 out[] = {(size_t)n * nb, (size_t)m * nb, (size_t)n * n * nb, (size_t)m * n * nb, (size_t)m * m * nb};
+    Arena A; A.h = h;
+    for (size_t s : in) A.want(s * 8);
+    for (size_t s : out) A.want(s * 8);
+    int rc = A.commit();
+    if (rc) return rc;
+    const double *dK = A.in(K, in[0]), *dk = A.in(k, in[1]), *dS = A.in(Sigmai, in[2]);
+    double *o0 = A.outp(cx, out[0]), *o1 = A.outp(cu, out[1]), *o2 = A.outp(cxx, out[2]), *o3 = A.outp(cxu, out[3]), *o4 = A.outp(cuu, out[4]);
+    if ((rc = A.upload())) return rc;
+    if ((rc = ddp_kl_terms_f64_dev(h, n, m, N, B, dK, dk, dS, o0, o1, o2, o3, o4))) return rc;
+    return A.download();
+}
+
+int ddp_back_pass_gps_f64(ddp_handle h, const ddp_bp_desc *d,
+                          const double *cx, const double *cu, const double *cxx, const double *cxu, const double *cuu,
+                          const double *fx, const double *fu, const ddp_kl_cost_terms *kl,
+                          const double *lims, const double *u,
+                          double *K, double *k, double *Quu, double *Quui, double *Vx, double *Vxx, double *dV,
+                          int32_t *diverge)
+{
+    DDP_CHECK(h && d && kl, "back_pass_gps: null handle/descriptor/kl terms");
+    const size_t n = d->n, m = d->m, N = d->N, B = d->B, nb = N * B;
+    const size_t fxc = N * (d->fx_batched ? B : 1), cc = N * (d->cost_batched ? B : 1);
+    const size_t in[] = {n * nb, m * nb, n * n * cc, n * m * cc, m * m * cc, n * n * fxc, n * m * fxc, 2 * m, m * nb,
+                         n * nb, m * nb, n * n * nb, m * n * nb, m * m * nb, kl->eta_tv ? nb : B};
+    const size_t out[] = {m * n * nb, m * nb, m * m * nb, m * m * nb, n * nb, n * n * nb, 2 * B};
+    Arena A; A.h = h;
+    for (size_t s : in) A.want(s * 8);
+    for (size_t s : out) A.want(s * 8);
+    A.want(B * 4);
+    int rc = A.commit();
+    if (rc) return rc;
+    const double *dcx = A.in(cx, in[0]), *dcu = A.in(cu, in[1]), *dcxx = A.in(cxx, in[2]), *dcxu = A.in(cxu, in[3]), *dcuu = A.in(cuu, in[4]),
+                 *dfx = A.in(fx, in[5]), *dfu = A.in(fu, in[6]), *dl = d->has_lims ? A.in(lims, in[7]) : nullptr,
+                 *du = d->has_lims ? A.in(u, in[8]) : nullptr;
+    ddp_kl_cost_terms kd;
+    kd.cx = A.in(kl->cx, in[9]); kd.cu = A.in(kl->cu, in[10]); kd.cxx = A.in(kl->cxx, in[11]); kd.cxu = A.in(kl->cxu, in[12]);
+    kd.cuu = A.in(kl->cuu, in[13]); kd.eta = A.in(kl->eta, in[14]); kd.eta_tv = kl->eta_tv;
+    double *dK = A.outp(K, out[0]), *dk = A.outp(k, out[1]), *dQuu = A.outp(Quu, out[2]), *dQuui = A.outp(Quui, out[3]),
+           *dVx = A.outp(Vx, out[4]), *dVxx = A.outp(Vxx, out[5]), *ddV = A.outp(dV, out[6]);
+    int32_t *ddiv = A.outp(diverge, B);
+    if ((rc = A.upload())) return rc;
+    if ((rc = ddp_back_pass_gps_f64_dev(h, d, dcx, dcu, dcxx, dcxu, dcuu, dfx, dfu, &kd, dl, du, nullptr, dK, dk, dQuu, dQuui, dVx, dVxx, ddV, ddiv)))
+        return rc;
+    return A.download();
+}
+
+int ddp_forward_covariance_f64(ddp_handle h, int n, int m, int N, int B, const double *fx, int fx_batched,
+                               const double *R1, const double *K, const double *Sigma, double *sigmanew)
+{
+    DDP_CHECK(h, "forward_covariance: null handle");
+    const size_t nb = (size_t)N * B, p = (size_t)n + m;
+    const size_t in[] = {(size_t)n * n * N * (fx_batched ? B : 1), (size_t)n * n, (size_t)m * n * nb, (size_t)m * m * nb};
+    Arena A; A.h = h;
+    for (size_t s : in) A.want(s * 8);
+    A.want(p * p * nb * 8);
+    int rc = A.commit();
+    if (rc) return rc;
+    const double *dfx = A.in(fx, in[0]), *dR = A.in(R1, in[1]), *dK = A.in(K, in[2]), *dS = A.in(Sigma, in[3]);
+    double *o = A.outp(sigmanew, p * p * nb);
+    if ((rc = A.upload())) return rc;
+    if ((rc = ddp_forward_covariance_f64_dev(h, n, m, N, B, dfx, fx_batched, dR, dK, dS, o))) return rc;
+    return A.download();
+}
+
+int ddp_kl_div_f64(ddp_handle h, int n, int m, int N, int B, const double *xnew, const double *xold,
+                   const double *sigmanew, const double *Kn, const double *kn, const double *Sn,
+                   const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                   double *kldiv, double *klmean)
+{
+    DDP_CHECK(h, "kl_div: null handle");
+    const size_t nb = (size_t)N * B, p = (size_t)n + m;
+    const size_t in[] = {n * nb, n * nb, p * p * nb, (size_t)m * n * nb, m * nb, (size_t)m * m * nb, (size_t)m * n * nb, m * nb,
+                         (size_t)m * m * nb, (size_t)m * m * nb};
+    Arena A; A.h = h;
+    for (size_t s : in) A.want(s * 8);
+    A.want(nb * 8); A.want((size_t)B * 8);
+    int rc = A.commit();
+    if (rc) return rc;
+    const double *a0 = A.in(xnew, in[0]), *a1 = A.in(xold, in[1]), *a2 = A.in(sigmanew, in[2]), *a3 = A.in(Kn, in[3]), *a4 = A.in(kn, in[4]),
+                 *a5 = A.in(Sn, in[5]), *a6 = A.in(Kp, in[6]), *a7 = A.in(kp, in[7]), *a8 = A.in(Sp, in[8]), *a9 = A.in(Sip, in[9]);
+    double *o0 = A.outp(kldiv, nb), *o1 = A.outp(klmean, (size_t)B);
+    if (!o0) o0 = (double *)A.take(nb * 8);
+    if ((rc = A.upload())) return rc;
+    if ((rc = ddp_kl_div_f64_dev(h, n, m, N, B, a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, o0, o1))) return rc;
+    return A.download();
+}
+
+}   // extern "C"

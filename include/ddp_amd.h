@@ -200,6 +200,59 @@ int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
                      double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
                      double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
 
+/* ---- KL-constrained path (BASELINE config 5) ------------------------------------------------------
+ * reference: back_pass_gps src/backward_pass.jl:259-350 (called from src/iLQGkl.jl:100,191), ∇kl and kl_div_wiki
+ * src/klutils.jl:8-23,70-103, forward_covariance src/forward_pass.jl:37-56.  calc_η and the iLQGkl loop are scalar
+ * host logic (host mirror / Julia wrapper).  `df(model,·)` / `covariance(model,·)` belong to the un-vendored dependency
+ * LinearTimeVaryingModelsBase: the model is passed as the arrays it would return (fx, R1).                     */
+typedef struct {
+    const double *cx, *cu;       /* cxkl[n,N,B], cukl[m,N,B]                                                     */
+    const double *cxx, *cxu;     /* cxxkl[n,n,N,B], cxukl[m,n,N,B]  (m x n, the layout ∇kl returns, klutils.jl:20) */
+    const double *cuu;           /* cuukl[m,m,N,B]                                                               */
+    const double *eta;           /* eta_tv == 0: η[B] (ηbracket[2] per trajectory); 1: η[N,B] (ηbracket[2,i])     */
+    int eta_tv;
+} ddp_kl_cost_terms;
+
+/* ∇kl(traj_prev): K[m,n,N,B], k[m,N,B], Sigmai[m,m,N,B] -> the five arrays of ddp_kl_cost_terms (outputs)      */
+int ddp_kl_terms_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *K, const double *k, const double *Sigmai,
+                         double *cx, double *cu, double *cxx, double *cxu, double *cuu);
+int ddp_kl_terms_f64(ddp_handle h, int n, int m, int N, int B, const double *K, const double *k, const double *Sigmai,
+                     double *cx, double *cu, double *cxx, double *cxu, double *cuu);
+
+/* back_pass_gps: d->fx_tv and d->cost_tv must be 1 (3-D arrays, as the reference's method signature), regType unused.
+ * Outputs as ddp_back_pass plus Quui[m,m,N,B] = inv(Quu_i) (the Σ field of the returned GaussianPolicy); Quu is the
+ * KL-augmented, symmetrised matrix (the Σi field).  n <= 32, m <= 8.                                              */
+int ddp_back_pass_gps_f64_dev(ddp_handle h, const ddp_bp_desc *d,
+                              const double *cx, const double *cu, const double *cxx, const double *cxu, const double *cuu,
+                              const double *fx, const double *fu, const ddp_kl_cost_terms *kl,
+                              const double *lims, const double *u, const int32_t *active,
+                              double *K, double *k, double *Quu, double *Quui, double *Vx, double *Vxx, double *dV,
+                              int32_t *diverge);
+int ddp_back_pass_gps_f64(ddp_handle h, const ddp_bp_desc *d,
+                          const double *cx, const double *cu, const double *cxx, const double *cxu, const double *cuu,
+                          const double *fx, const double *fu, const ddp_kl_cost_terms *kl,
+                          const double *lims, const double *u,
+                          double *K, double *k, double *Quu, double *Quui, double *Vx, double *Vxx, double *dV,
+                          int32_t *diverge);
+
+/* forward_covariance: fx[n,n,N] (fx_batched: [n,n,N,B]) and R1[n,n] (shared) of the model, K[m,n,N,B], Sigma[m,m,N,B]
+ * -> sigmanew[(n+m),(n+m),N,B]; entries the reference leaves undef (u-blocks of the last step) are zero.           */
+int ddp_forward_covariance_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *fx, int fx_batched,
+                                   const double *R1, const double *K, const double *Sigma, double *sigmanew);
+int ddp_forward_covariance_f64(ddp_handle h, int n, int m, int N, int B, const double *fx, int fx_batched,
+                               const double *R1, const double *K, const double *Sigma, double *sigmanew);
+
+/* kl_div_wiki: per-step divergence kldiv[N,B] (clipped at 0) and its mean over time klmean[B]; a trajectory whose
+ * logdet would throw (non-positive determinant of Σ) gets klmean = +Inf like the reference's `return Inf`.          */
+int ddp_kl_div_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *xnew, const double *xold,
+                       const double *sigmanew, const double *Kn, const double *kn, const double *Sn,
+                       const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                       double *kldiv, double *klmean);
+int ddp_kl_div_f64(ddp_handle h, int n, int m, int N, int B, const double *xnew, const double *xold,
+                   const double *sigmanew, const double *Kn, const double *kn, const double *Sn,
+                   const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                   double *kldiv, double *klmean);
+
 #ifdef __cplusplus
 }
 #endif

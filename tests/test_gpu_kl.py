@@ -1,0 +1,157 @@
+"""GPU parity tests of the KL-constrained path (BASELINE config 5) through the C ABI: back_pass_gps, ∇kl, forward_covariance,
+kl_div_wiki and the single-constraint iLQGkl loop against the committed fixtures and the CPU oracle.  Tolerance 1e-8
+relative (BASELINE.json)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+GPS = ["kl_gps_n4m2", "kl_gps_n4m2_lims", "kl_gps_n4m2_eta_per_step", "kl_gps_n4m1_lims", "kl_gps_n10m2", "kl_gps_n4m2_diverge"]
+
+
+@pytest.fixture(scope="module")
+def ddp():
+    import ddp_amd
+    import ddp_amd.kl  # noqa: F401
+    ddp_amd.default_handle()
+    return ddp_amd
+
+
+def _lims(g):
+    return None if g["lims"].size == 0 else g["lims"]
+
+
+@pytest.mark.parametrize("name", GPS)
+def test_gps_chain_golden(ddp, name):
+    kl = ddp.kl
+    g = load_golden(name)
+    N = g["u"].shape[1]
+    prev = ddp.GaussianPolicy(N, g["x"].shape[0], g["u"].shape[0], g["Kp"], g["kp"], g["Sp"], g["Sip"])
+    terms = kl.grad_kl(prev)
+    for got, key in zip(terms, ("cxkl", "cukl", "cxxkl", "cxukl", "cuukl")):
+        assert relerr(got, g[key]) < RTOL, key
+    d, pol, Vx, Vxx, dV = kl.back_pass_gps(g["cx"], g["cu"], g["cxx"], g["cxu"], g["cuu"], g["fx"], g["fu"], _lims(g), g["x"], g["u"],
+                                           (terms, g["etab"]))
+    assert d == int(g["diverge"])
+    for got, key in ((pol.K, "K"), (pol.k, "k"), (pol.Σ, "Quui"), (pol.Σi, "Quu"), (Vx, "Vx"), (Vxx, "Vxx"), (dV, "dV")):
+        assert relerr(got, g[key]) < RTOL, (key, relerr(got, g[key]))
+    assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2)))
+    sig = kl.forward_covariance(kl.Model(g["fx"], g["fu"], g["R1"]), g["x"], g["u"], pol)
+    assert relerr(sig, g["sigmanew"]) < RTOL
+    kld = kl.kl_div_wiki(g["xnew"], g["x"], sig, pol, prev)
+    fin = np.isfinite(g["kldiv"])
+    assert np.array_equal(np.isfinite(kld), fin) and relerr(kld[fin], g["kldiv"][fin]) < RTOL
+
+
+def test_gps_batch_matches_oracle(ddp):
+    """a ragged batch with per-trajectory η, per-trajectory dynamics and cost, one trajectory diverging"""
+    from oracle import oracle_ctypes as oc
+    kl = ddp.kl
+    rng = np.random.default_rng(11)
+    n, m, N, B = 6, 3, 25, 5
+
+    def spd(d, s=1.0):
+        a = rng.standard_normal((d, d)); return s * (a @ a.T / d + 0.5 * np.eye(d))
+    fx = np.stack([np.stack([np.eye(n) + 0.1 * rng.standard_normal((n, n)) for _ in range(N)], -1) for _ in range(B)], -1)
+    fu = 0.3 * rng.standard_normal((n, m, N, B))
+    cxx = np.stack([np.stack([spd(n) for _ in range(N)], -1) for _ in range(B)], -1)
+    cuu = np.stack([np.stack([spd(m, 0.5) for _ in range(N)], -1) for _ in range(B)], -1)
+    cuu[:, :, 9, 3] = -30 * np.eye(m)
+    cxu = 0.05 * rng.standard_normal((n, m, N, B))
+    cx, cu, u, x = rng.standard_normal((n, N, B)), rng.standard_normal((m, N, B)), 0.3 * rng.standard_normal((m, N, B)), rng.standard_normal((n, N, B))
+    Kp, kp = 0.2 * rng.standard_normal((m, n, N, B)), 0.1 * rng.standard_normal((m, N, B))
+    Sip = np.stack([np.stack([spd(m, 2.0) for _ in range(N)], -1) for _ in range(B)], -1)
+    Sp = np.stack([np.stack([np.linalg.inv(Sip[:, :, t, b]) for t in range(N)], -1) for b in range(B)], -1)
+    etab = np.stack([1e-8 * np.ones(B), np.array([1.0, 0.5, 2.0, 1.0, 4.0]), 1e16 * np.ones(B)])
+    prev = ddp.GaussianPolicy(N, n, m, Kp, kp, Sp, Sip)
+    terms = kl.grad_kl(prev)
+    for lims in (None, np.stack([-0.3 * np.ones(m), 0.25 * np.ones(m)], 1)):
+        div, pol, Vx, Vxx, dV = kl.back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, (terms, etab))
+        for b in range(B):
+            tb = oc.kl_terms(Kp[..., b], kp[..., b], Sip[..., b])
+            d, (K, k, Quui, Quu), vx, vxx, dv = oc.back_pass_gps(cx[..., b], cu[..., b], cxx[..., b], cxu[..., b], cuu[..., b], fx[..., b],
+                                                                fu[..., b], lims, x[..., b], u[..., b], (tb, etab[:, b]))
+            assert div[b] == d and (d == 10) == (b == 3)
+            for got, ref, nm in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (pol.Σ[..., b], Quui, "Quui"), (pol.Σi[..., b], Quu, "Quu"),
+                                 (Vx[..., b], vx, "Vx"), (Vxx[..., b], vxx, "Vxx"), (dV[:, b], dv, "dV")):
+                assert relerr(got, ref) < RTOL, (nm, b, relerr(got, ref))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ilqgkl_golden(ddp, tag):
+    kl = ddp.kl
+    g = load_golden("kl_ilqgkl_lq_" + tag)
+    n, T = g["x"].shape
+    m = g["u"].shape[0]
+    eye = np.repeat(np.eye(m)[:, :, None], T, 2)
+    prev = ddp.GaussianPolicy(T, n, m, np.zeros((m, n, T)), g["u"], eye, eye.copy())
+    fx, fu = np.repeat(g["A"][:, :, None], T, 2), np.repeat(g["B"][:, :, None], T, 2)
+    prob = ddp.LQProblem(g["A"], g["B"], g["Q"], g["R"])
+    x, u, pol, Vx, Vxx, cost, tr = kl.iLQGkl(prob, g["x"], prev, kl.Model(fx, fu, g["R1"]), kl_step=float(g["kl_step"]), max_iter=50,
+                                             cost=float(g["cost0"]))
+    assert (int(tr["status"]), int(tr["iter"]), int(tr["n_backpass"])) == (int(g["status"]), int(g["iter"]), int(g["n_backpass"]))
+    assert relerr(tr["η"], g["eta"]) < RTOL and abs(float(tr["divergence"]) - float(g["divergence"])) < 1e-7 * float(g["kl_step"])
+    assert relerr(x, g["xnew"]) < RTOL and relerr(u, g["unew"]) < RTOL and relerr(pol.K, g["K"]) < RTOL
+    assert relerr(pol.Σ, g["S"]) < RTOL and relerr(Vxx, g["Vxx"]) < RTOL and relerr(cost, g["cost"]) < RTOL
+    assert np.array_equal(pol.k, u)                                       # traj_new.k = copy(u)  (iLQGkl.jl:239)
+    assert np.array_equal(prev.k, g["u"])                                 # traj_prev.k restored (iLQGkl.jl:247)
+
+
+def test_ilqgkl_batch_independent_eta(ddp):
+    """a batch of KL-constrained solves: every trajectory runs its own η bracket and matches its own oracle solve"""
+    from oracle import oracle_ctypes as oc
+    import scipy.linalg as sla
+    kl = ddp.kl
+    rng = np.random.default_rng(21)
+    n, m, T, B, h = 6, 2, 50, 4, 0.01
+    A0 = rng.standard_normal((n, n)); A = sla.expm(h * (A0 - A0.T)); Bm = h * rng.standard_normal((n, m))
+    Q, R = h * np.eye(n), 0.1 * h * np.eye(m)
+    u = 0.1 * rng.standard_normal((m, T, B)) * np.array([1.0, 2.0, 0.5, 3.0])
+    x = np.zeros((n, T, B)); x[:, 0, :] = 1.0 + 0.1 * rng.standard_normal((n, B))
+    for t in range(T - 1):
+        x[:, t + 1, :] = A @ x[:, t, :] + Bm @ u[:, t, :]
+    cost0 = 0.5 * np.einsum("itb,ij,jtb->b", x, Q, x) + 0.5 * np.einsum("itb,ij,jtb->b", u, R, u)
+    eye = np.repeat(np.repeat(np.eye(m)[:, :, None, None], T, 2), B, 3)
+    prev = ddp.GaussianPolicy(T, n, m, np.zeros((m, n, T, B)), u, eye, eye.copy())
+    fx, fu, R1 = np.repeat(A[:, :, None], T, 2), np.repeat(Bm[:, :, None], T, 2), 1e-4 * np.eye(n)
+    xo, uo, pol, Vx, Vxx, cost, tr = kl.iLQGkl(ddp.LQProblem(A, Bm, Q, R), x, prev, kl.Model(fx, fu, R1), kl_step=2e-4, max_iter=40, cost=cost0)
+    p = oc.make_problem("lq", n, m, T, A=A, B=Bm, Q=Q, R=R)
+    for b in range(B):
+        pb = dict(K=np.zeros((m, n, T)), k=u[..., b], S=eye[..., b], Si=eye[..., b])
+        xr, ur, polr, vx, vxx, cr, info = oc.ilqgkl(p, x[..., b], float(cost0[b]), pb, dict(fx=fx, R1=R1), kl_step=2e-4, max_iter=40)
+        assert (tr["status"][b], tr["iter"][b], tr["n_backpass"][b]) == (info["status"], info["iter"], info["n_backpass"])
+        assert relerr(tr["η"][:, b], info["eta"]) < RTOL
+        assert relerr(xo[..., b], xr) < RTOL and relerr(uo[..., b], ur) < RTOL and relerr(pol.K[..., b], polr["K"]) < RTOL
+        assert relerr(cost[:, b], cr) < RTOL
+    assert len(set(tr["η"][1])) > 1                                       # the brackets really are per trajectory
+
+
+def test_ilqgkl_pendcart_c5_shape(ddp):
+    """BASELINE config 5 = config 3 (pendcart, n=4, m=1, control limits) + the KL constraint; reduced N and B"""
+    from oracle import oracle_ctypes as oc
+    kl = ddp.kl
+    rng = np.random.default_rng(31)
+    N, B = 80, 3
+    prob = ddp.PendcartProblem()
+    lims = np.array([[-5.0, 5.0]])
+    u = (1.5 * np.sin(np.arange(N) / 9.0))[None, :, None] * np.array([1.0, 0.7, 1.3]) + 0.05 * rng.standard_normal((1, N, B))
+    x0 = np.array([np.pi - 0.6, 0, 0, 0])[:, None] + 0.05 * rng.standard_normal((4, B))
+    x, _, c0 = ddp.forward_pass(None, x0, u, None, 1.0, prob, lims)
+    cost0 = c0.sum(axis=0)
+    fx, fu = ddp.df(prob, x, u)[:2]
+    R1 = 1e-3 * np.eye(4)
+    eye = np.ones((1, 1, N, B))
+    prev = ddp.GaussianPolicy(N, 4, 1, np.zeros((1, 4, N, B)), u, eye, eye.copy())
+    xo, uo, pol, Vx, Vxx, cost, tr = kl.iLQGkl(prob, x, prev, kl.Model(fx, fu, R1), kl_step=0.05, lims=lims, max_iter=30, cost=cost0)
+    pend = dict(g=prob.g, l=prob.l, h=prob.h, d=prob.d, goal=prob.goal)
+    p = oc.make_problem("pendcart", 4, 1, N, Q=prob.Q, R=prob.R, pend=pend)
+    for b in range(B):
+        pb = dict(K=np.zeros((1, 4, N)), k=u[..., b], S=eye[..., b], Si=eye[..., b])
+        xr, ur, polr, vx, vxx, cr, info = oc.ilqgkl(p, x[..., b], float(cost0[b]), pb, dict(fx=fx[..., b], R1=R1), kl_step=0.05, lims=lims,
+                                                    max_iter=30)
+        assert (tr["status"][b], tr["iter"][b], tr["n_backpass"][b]) == (info["status"], info["iter"], info["n_backpass"]), b
+        assert relerr(tr["η"][:, b], info["eta"]) < 1e-7
+        assert relerr(xo[..., b], xr) < 1e-7 and relerr(uo[..., b], ur) < 1e-7 and relerr(pol.K[..., b], polr["K"]) < 1e-7
+        assert np.abs(uo[..., b]).max() <= 5.0
