@@ -179,4 +179,84 @@ function iLQG(problem, x0, u0; lims=[], α=exp10.(range(0, stop=-3, length=11)),
     return x, u, GaussianPolicy(N, n, m, K, k, zeros(m, m, N), Quu), Vx, Vxx, cost, trace
 end
 
+# ---- KL-constrained path (src/backward_pass.jl:259-350, src/klutils.jl, src/forward_pass.jl:37-56) -------------------
+struct KLCostTerms
+    cx::Ptr{Float64}; cu::Ptr{Float64}; cxx::Ptr{Float64}; cxu::Ptr{Float64}; cuu::Ptr{Float64}; eta::Ptr{Float64}; eta_tv::Cint
+end
+
+"""
+    ∇kl(traj_prev) -> cx, cu, cxx, cxu, cuu          (klutils.jl:8-23; cxu is m×n×T like the reference)
+"""
+function ∇kl(traj_prev::GaussianPolicy; handle=default_handle())
+    isempty(traj_prev) && return (0, 0, 0, 0, 0)
+    m, n, T = traj_prev.m, traj_prev.n, traj_prev.T
+    cx, cu, cxx, cxu, cuu = zeros(n, T), zeros(m, T), zeros(n, n, T), zeros(m, n, T), zeros(m, m, T)
+    K, k, Σi = traj_prev.K, traj_prev.k, traj_prev.Σi
+    GC.@preserve K k Σi cx cu cxx cxu cuu begin
+        check(@ccall libddp.ddp_kl_terms_f64(handle.ptr::Ptr{Cvoid}, n::Cint, m::Cint, T::Cint, 1::Cint, K::Ptr{Float64},
+            k::Ptr{Float64}, Σi::Ptr{Float64}, cx::Ptr{Float64}, cu::Ptr{Float64}, cxx::Ptr{Float64}, cxu::Ptr{Float64},
+            cuu::Ptr{Float64})::Cint)
+    end
+    return cx, cu, cxx, cxu, cuu
+end
+
+"""
+    back_pass_gps(cx,cu,cxx,cxu,cuu,fx,fu,lims,x,u,kl_cost_terms) -> diverge, GaussianPolicy(N,n,m,K,k,Quui,Quu), Vx, Vxx, dV
+
+Same signature and return values as backward_pass.jl:259; `kl_cost_terms = (∇kl(traj_prev), ηbracket)` with `ηbracket`
+a 3-vector or a 3×N matrix.
+"""
+function back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, kl_cost_terms; handle=default_handle())
+    n, N = size(cx); m = size(cu, 1)
+    cx, cu, cxx, cxu, cuu, fx, fu, u = map(_f64, (cx, cu, cxx, cxu, cuu, fx, fu, u))
+    cxkl, cukl, cxxkl, cxukl, cuukl = map(_f64, kl_cost_terms[1])
+    ηb = kl_cost_terms[2]
+    η = isa(ηb, AbstractMatrix) ? _f64(ηb[2, :]) : [Float64(ηb[2])]
+    has_lims = !isempty(lims)
+    limsp = has_lims ? _f64(lims) : Float64[]
+    d = BPDesc(n, m, N, 1, 1, 0, 1, 0, 1, has_lims)
+    K = zeros(m, n, N); k = zeros(m, N); Quu = zeros(m, m, N); Quui = zeros(m, m, N); Vx = zeros(n, N); Vxx = zeros(n, n, N)
+    dV = zeros(2); diverge = Ref{Int32}(0)
+    GC.@preserve cx cu cxx cxu cuu fx fu u cxkl cukl cxxkl cxukl cuukl η limsp K k Quu Quui Vx Vxx dV begin
+        t = KLCostTerms(pointer(cxkl), pointer(cukl), pointer(cxxkl), pointer(cxukl), pointer(cuukl), pointer(η), isa(ηb, AbstractMatrix))
+        check(@ccall libddp.ddp_back_pass_gps_f64(handle.ptr::Ptr{Cvoid}, Ref(d)::Ptr{BPDesc}, cx::Ptr{Float64}, cu::Ptr{Float64},
+            cxx::Ptr{Float64}, cxu::Ptr{Float64}, cuu::Ptr{Float64}, fx::Ptr{Float64}, fu::Ptr{Float64}, Ref(t)::Ptr{KLCostTerms},
+            (has_lims ? pointer(limsp) : Ptr{Float64}(C_NULL))::Ptr{Float64}, (has_lims ? pointer(u) : Ptr{Float64}(C_NULL))::Ptr{Float64},
+            K::Ptr{Float64}, k::Ptr{Float64}, Quu::Ptr{Float64}, Quui::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64},
+            dV::Ptr{Float64}, diverge::Ptr{Int32})::Cint)
+    end
+    return Int(diverge[]), GaussianPolicy(N, n, m, K, k, Quui, Quu), Vx, Vxx, dV
+end
+
+"""
+    forward_covariance(fx, R1, traj) -> sigmanew       (forward_pass.jl:37-56 with `df(model,·)[1]`, `covariance(model,·)` passed in)
+"""
+function forward_covariance(fx::Array{Float64,3}, R1::Matrix{Float64}, traj::GaussianPolicy; handle=default_handle())
+    n, m, N = traj.n, traj.m, traj.T
+    S = zeros(n + m, n + m, N); K, Σ = traj.K, traj.Σ
+    GC.@preserve fx R1 K Σ S begin
+        check(@ccall libddp.ddp_forward_covariance_f64(handle.ptr::Ptr{Cvoid}, n::Cint, m::Cint, N::Cint, 1::Cint, fx::Ptr{Float64},
+            0::Cint, R1::Ptr{Float64}, K::Ptr{Float64}, Σ::Ptr{Float64}, S::Ptr{Float64})::Cint)
+    end
+    return S
+end
+
+"""
+    kl_div_wiki(xnew, xold, Σ_new, traj_new, traj_prev) -> kldiv (or Inf)      (klutils.jl:70-103)
+"""
+function kl_div_wiki(xnew, xold, Σ_new, traj_new::GaussianPolicy, traj_prev::GaussianPolicy; handle=default_handle())
+    n, m, T = traj_new.n, traj_new.m, traj_new.T
+    kld = zeros(T); mean_ = zeros(1)
+    xnew, xold, Σ_new = map(_f64, (xnew, xold, Σ_new))
+    Kn, kn, Σn, Kp, kp, Σp, Σip = traj_new.K, traj_new.k, traj_new.Σ, traj_prev.K, traj_prev.k, traj_prev.Σ, traj_prev.Σi
+    GC.@preserve xnew xold Σ_new Kn kn Σn Kp kp Σp Σip kld mean_ begin
+        check(@ccall libddp.ddp_kl_div_f64(handle.ptr::Ptr{Cvoid}, n::Cint, m::Cint, T::Cint, 1::Cint, xnew::Ptr{Float64},
+            xold::Ptr{Float64}, Σ_new::Ptr{Float64}, Kn::Ptr{Float64}, kn::Ptr{Float64}, Σn::Ptr{Float64}, Kp::Ptr{Float64},
+            kp::Ptr{Float64}, Σp::Ptr{Float64}, Σip::Ptr{Float64}, kld::Ptr{Float64}, mean_::Ptr{Float64})::Cint)
+    end
+    return isinf(mean_[1]) && all(isfinite, kld) ? Inf : kld
+end
+# calc_η, geom and the iLQGkl loop stay the reference's scalar Julia code (klutils.jl:112-155, iLQGkl.jl): with the four
+# functions above rebound, src/iLQGkl.jl:90,100,133 and klutils.jl:114 run on the GPU unchanged.
+
 end # module
