@@ -258,12 +258,15 @@ STATUS = {1: "SUCCESS: gradient norm < tol_grad", 2: "SUCCESS: cost change < tol
 
 
 def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0,
-         λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0, verbosity=0, trace_cap=None, handle=None):
+         λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0, verbosity=0, trace_cap=None, cost=None,
+         handle=None):
     """Drop-in for ``iLQG(f,costfun,df,x0,u0; lims, α, tol_fun, ...)`` (iLQG.jl:143-163) with a registered
     ``problem`` standing in for the three closures.  ``u0[m,N,B]`` / ``x0[n,B]`` solve a batch of
     independent problems, each with its own λ schedule, line search and termination.
     Returns ``(x, u, traj_new, Vx, Vxx, cost, trace)``; ``trace`` is a dict with the reference's trace
     keys that survive batching (``:cost`` per iteration) plus the per-trajectory summary ``stats``.
+    ``x0[n,N]`` (``x0[n,N,B]`` with a batch) is a PRE-ROLLED initial trajectory (iLQG.jl:193-197: no initial rollout;
+    ``cost`` as given or ``costfun(x0,u0)``) — the warm start of an MPC loop.
     Returns ``None`` when the initial control sequence diverges (iLQG.jl:205-210) in the unbatched case."""
     h = handle or default_handle()
     u0, x0 = _lib.f64(u0), _lib.f64(x0)
@@ -271,8 +274,14 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     m, N = u0.shape[:2]
     n = x0.shape[0]
     B = u0.shape[2] if batched else 1
-    if x0.ndim > 1 and x0.shape[1] == N and not batched:
-        raise NotImplementedError("pre-rolled initial trajectories (size(x0,2) == N) are not offloaded")
+    prerolled = False
+    if x0.ndim == (3 if batched else 2):                      # x0 has a time axis: single column or pre-rolled (iLQG.jl:181,193)
+        if x0.shape[1] == N:
+            prerolled = True
+        elif x0.shape[1] == 1:
+            x0 = _lib.f64(x0[:, 0])
+        else:
+            raise ValueError("pre-rolled initial trajectory must be of correct length (size(x0,2) == N)")     # iLQG.jl:199
     dp = _DevProblem(problem, N, B)
     o = _lib.ILQGOpts()
     _lib.lib().ddp_ilqg_default_opts(_C.byref(o))
@@ -288,15 +297,23 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     CL = dp.cost_len
     x = np.zeros((n, N, B), order="F"); u = np.zeros((m, N, B), order="F")
     K = np.zeros((m, n, N, B), order="F"); k = np.zeros((m, N, B), order="F"); Quu = np.zeros((m, m, N, B), order="F")
-    Vx = np.zeros((n, N, B), order="F"); Vxx = np.zeros((n, n, N, B), order="F"); cost = np.zeros((CL, B), order="F")
+    Vx = np.zeros((n, N, B), order="F"); Vxx = np.zeros((n, n, N, B), order="F")
     stats = np.zeros((8, B), order="F")
     cap = trace_cap if trace_cap is not None else 4 * max_iter + 64
     cap = min(cap, 4096)
     tr = np.zeros((cap, B), order="F")
     git = _C.c_int(0)
-    _lib.check(_lib.lib().ddp_ilqg_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), _lib.ptr(u0), _lib.ptr(L),
-                                       *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr),
-                                       _C.byref(git)))
+    if prerolled:
+        c0 = None if cost is None or np.size(cost) == 0 else _lib.f64(np.reshape(cost, (CL, B), order="F"))
+        cost = np.zeros((CL, B), order="F")
+        _lib.check(_lib.lib().ddp_ilqg_warm_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), _lib.ptr(u0), _lib.ptr(c0),
+                                                _lib.ptr(L), *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr),
+                                                _C.byref(git)))
+    else:
+        cost = np.zeros((CL, B), order="F")
+        _lib.check(_lib.lib().ddp_ilqg_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), _lib.ptr(u0), _lib.ptr(L),
+                                           *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr),
+                                           _C.byref(git)))
     trace = dict(stats=stats, status=stats[0].astype(int), iter=stats[1].astype(int), λ=stats[5], grad_norm=stats[6],
                  cost=tr, global_iters=git.value)
     if verbosity > 0:

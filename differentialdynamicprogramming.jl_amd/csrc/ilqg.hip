@@ -63,6 +63,58 @@ __global__ __launch_bounds__(64) void init_check_kernel(int n, int m, int N, int
     if (lane == 0) { s.div0[b] = 0; s.csum[b] = csum[b]; }
 }
 
+// costfun of the registered families on a given trajectory: one wave per trajectory, lanes over time
+//   LQ        c_i = .5 x_i'Q x_i + .5 u_i'R u_i                       (src/demo_linear.jl:49, split per step)
+//   pendcart  c_i = .5 ((x_i-goal)'Q(x_i-goal) + R u_i^2),  c_{N+1} = .5 (x_N-goal)'Q(x_N-goal)   (src/system_pendcart.jl:97-106)
+__global__ __launch_bounds__(64) void costfun_kernel(int kind, int n, int m, int N, int CL, const double *Q, const double *R,
+                                                     double g0, double g1, double g2, double g3, const double *x, const double *u,
+                                                     const int32_t *active, double *cost, double *csum)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (active && active[b] == 0) return;
+    const double *xb = x + (size_t)n * N * b, *ub = u + (size_t)m * N * b;
+    const double goal[4] = {g0, g1, g2, g3};
+    const bool pend = kind == DDP_PROBLEM_PENDCART;
+    double acc = 0.0;
+    for (int t = lane; t < CL; t += 64) {
+        const int tx = t < N ? t : N - 1;
+        double qx = 0.0, ru = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += Q[i + n * j] * (xb[(size_t)n * tx + j] - (pend ? goal[j & 3] : 0.0));
+            qx += (xb[(size_t)n * tx + i] - (pend ? goal[i & 3] : 0.0)) * s;
+        }
+        if (t < N)
+            for (int i = 0; i < m; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < m; ++j) s += R[i + m * j] * ub[(size_t)m * t + j];
+                ru += ub[(size_t)m * t + i] * s;
+            }
+        const double c = pend ? 0.5 * (qx + ru) : 0.5 * qx + 0.5 * ru;
+        cost[(size_t)CL * b + t] = c;
+        acc += c;
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0 && csum) csum[b] = acc;
+}
+
+// pre-rolled initial trajectory (iLQG.jl:193-197): x = x0[n,N], u = u0, cost given or costfun(x,u); x0c <- x0[:,1]
+__global__ __launch_bounds__(64) void preroll_init_kernel(int n, int m, int N, int CL, const double *x0, const double *u0,
+                                                          const double *cost0, Traj s, double *x, double *u, double *cost, double *x0c)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (size_t e = lane; e < (size_t)n * N; e += 64) x[(size_t)n * N * b + e] = x0[(size_t)n * N * b + e];
+    for (size_t e = lane; e < (size_t)m * N; e += 64) u[(size_t)m * N * b + e] = u0[(size_t)m * N * b + e];
+    for (int e = lane; e < n; e += 64) x0c[(size_t)n * b + e] = x0[(size_t)n * N * b + e];
+    if (cost0) {
+        double acc = 0.0;
+        for (int e = lane; e < CL; e += 64) { const double c = cost0[(size_t)CL * b + e]; cost[(size_t)CL * b + e] = c; acc += c; }
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) s.csum[b] = acc;
+    }
+    if (lane == 0) s.div0[b] = 0;
+}
+
 __global__ void count_ok_kernel(int B, Traj s, int *counter)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,9 +257,10 @@ void ddp_ilqg_default_opts(ddp_ilqg_opts *o)
     for (int i = 0; i < 16; ++i) o->alpha[i] = i < 11 ? pow(10.0, -3.0 * i / 10.0) : 0.0;
 }
 
-int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, const double *x0, const double *u0,
+static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, const double *x0, const double *u0,
                      const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx,
-                     double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+                     double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters,
+                     bool prerolled, const double *cost0)
 {
     DDP_CHECK(h && p && x0 && u0 && x && u && K && k && Quu && Vx && Vxx && cost && stats, "ilqg: null argument");
     ddp_ilqg_opts od;
@@ -222,8 +275,8 @@ int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     const size_t s_cx = al(n * N * B * 8), s_cu = al(m * N * B * 8), s_fx = pend ? al(n * n * N * B * 8) : 0,
                  s_fu = pend ? al(n * m * N * B * 8) : 0, s_xn = al(n * N * B * na * 8), s_un = al(m * N * B * na * 8),
                  s_cn = al(CL * B * na * 8), s_cs = al(B * na * 8), s_dV = al(2 * B * 8), s_div = al(B * 4),
-                 s_cxu = al(n * m * 8), s_us = al(m * N * B * 8), s_d = al(B * 8), s_i = al(B * 4);
-    bytes = s_cx + s_cu + s_fx + s_fu + s_xn + s_un + s_cn + s_cs + s_dV + s_div + s_cxu + s_us + 4 * s_d + 10 * s_i + 256;
+                 s_cxu = al(n * m * 8), s_us = al(m * N * B * 8), s_d = al(B * 8), s_i = al(B * 4), s_x0 = al(n * B * 8);
+    bytes = s_cx + s_cu + s_fx + s_fu + s_xn + s_un + s_cn + s_cs + s_dV + s_div + s_cxu + s_us + 4 * s_d + 10 * s_i + 256 + s_x0;
     void *base;
     int rc = ddp_scratch(h, bytes, &base);
     if (rc) return rc;
@@ -240,6 +293,7 @@ int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     s.nfp = (int32_t *)take(s_i); s.flg = (int32_t *)take(s_i); s.run = (int32_t *)take(s_i); s.dodf = (int32_t *)take(s_i);
     s.dofwd = (int32_t *)take(s_i); s.div0 = (int32_t *)take(s_i);
     int *counter = (int *)take(256);
+    double *x0c = (double *)take(s_x0);                  // first column of a pre-rolled x0
     DDP_CHECK(h->h_pinned, "ilqg: pinned poll buffer missing");
 
     Opt o;
@@ -263,7 +317,15 @@ int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
 
     // ---- initial trajectory (iLQG.jl:181-192): first α for which the open-loop rollout of α·u0 stays bounded
     const double one = 1.0;
-    for (size_t ai = 0; ai < na; ++ai) {
+    if (prerolled) {                                     // iLQG.jl:193-197: x = x0, cost given or costfun(x, u); no divergence test
+        hipLaunchKernelGGL(preroll_init_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, x0, u0, cost0, s,
+                           x, u, cost, x0c);
+        if (!cost0)
+            hipLaunchKernelGGL(costfun_kernel, dim3((unsigned)B), dim3(64), 0, st, p->kind, (int)n, (int)m, (int)N, (int)CL, p->Q, p->R,
+                               p->goal[0], p->goal[1], p->goal[2], p->goal[3], x, u, (const int32_t *)nullptr, cost, s.csum);
+        x0 = x0c;
+    }
+    for (size_t ai = 0; !prerolled && ai < na; ++ai) {
         const size_t tot = m * N * B;
         hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m * N, (int)B, oo->alpha[ai], u0,
                            s.div0, us);
@@ -317,9 +379,34 @@ int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     return 0;
 }
 
-int ddp_ilqg_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, const double *x0, const double *u0,
-                 const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
-                 double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, const double *x0, const double *u0,
+                     const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx,
+                     double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+{
+    return ilqg_impl(h, p, oo, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, trace_cost, global_iters, false, nullptr);
+}
+
+int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, const double *x0, const double *u0,
+                          const double *cost0, const double *lims, double *x, double *u, double *K, double *k, double *Quu,
+                          double *Vx, double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+{
+    return ilqg_impl(h, p, oo, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, trace_cost, global_iters, true, cost0);
+}
+
+int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
+                        double *cost, double *csum)
+{
+    DDP_CHECK(h && p && x && u && cost, "costfun: null argument");
+    hipLaunchKernelGGL(costfun_kernel, dim3((unsigned)p->B), dim3(64), 0, h->stream, p->kind, p->n, p->m, p->N, ddp_cost_len(p), p->Q, p->R,
+                       p->goal[0], p->goal[1], p->goal[2], p->goal[3], x, u, active, cost, csum);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+static int ilqg_host(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, const double *x0, const double *u0,
+                     const double *cost0, bool prerolled,
+                     const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                     double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
 {
     DDP_CHECK(h && p && x0 && u0, "ilqg: null argument");
     const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p);
@@ -339,8 +426,9 @@ int ddp_ilqg_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, con
     if (p->kind == DDP_PROBLEM_LQ) { pd.A = (double *)dev(p->A, nullptr, n * n * dc * 8); pd.Bm = (double *)dev(p->Bm, nullptr, n * m * dc * 8); }
     pd.Q = (double *)dev(p->Q, nullptr, n * n * 8);
     pd.R = (double *)dev(p->R, nullptr, m * m * 8);
-    double *dx0 = (double *)dev(x0, nullptr, n * B * 8), *du0 = (double *)dev(u0, nullptr, m * N * B * 8),
-           *dl = lims ? (double *)dev(lims, nullptr, 2 * m * 8) : nullptr;
+    double *dx0 = (double *)dev(x0, nullptr, n * (prerolled ? N : 1) * B * 8), *du0 = (double *)dev(u0, nullptr, m * N * B * 8),
+           *dl = lims ? (double *)dev(lims, nullptr, 2 * m * 8) : nullptr,
+           *dc0 = (prerolled && cost0) ? (double *)dev(cost0, nullptr, CL * B * 8) : nullptr;
     double *dx = (double *)dev(nullptr, x, n * N * B * 8), *du = (double *)dev(nullptr, u, m * N * B * 8),
            *dK = (double *)dev(nullptr, K, m * n * N * B * 8), *dk = (double *)dev(nullptr, k, m * N * B * 8),
            *dQuu = (double *)dev(nullptr, Quu, m * m * N * B * 8), *dVx = (double *)dev(nullptr, Vx, n * N * B * 8),
@@ -349,13 +437,27 @@ int ddp_ilqg_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, con
            *dtr = (trace_cost && trace_cap > 0) ? (double *)dev(nullptr, trace_cost, (size_t)trace_cap * B * 8) : nullptr;
     int rc = failed ? -2 : 0;
     if (failed) ddp_set_error("ilqg: device allocation / upload failed");
-    if (!rc) rc = ddp_ilqg_f64_dev(h, &pd, o, dx0, du0, dl, dx, du, dK, dk, dQuu, dVx, dVxx, dcost, dstats, trace_cap, dtr, global_iters);
+    if (!rc) rc = ilqg_impl(h, &pd, o, dx0, du0, dl, dx, du, dK, dk, dQuu, dVx, dVxx, dcost, dstats, trace_cap, dtr, global_iters, prerolled, dc0);
     if (!rc)
         for (auto &bf : bufs)
             if (bf.hdst && hipMemcpyAsync(bf.hdst, bf.d, bf.bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = -2;
     hipStreamSynchronize(h->stream);
     for (auto &bf : bufs) hipFree(bf.d);
     return rc;
+}
+
+int ddp_ilqg_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, const double *x0, const double *u0,
+                 const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                 double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+{
+    return ilqg_host(h, p, o, x0, u0, nullptr, false, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, trace_cost, global_iters);
+}
+
+int ddp_ilqg_warm_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, const double *x0, const double *u0,
+                      const double *cost0, const double *lims, double *x, double *u, double *K, double *k, double *Quu,
+                      double *Vx, double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+{
+    return ilqg_host(h, p, o, x0, u0, cost0, true, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, trace_cost, global_iters);
 }
 
 }   // extern "C"

@@ -200,6 +200,21 @@ int ddp_ilqg_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
                      double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
                      double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
 
+/* Warm start from a PRE-ROLLED trajectory (src/iLQG.jl:193-197: `size(x0,2) == N` ⇒ `x = x0`, no initial rollout, no
+ * divergence test; `cost` as given or `costfun(x,u)`) — the entry an MPC loop calls with its shifted previous solution.
+ * x0[n,N,B]; cost0[CL,B] or NULL.  Line-search rollouts start from x0[:,1] like the reference (iLQG.jl:268).          */
+int ddp_ilqg_warm_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
+                      const double *x0, const double *u0, const double *cost0, const double *lims,
+                      double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                      double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
+                          const double *x0, const double *u0, const double *cost0, const double *lims,
+                          double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                          double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+/* the `costfun` closure of the registered families on given trajectories: cost[CL,B], csum[B] (may be NULL)          */
+int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
+                        double *cost, double *csum);
+
 /* ---- KL-constrained path (BASELINE config 5) ------------------------------------------------------
  * reference: back_pass_gps src/backward_pass.jl:259-350 (called from src/iLQGkl.jl:100,191), ∇kl and kl_div_wiki
  * src/klutils.jl:8-23,70-103, forward_covariance src/forward_pass.jl:37-56.  calc_η and the iLQGkl loop are scalar

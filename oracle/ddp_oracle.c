@@ -584,13 +584,13 @@ void ddp_oracle_ilqg_default_opts(ddp_oracle_ilqg_opts *o)
 
 static double sum_(const double *v, int len) { double s = 0.0; for (int i = 0; i < len; ++i) s += v[i]; return s; }
 
-int ddp_oracle_ilqg(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
-                    const double *x0, const double *u0, const double *lims,
-                    double *x, double *u, double *K, double *k, double *Quu,
-                    double *Vx, double *Vxx, double *cost,
-                    ddp_oracle_ilqg_result *res,
-                    int trace_cap, double *tr_cost, double *tr_lambda, double *tr_alpha,
-                    double *tr_gnorm)
+static int ilqg_impl(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
+                     const double *x0, const double *u0, const double *lims,
+                     double *x, double *u, double *K, double *k, double *Quu,
+                     double *Vx, double *Vxx, double *cost,
+                     ddp_oracle_ilqg_result *res,
+                     int trace_cap, double *tr_cost, double *tr_lambda, double *tr_alpha,
+                     double *tr_gnorm, int prerolled, const double *cost0)
 {
     const int n = p->n, m = p->m, N = p->N, CL = ddp_oracle_cost_len(p);
     const size_t nN = (size_t)n * N, mN = (size_t)m * N;
@@ -608,7 +608,14 @@ int ddp_oracle_ilqg(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
 
     /* --- initial trajectory, iLQG.jl:181-192 (x0 is a single column) */
     int diverge0 = 1;
-    for (int ai = 0; ai < o->n_alpha; ++ai) {
+    if (prerolled) {                                                /* x0 is [n,N]: iLQG.jl:193-197 */
+        memcpy(x, x0, sizeof(double) * nN);
+        memcpy(u, u0, sizeof(double) * mN);
+        if (cost0) memcpy(cost, cost0, sizeof(double) * (size_t)CL);
+        else ddp_oracle_costfun(p, x, u, cost);                     /* isempty(cost) && (cost = costfun(x, u)) */
+        diverge0 = 0;
+    }
+    for (int ai = 0; !prerolled && ai < o->n_alpha; ++ai) {
         for (size_t t = 0; t < mN; ++t) us[t] = o->alpha[ai] * u0[t];
         ddp_oracle_forward_pass(p, NULL, NULL, x0, us, NULL, 1.0, lims, x, unew, cost);
         int ok = 1;
@@ -708,6 +715,26 @@ finish:
     if (fxb) free(fxb);
     if (fub) free(fub);
     return status;
+}
+
+int ddp_oracle_ilqg(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
+                    const double *x0, const double *u0, const double *lims,
+                    double *x, double *u, double *K, double *k, double *Quu,
+                    double *Vx, double *Vxx, double *cost,
+                    ddp_oracle_ilqg_result *res,
+                    int trace_cap, double *tr_cost, double *tr_lambda, double *tr_alpha,
+                    double *tr_gnorm)
+{
+    return ilqg_impl(p, o, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, res, trace_cap, tr_cost, tr_lambda, tr_alpha, tr_gnorm, 0, NULL);
+}
+
+/* pre-rolled initial trajectory x0[n,N] (iLQG.jl:193-197): no initial rollout; cost0[cost_len] or NULL (= costfun(x0,u0)) */
+int ddp_oracle_ilqg_prerolled(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
+                              const double *x0, const double *u0, const double *cost0, const double *lims,
+                              double *x, double *u, double *K, double *k, double *Quu,
+                              double *Vx, double *Vxx, double *cost, ddp_oracle_ilqg_result *res)
+{
+    return ilqg_impl(p, o, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, res, 0, NULL, NULL, NULL, NULL, 1, cost0);
 }
 
 int ddp_oracle_pass_batch_lq(const ddp_oracle_problem *p, int B,

@@ -151,6 +151,12 @@ int ddp_oracle_ilqg(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
                     int trace_cap, double *tr_cost, double *tr_lambda, double *tr_alpha,
                     double *tr_gnorm);
 
+/* pre-rolled initial trajectory x0[n,N] (iLQG.jl:193-197): no initial rollout; cost0[cost_len] or NULL (= costfun(x0,u0)) */
+int ddp_oracle_ilqg_prerolled(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
+                              const double *x0, const double *u0, const double *cost0, const double *lims,
+                              double *x, double *u, double *K, double *k, double *Quu,
+                              double *Vx, double *Vxx, double *cost, ddp_oracle_ilqg_result *res);
+
 /* Batch helpers used by bench.py's cpu_baseline leg: loop ddp_oracle_back_pass +
  * ddp_oracle_forward_pass over B trajectories (batch slowest), single thread. Returns
  * number of diverged trajectories. */

@@ -146,3 +146,43 @@ def test_ilqg_lambda_exit_and_per_trajectory_status(ddp):
     ref = oc.ilqg(p, P["x0"], P["u0"], lam_max=1e2)
     st = out[6]["stats"][:, 0]
     assert int(st[0]) == ref[6]["status"] == 3 and int(st[3]) == ref[6]["n_backpass"] and st[5] == ref[6]["lam"]
+
+
+# ------------------------------------------------------------------ pre-rolled warm start (iLQG.jl:193-197)
+@pytest.mark.parametrize("kind", ["lq", "pendcart"])
+@pytest.mark.parametrize("give_cost", [False, True])
+def test_ilqg_prerolled_warm_start(ddp, kind, give_cost):
+    """x0[n,N,B] pre-rolled: no initial rollout, cost given or costfun(x0,u0); an MPC-style shifted (dynamically
+    inconsistent) trajectory is taken as it is, like the reference does"""
+    from oracle import oracle_ctypes as oc, np_restatement as npr
+    rng = np.random.default_rng(41)
+    B = 3
+    if kind == "lq":
+        n, m, N = 10, 2, 60
+        P = npr.make_lq_problem(rng, T=N)
+        prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+        p = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=P["Q"], R=P["R"])
+        x0c = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B)); u0 = 0.1 * rng.standard_normal((m, N, B)); lims = None
+        kw = dict(max_iter=30)
+    else:
+        n, m, N = 4, 1, 70
+        prob = ddp.PendcartProblem()
+        p = oc.make_problem("pendcart", 4, 1, N, Q=prob.Q, R=prob.R, pend=dict(g=prob.g, l=prob.l, h=prob.h, d=prob.d, goal=prob.goal))
+        x0c = np.array([np.pi - 0.6, 0, 0, 0])[:, None] + 0.05 * rng.standard_normal((4, B)); u0 = 0.5 * rng.standard_normal((1, N, B))
+        lims = np.array([[-5.0, 5.0]])
+        kw = dict(max_iter=15, regType=2)
+    xr, ur, c0 = ddp.forward_pass(None, x0c, u0, None, 1.0, prob, lims)
+    # receding-horizon shift: drop the first step, repeat the last (the result is not a rollout of u any more)
+    x0 = np.concatenate([xr[:, 1:], xr[:, -1:]], axis=1); u0s = np.concatenate([ur[:, 1:], ur[:, -1:]], axis=1)
+    cost0 = None
+    if give_cost:
+        cost0 = np.stack([oc.forward_pass(p, None, x0[:, 0, b], u0s[..., b], None, 1.0, lims)[2] for b in range(B)], -1) * 1.0 + 0.01
+    opts = dict(kw)
+    res = ddp.iLQG(prob, x0, u0s, lims=lims, cost=cost0, λ=kw.get("lam", 1.0), max_iter=kw["max_iter"], regType=kw.get("regType", 1))
+    x, u, pol, Vx, Vxx, cost, tr = res
+    for b in range(B):
+        xo, uo, (K, k, Quu), vx, vxx, co, info = oc.ilqg_prerolled(p, x0[..., b], u0s[..., b], None if cost0 is None else cost0[:, b], lims, **opts)
+        st = tr["stats"][:, b]
+        assert (int(st[0]), int(st[1])) == (info["status"], info["iter"]), (b, st[:2], info)
+        assert relerr(x[..., b], xo) < 1e-7 and relerr(u[..., b], uo) < 1e-7 and relerr(Vxx[..., b], vxx) < 1e-7
+        assert abs(cost[:, b].sum() - co.sum()) < 1e-8 * abs(co.sum())
