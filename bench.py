@@ -105,9 +105,8 @@ class PassBench:
             _lib.check(L.ddp_event_record(h.raw, ev[2]))
         if dist is not None:
             # the single collective of the path: batch-level line-search statistics (latency-bound, 32 B)
-            s = self.stats
-            s[0] = self.dcsn.sum(); s[1] = self.ddV[0::2].sum(); s[2] = self.ddV[1::2].sum(); s[3] = self.ddiv.sum()
-            dist.all_reduce(s)
+            _lib.check(L.ddp_batch_stats_f64_dev(h.raw, self.B, p(self.dcsn), p(self.ddV), p(self.ddiv), p(self.stats)))
+            dist.all_reduce(self.stats)
 
     def timed(self, steps, warmup, fence, dist=None):
         _lib, L, h = self._lib, self.L, self.h
@@ -179,8 +178,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run the collective path runs even with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import ddp_amd
@@ -191,14 +192,14 @@ def main():
     h = ddp_amd.Handle(local, stream=stream)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     n, m, N, B = N_STATE, N_CTRL, args.horizon, args.batch
     pb = PassBench(torch, dev, h, L, rank, n, m, N, B)
-    elapsed, bp_ms, fp_ms = pb.timed(args.steps, args.warmup, fence, dist if world > 1 else None)
-    if world > 1:
+    elapsed, bp_ms, fp_ms = pb.timed(args.steps, args.warmup, fence, dist if use_dist else None)
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -240,7 +241,7 @@ def main():
                           "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1"},
                "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -393,6 +393,34 @@ int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opt
     return ilqg_impl(h, p, oo, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, trace_cost, global_iters, true, cost0);
 }
 
+// batch-level line-search statistics in ONE launch: out[4] = [Σ_b csum, Σ_b dV[1,b], Σ_b dV[2,b], #diverged] — the vector a
+// multi-GPU job all-reduces once per pass (bench.py, sharding.py)
+__global__ __launch_bounds__(256) void batch_stats_kernel(int B, const double *csum, const double *dV, const int32_t *diverge, double *out)
+{
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        a0 += csum ? csum[b] : 0.0;
+        if (dV) { a1 += dV[2 * b]; a2 += dV[2 * b + 1]; }
+        a3 += (diverge && diverge[b] != 0) ? 1.0 : 0.0;
+    }
+    __shared__ double red[4][4];
+    for (int off = 32; off >= 1; off >>= 1) {
+        a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = a0; red[w][1] = a1; red[w][2] = a2; red[w][3] = a3; }
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const double *dV, const int32_t *diverge, double *out4)
+{
+    DDP_CHECK(h && out4 && B >= 1, "batch_stats: bad argument");
+    hipLaunchKernelGGL(batch_stats_kernel, dim3(1), dim3(256), 0, h->stream, B, csum, dV, diverge, out4);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
 int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
                         double *cost, double *csum)
 {

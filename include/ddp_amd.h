@@ -211,6 +211,9 @@ int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opt
                           const double *x0, const double *u0, const double *cost0, const double *lims,
                           double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
                           double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+/* batch-level statistics of one pass in one launch: out4 = [sum(csum[B]), sum(dV[1,:]), sum(dV[2,:]), #(diverge != 0)];
+ * any input may be NULL.  This is the vector a multi-GPU job all-reduces (one small collective per pass).               */
+int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const double *dV, const int32_t *diverge, double *out4);
 /* the `costfun` closure of the registered families on given trajectories: cost[CL,B], csum[B] (may be NULL)          */
 int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
                         double *cost, double *csum);
