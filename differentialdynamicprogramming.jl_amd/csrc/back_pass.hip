@@ -633,7 +633,7 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     // Kernel choice.  Several implementations of the same arithmetic exist:
     //   x (mx)  one 16x16 fp64 MFMA tile per trajectory, one wave each (back_pass_mx.hip; n=10, m=2, no limits): shortest
     //           dependent chain per time step, best while the batch gives a SIMD only one or two waves (B=1024: 0.55 ms
-    //           against 0.90 ms for `fast`); measured cross-over with `dpp` between B=4096 and B=8192;
+    //           against 0.90 ms for `fast`); measured cross-over with `dpp` between B=4096 and B=6144;
     //   dpp     16 lanes per trajectory (back_pass_dpp.hip): fewest instructions per trajectory-step, best once the
     //           batch gives every SIMD a few wavefronts; also the kernel for control limits;
     //   fast    64 lanes per trajectory, LDS-lean vector kernel (back_pass_fast.hip; n=10, m=2, no limits);
@@ -641,7 +641,7 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     // DDP_BACKPASS=x|general|fast|dpp|big forces one (A/B timing, tests of every code path).
     const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
-    if (force == 'x' || (force == 0 && d->B < 6144)) {
+    if (force == 'x' || (force == 0 && d->B < 5120)) {
         const int rc = ddp_launch_back_pass_mx(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;
     }

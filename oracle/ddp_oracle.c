@@ -758,3 +758,17 @@ int ddp_oracle_pass_batch_lq(const ddp_oracle_problem *p, int B,
     }
     return ndiv;
 }
+
+/* the same, nrep times over (one long call per host thread for the all-cores figure of bench.py) */
+int ddp_oracle_pass_batch_lq_rep(const ddp_oracle_problem *p, int B, int nrep,
+                                 const double *cx, const double *cu, const double *cxx,
+                                 const double *cxu, const double *cuu, double lambda, int regType,
+                                 const double *x0, const double *u, const double *x, double alpha,
+                                 double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                                 double *dV, double *xnew, double *unew, double *cnew)
+{
+    int nd = 0;
+    for (int r = 0; r < nrep; ++r)
+        nd += ddp_oracle_pass_batch_lq(p, B, cx, cu, cxx, cxu, cuu, lambda, regType, x0, u, x, alpha, K, k, Quu, Vx, Vxx, dV, xnew, unew, cnew);
+    return nd;
+}

@@ -167,6 +167,13 @@ int ddp_oracle_pass_batch_lq(const ddp_oracle_problem *p, int B,
                              double *K, double *k, double *Quu, double *Vx, double *Vxx,
                              double *dV, double *xnew, double *unew, double *cnew);
 
+int ddp_oracle_pass_batch_lq_rep(const ddp_oracle_problem *p, int B, int nrep,
+                                 const double *cx, const double *cu, const double *cxx,
+                                 const double *cxu, const double *cuu, double lambda, int regType,
+                                 const double *x0, const double *u, const double *x, double alpha,
+                                 double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                                 double *dV, double *xnew, double *unew, double *cnew);
+
 /* ---- KL-constrained path (ddp_oracle_kl.c): src/backward_pass.jl:259-350, src/klutils.jl, src/forward_pass.jl:37-56,
  *      src/iLQGkl.jl (single-constraint branch).  PARITY UNPINNED — see the header of ddp_oracle_kl.c. ------------- */
 void ddp_oracle_kl_terms(int n, int m, int T, const double *K, const double *k, const double *Sigmai,
