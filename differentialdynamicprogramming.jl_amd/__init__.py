@@ -301,21 +301,18 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     stats = np.zeros((8, B), order="F")
     cap = trace_cap if trace_cap is not None else 4 * max_iter + 64
     cap = min(cap, 4096)
-    tr = np.zeros((cap, B), order="F")
     git = _C.c_int(0)
-    if prerolled:
-        c0 = None if cost is None or np.size(cost) == 0 else _lib.f64(np.reshape(cost, (CL, B), order="F"))
-        cost = np.zeros((CL, B), order="F")
-        _lib.check(_lib.lib().ddp_ilqg_warm_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), _lib.ptr(u0), _lib.ptr(c0),
-                                                _lib.ptr(L), *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr),
-                                                _C.byref(git)))
-    else:
-        cost = np.zeros((CL, B), order="F")
-        _lib.check(_lib.lib().ddp_ilqg_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), _lib.ptr(u0), _lib.ptr(L),
-                                           *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr),
-                                           _C.byref(git)))
+    c0 = None if (not prerolled or cost is None or np.size(cost) == 0) else _lib.f64(np.reshape(cost, (CL, B), order="F"))
+    cost = np.zeros((CL, B), order="F")
+    tr7 = np.zeros((7, cap, B), order="F")
+    _lib.check(_lib.lib().ddp_ilqg_ex_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), int(prerolled), _lib.ptr(u0), _lib.ptr(c0),
+                                          _lib.ptr(L), *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr7),
+                                          _C.byref(git)))
+    tr = tr7[4]
+    # the reference's trace keys (iLQG.jl:257,325-330), one row per iteration: trace["history"][key][iteration-1(, b)]
+    hist = {key: tr7[c] for c, key in enumerate(("λ", "dλ", "α", "improvement", "cost", "reduce_ratio", "grad_norm"))}
     trace = dict(stats=stats, status=stats[0].astype(int), iter=stats[1].astype(int), λ=stats[5], grad_norm=stats[6],
-                 cost=tr, global_iters=git.value)
+                 cost=tr, global_iters=git.value, history=hist)
     if verbosity > 0:
         for b in range(min(B, 8)):
             print("[%d] %s after %d iterations, cost %.6g" % (b, STATUS.get(int(stats[0, b]), "?"), int(stats[1, b]), stats[7, b]))
@@ -324,6 +321,7 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
             return None
         it = int(stats[1, 0])
         trace["cost"] = tr[: max(it - 1, 0), 0]
+        trace["history"] = {key: v[: max(it - 1, 0), 0] for key, v in hist.items()}
         pol = GaussianPolicy(N, n, m, K[..., 0], k[..., 0], np.zeros((m, m, N)), Quu[..., 0])
         return x[..., 0], u[..., 0], pol, Vx[..., 0], Vxx[..., 0], cost[:, 0], trace
     pol = GaussianPolicy(N, n, m, K, k, np.zeros((m, m, N, B)), Quu)

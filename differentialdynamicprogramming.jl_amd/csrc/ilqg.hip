@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void post_bp_kernel(int m, int N, Opt o, const 
 __global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, int CL, Opt o, const double *dV,
                                                     const double *xnew, const double *unew, const double *cnew,
                                                     const double *csumnew, Traj s, double *x, double *u, double *cost,
-                                                    double *k, int trace_cap, double *trace_cost, int *counter)
+                                                    double *k, int trace_cap, double *trace_cost, double *trace7, int *counter)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (!s.run[b]) return;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, 
     }
     const double c0 = s.csum[b], dV0 = dV[2 * b], dV1 = dV[2 * b + 1];
     int sel = -1;
-    double dcost = 0.0;
+    double dcost = 0.0, zlast = 0.0;
     for (int ai = 0; ai < o.nalpha; ++ai) {                            // serial order of the reference
         const double a = o.alpha[ai];
         dcost = c0 - csumnew[(size_t)b + (size_t)B * ai];
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, 
         double z;
         if (expected > 0) z = dcost / expected;
         else z = (dcost > 0) ? 1.0 : ((dcost < 0) ? -1.0 : dcost);    // sign(Δcost) (NaN stays NaN)
+        zlast = z;
         if (z > o.rrmin) { sel = ai; break; }
     }
     double lam = s.lam[b], dlam = s.dlam[b];
@@ -228,6 +229,11 @@ __global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, 
     if (status == DDP_EXIT_RUNNING) {
         const int it = s.iter[b];
         if (trace_cost && it - 1 < trace_cap) trace_cost[(size_t)trace_cap * b + (it - 1)] = s.csum[b];   // :329
+        if (trace7 && it - 1 < trace_cap) {                            // :257,325-330: λ, dλ, α, improvement, cost, reduce_ratio, grad_norm
+            double *t7 = trace7 + 7 * ((size_t)trace_cap * b + (it - 1));
+            t7[0] = lam; t7[1] = dlam; t7[2] = sel >= 0 ? o.alpha[sel] : NAN; t7[3] = dcost; t7[4] = s.csum[b]; t7[5] = zlast;
+            t7[6] = s.gnorm[b];
+        }
         s.iter[b] = it + 1;
         if (acc > o.max_iter) status = DDP_EXIT_MAXITER;               // while accepted_iter <= max_iter (:222)
     }
@@ -260,7 +266,7 @@ void ddp_ilqg_default_opts(ddp_ilqg_opts *o)
 static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, const double *x0, const double *u0,
                      const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx,
                      double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters,
-                     bool prerolled, const double *cost0)
+                     bool prerolled, const double *cost0, double *trace7 = nullptr)
 {
     DDP_CHECK(h && p && x0 && u0 && x && u && K && k && Quu && Vx && Vxx && cost && stats, "ilqg: null argument");
     ddp_ilqg_opts od;
@@ -314,6 +320,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     DDP_HIP(hipMemsetAsync(u, 0, m * N * B * 8, st));
     DDP_HIP(hipMemsetAsync(cost, 0, CL * B * 8, st));
     if (trace_cost && trace_cap > 0) DDP_HIP(hipMemsetAsync(trace_cost, 0, (size_t)trace_cap * B * 8, st));
+    if (trace7 && trace_cap > 0) DDP_HIP(hipMemsetAsync(trace7, 0, (size_t)7 * trace_cap * B * 8, st));
 
     // ---- initial trajectory (iLQG.jl:181-192): first α for which the open-loop rollout of α·u0 stays bounded
     const double one = 1.0;
@@ -366,7 +373,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
         if (rc) return rc;
         DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
         hipLaunchKernelGGL(accept_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)B, (int)CL, o, dV, xn,
-                           un, cn, cs, s, x, u, cost, k, trace_cap, trace_cost, counter);            // STEP 4
+                           un, cn, cs, s, x, u, cost, k, trace_cap, trace_cost, trace7, counter);    // STEP 4
         DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
         DDP_HIP(hipStreamSynchronize(st));
         running = h->h_pinned[0];
@@ -421,6 +428,17 @@ int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const doubl
     return 0;
 }
 
+// everything at once: optional pre-rolled x0 (+ cost0) and the seven per-iteration trace keys of the reference
+// (iLQG.jl:257,325-330): trace7[7, trace_cap, B] rows λ, dλ, α (NaN: no step accepted), improvement, cost, reduce_ratio, grad_norm
+int ddp_ilqg_ex_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, const double *x0, int x0_prerolled,
+                        const double *u0, const double *cost0, const double *lims, double *x, double *u, double *K, double *k,
+                        double *Quu, double *Vx, double *Vxx, double *cost, double *stats, int trace_cap, double *trace7,
+                        int *global_iters)
+{
+    return ilqg_impl(h, p, oo, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, nullptr, global_iters, x0_prerolled != 0,
+                     x0_prerolled ? cost0 : nullptr, trace7);
+}
+
 int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
                         double *cost, double *csum)
 {
@@ -434,7 +452,7 @@ int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, con
 static int ilqg_host(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, const double *x0, const double *u0,
                      const double *cost0, bool prerolled,
                      const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
-                     double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
+                     double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters, double *trace7 = nullptr)
 {
     DDP_CHECK(h && p && x0 && u0, "ilqg: null argument");
     const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p);
@@ -462,10 +480,11 @@ static int ilqg_host(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
            *dQuu = (double *)dev(nullptr, Quu, m * m * N * B * 8), *dVx = (double *)dev(nullptr, Vx, n * N * B * 8),
            *dVxx = (double *)dev(nullptr, Vxx, n * n * N * B * 8), *dcost = (double *)dev(nullptr, cost, CL * B * 8),
            *dstats = (double *)dev(nullptr, stats, DDP_ILQG_NSTATS * B * 8),
-           *dtr = (trace_cost && trace_cap > 0) ? (double *)dev(nullptr, trace_cost, (size_t)trace_cap * B * 8) : nullptr;
+           *dtr = (trace_cost && trace_cap > 0) ? (double *)dev(nullptr, trace_cost, (size_t)trace_cap * B * 8) : nullptr,
+           *dt7 = (trace7 && trace_cap > 0) ? (double *)dev(nullptr, trace7, (size_t)7 * trace_cap * B * 8) : nullptr;
     int rc = failed ? -2 : 0;
     if (failed) ddp_set_error("ilqg: device allocation / upload failed");
-    if (!rc) rc = ilqg_impl(h, &pd, o, dx0, du0, dl, dx, du, dK, dk, dQuu, dVx, dVxx, dcost, dstats, trace_cap, dtr, global_iters, prerolled, dc0);
+    if (!rc) rc = ilqg_impl(h, &pd, o, dx0, du0, dl, dx, du, dK, dk, dQuu, dVx, dVxx, dcost, dstats, trace_cap, dtr, global_iters, prerolled, dc0, dt7);
     if (!rc)
         for (auto &bf : bufs)
             if (bf.hdst && hipMemcpyAsync(bf.hdst, bf.d, bf.bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = -2;
@@ -486,6 +505,15 @@ int ddp_ilqg_warm_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o
                       double *Vx, double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters)
 {
     return ilqg_host(h, p, o, x0, u0, cost0, true, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, trace_cost, global_iters);
+}
+
+int ddp_ilqg_ex_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, const double *x0, int x0_prerolled,
+                    const double *u0, const double *cost0, const double *lims, double *x, double *u, double *K, double *k,
+                    double *Quu, double *Vx, double *Vxx, double *cost, double *stats, int trace_cap, double *trace7,
+                    int *global_iters)
+{
+    return ilqg_host(h, p, o, x0, u0, x0_prerolled ? cost0 : nullptr, x0_prerolled != 0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats,
+                     trace_cap, nullptr, global_iters, trace7);
 }
 
 }   // extern "C"

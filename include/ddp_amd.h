@@ -211,6 +211,18 @@ int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opt
                           const double *x0, const double *u0, const double *cost0, const double *lims,
                           double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
                           double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+/* The general entry: optional pre-rolled x0 (x0_prerolled != 0: x0[n,N,B] and cost0[CL,B] or NULL) and ALL per-iteration
+ * trace keys of the reference (src/iLQG.jl:257,325-330) per trajectory: trace7[7, trace_cap, B] (may be NULL), rows
+ * λ, dλ, α (NaN when no step was accepted), improvement (Δcost), cost (sum), reduce_ratio, grad_norm; entry `iter-1` of
+ * trajectory b is written when its iteration `iter` completes (exits by tolerance leave before the trace like upstream). */
+int ddp_ilqg_ex_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
+                    const double *x0, int x0_prerolled, const double *u0, const double *cost0, const double *lims,
+                    double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                    double *cost, double *stats, int trace_cap, double *trace7, int *global_iters);
+int ddp_ilqg_ex_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
+                        const double *x0, int x0_prerolled, const double *u0, const double *cost0, const double *lims,
+                        double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                        double *cost, double *stats, int trace_cap, double *trace7, int *global_iters);
 /* batch-level statistics of one pass in one launch: out4 = [sum(csum[B]), sum(dV[1,:]), sum(dV[2,:]), #(diverge != 0)];
  * any input may be NULL.  This is the vector a multi-GPU job all-reduces (one small collective per pass).               */
 int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const double *dV, const int32_t *diverge, double *out4);

@@ -590,7 +590,8 @@ static int ilqg_impl(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
                      double *Vx, double *Vxx, double *cost,
                      ddp_oracle_ilqg_result *res,
                      int trace_cap, double *tr_cost, double *tr_lambda, double *tr_alpha,
-                     double *tr_gnorm, int prerolled, const double *cost0)
+                     double *tr_gnorm, int prerolled, const double *cost0,
+                     double *tr_dlambda, double *tr_improvement, double *tr_ratio)
 {
     const int n = p->n, m = p->m, N = p->N, CL = ddp_oracle_cost_len(p);
     const size_t nN = (size_t)n * N, mN = (size_t)m * N;
@@ -700,6 +701,9 @@ static int ilqg_impl(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
             if (tr_cost) tr_cost[tl] = sum_(cost, CL);
             if (tr_lambda) tr_lambda[tl] = lambda;
             if (tr_alpha) tr_alpha[tl] = alpha_used;
+            if (tr_dlambda) tr_dlambda[tl] = dlambda;               /* :326 */
+            if (tr_improvement) tr_improvement[tl] = dcost;         /* :328 */
+            if (tr_ratio) tr_ratio[tl] = reduce_ratio;              /* :330 */
             ++tl;
         }
         iter += 1;
@@ -725,7 +729,24 @@ int ddp_oracle_ilqg(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
                     int trace_cap, double *tr_cost, double *tr_lambda, double *tr_alpha,
                     double *tr_gnorm)
 {
-    return ilqg_impl(p, o, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, res, trace_cap, tr_cost, tr_lambda, tr_alpha, tr_gnorm, 0, NULL);
+    return ilqg_impl(p, o, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, res, trace_cap, tr_cost, tr_lambda, tr_alpha, tr_gnorm, 0, NULL,
+                     NULL, NULL, NULL);
+}
+
+/* all seven per-iteration trace keys of iLQG.jl:257,325-330: tr7[7,trace_cap] rows λ, dλ, α (NaN: no step), improvement, cost,
+ * reduce_ratio, grad_norm */
+int ddp_oracle_ilqg_trace7(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
+                           const double *x0, const double *u0, const double *lims,
+                           double *x, double *u, double *K, double *k, double *Quu,
+                           double *Vx, double *Vxx, double *cost, ddp_oracle_ilqg_result *res, int trace_cap, double *tr7)
+{
+    double *t[7];
+    for (int c = 0; c < 7; ++c) t[c] = (double *)calloc((size_t)(trace_cap > 0 ? trace_cap : 1), sizeof(double));
+    const int st = ilqg_impl(p, o, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, res, trace_cap, t[4], t[0], t[2], t[6], 0, NULL, t[1], t[3], t[5]);
+    for (int i = 0; i < trace_cap; ++i)
+        for (int c = 0; c < 7; ++c) tr7[c + 7 * i] = t[c][i];
+    for (int c = 0; c < 7; ++c) free(t[c]);
+    return st;
 }
 
 /* pre-rolled initial trajectory x0[n,N] (iLQG.jl:193-197): no initial rollout; cost0[cost_len] or NULL (= costfun(x0,u0)) */
@@ -734,7 +755,7 @@ int ddp_oracle_ilqg_prerolled(const ddp_oracle_problem *p, const ddp_oracle_ilqg
                               double *x, double *u, double *K, double *k, double *Quu,
                               double *Vx, double *Vxx, double *cost, ddp_oracle_ilqg_result *res)
 {
-    return ilqg_impl(p, o, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, res, 0, NULL, NULL, NULL, NULL, 1, cost0);
+    return ilqg_impl(p, o, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, res, 0, NULL, NULL, NULL, NULL, 1, cost0, NULL, NULL, NULL);
 }
 
 int ddp_oracle_pass_batch_lq(const ddp_oracle_problem *p, int B,

@@ -151,6 +151,13 @@ int ddp_oracle_ilqg(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
                     int trace_cap, double *tr_cost, double *tr_lambda, double *tr_alpha,
                     double *tr_gnorm);
 
+/* all seven per-iteration trace keys (iLQG.jl:257,325-330): tr7[7,trace_cap] rows λ, dλ, α (NaN: no step), improvement, cost,
+ * reduce_ratio, grad_norm */
+int ddp_oracle_ilqg_trace7(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
+                           const double *x0, const double *u0, const double *lims,
+                           double *x, double *u, double *K, double *k, double *Quu,
+                           double *Vx, double *Vxx, double *cost, ddp_oracle_ilqg_result *res, int trace_cap, double *tr7);
+
 /* pre-rolled initial trajectory x0[n,N] (iLQG.jl:193-197): no initial rollout; cost0[cost_len] or NULL (= costfun(x0,u0)) */
 int ddp_oracle_ilqg_prerolled(const ddp_oracle_problem *p, const ddp_oracle_ilqg_opts *o,
                               const double *x0, const double *u0, const double *cost0, const double *lims,

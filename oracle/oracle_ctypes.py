@@ -303,3 +303,30 @@ def ilqg_prerolled(p, x0, u0, cost0=None, lims=None, **kw):
     info = dict(status=res.status, iter=res.iter, accepted_iter=res.accepted_iter, n_backpass=res.n_backpass,
                 n_forward=res.n_forward, lam=res.lambda_, dlam=res.dlambda, g_norm=res.g_norm, dV=np.array(res.dV[:]))
     return x, u, (K, k, Quu), Vx, Vxx, cost, info
+
+
+def ilqg_trace7(p, x0, u0, lims=None, trace_cap=2048, **kw):
+    """ilqg() returning all seven per-iteration trace keys (iLQG.jl:257,325-330) as info["history"]"""
+    n, m, N = p.n, p.m, p.N
+    CL = lib().ddp_oracle_cost_len(C.byref(p))
+    o = ILQGOpts()
+    lib().ddp_oracle_ilqg_default_opts(C.byref(o))
+    alpha = _f(kw.pop("alpha", 10.0 ** np.linspace(0, -3, 11)))
+    o.n_alpha, o.alpha = len(alpha), _p(alpha)
+    names = dict(lam="lambda_", dlam="dlambda", lam_factor="lambda_factor", lam_max="lambda_max", lam_min="lambda_min")
+    for key, val in kw.items():
+        setattr(o, names.get(key, key), val)
+    x0, u0 = _f(x0), _f(u0)
+    L = None if lims is None or np.size(lims) == 0 else _f(lims)
+    x = np.zeros((n, N), order="F"); u = np.zeros((m, N), order="F")
+    K = np.zeros((m, n, N), order="F"); k = np.zeros((m, N), order="F"); Quu = np.zeros((m, m, N), order="F")
+    Vx = np.zeros((n, N), order="F"); Vxx = np.zeros((n, n, N), order="F"); cost = np.zeros(CL)
+    res = ILQGResult()
+    tr7 = np.zeros((7, trace_cap), order="F")
+    lib().ddp_oracle_ilqg_trace7.restype = C.c_int
+    lib().ddp_oracle_ilqg_trace7(C.byref(p), C.byref(o), _p(x0), _p(u0), _p(L), _p(x), _p(u), _p(K), _p(k), _p(Quu), _p(Vx), _p(Vxx),
+                                 _p(cost), C.byref(res), trace_cap, _p(tr7))
+    tl = res.trace_len
+    hist = {key: tr7[c, :tl] for c, key in enumerate(("λ", "dλ", "α", "improvement", "cost", "reduce_ratio", "grad_norm"))}
+    info = dict(status=res.status, iter=res.iter, history=hist, trace_len=tl)
+    return x, u, (K, k, Quu), Vx, Vxx, cost, info

@@ -186,3 +186,36 @@ def test_ilqg_prerolled_warm_start(ddp, kind, give_cost):
         assert (int(st[0]), int(st[1])) == (info["status"], info["iter"]), (b, st[:2], info)
         assert relerr(x[..., b], xo) < 1e-7 and relerr(u[..., b], uo) < 1e-7 and relerr(Vxx[..., b], vxx) < 1e-7
         assert abs(cost[:, b].sum() - co.sum()) < 1e-8 * abs(co.sum())
+
+
+# ------------------------------------------------------------------ trace keys (iLQG.jl:257,325-330)
+@pytest.mark.parametrize("kind", ["lq", "pendcart"])
+def test_ilqg_trace_history_matches_oracle(ddp, kind):
+    """λ, dλ, α, improvement, cost, reduce_ratio, grad_norm per iteration and trajectory, like the reference's MVHistory"""
+    from oracle import oracle_ctypes as oc, np_restatement as npr
+    rng = np.random.default_rng(51)
+    B = 3
+    if kind == "lq":
+        n, m, N = 10, 2, 50
+        P = npr.make_lq_problem(rng, T=N)
+        prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+        p = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=P["Q"], R=P["R"])
+        x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B)); u0 = 0.1 * rng.standard_normal((m, N, B)); lims = None
+        kw = dict(max_iter=25)
+    else:
+        n, m, N = 4, 1, 60
+        prob = ddp.PendcartProblem()
+        p = oc.make_problem("pendcart", 4, 1, N, Q=prob.Q, R=prob.R, pend=dict(g=prob.g, l=prob.l, h=prob.h, d=prob.d, goal=prob.goal))
+        x0 = np.array([np.pi - 0.6, 0, 0, 0])[:, None] + 0.05 * rng.standard_normal((4, B)); u0 = 0.3 * rng.standard_normal((1, N, B))
+        lims = np.array([[-5.0, 5.0]])
+        kw = dict(max_iter=12, regType=2)
+    x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(prob, x0, u0, lims=lims, max_iter=kw["max_iter"], regType=kw.get("regType", 1))
+    for b in range(B):
+        info = oc.ilqg_trace7(p, x0[:, b], u0[..., b], lims, **kw)[6]
+        tl = info["trace_len"]
+        assert tl >= 3
+        for key, ref in info["history"].items():
+            got = tr["history"][key][:tl, b]
+            both_nan = np.isnan(got) & np.isnan(ref)
+            scale = max(1e-300, np.nanmax(np.abs(ref))) if np.isfinite(ref).any() else 1.0
+            assert np.all(both_nan | (np.abs(got - ref) <= 1e-7 * scale + 1e-12)), (key, b, got, ref)
