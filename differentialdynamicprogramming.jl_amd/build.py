@@ -20,7 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 
 
 # MFMA accumulators stay in the (unified) VGPR file: no v_accvgpr_read/write shuffles around every product
-EXTRA_FLAGS = {"back_pass_mx.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"back_pass_mx.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "back_pass_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _stale(target, deps):
