@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libddp_amd.so")
-SOURCES = ["capi.hip", "back_pass.hip", "back_pass_fast.hip", "back_pass_dpp.hip", "back_pass_big.hip", "back_pass_mfma.hip", "back_pass_mx.hip",
+SOURCES = ["capi.hip", "back_pass.hip", "back_pass_fast.hip", "back_pass_dpp.hip", "back_pass_big.hip", "back_pass_mfma.hip", "back_pass_mfma_lims.hip", "back_pass_mx.hip",
            "forward_pass.hip", "forward_pass_dpp.hip", "forward_pass_big.hip", "df.hip", "ilqg.hip", "kl.hip"]
 HEADERS = ["ddp_internal.h", "boxqp_dev.h", "arena.h", os.path.join("..", "..", "include", "ddp_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
@@ -24,6 +24,9 @@ EXTRA_FLAGS = {"back_pass_mx.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "back_pass_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
+EXTRA_DEPS = {"back_pass_mfma.hip": ["back_pass_mfma_kernel.h"], "back_pass_mfma_lims.hip": ["back_pass_mfma_kernel.h"]}
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -33,7 +36,7 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS + EXTRA_DEPS.get(src, [])]
     if _stale(obj, deps):
         cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
