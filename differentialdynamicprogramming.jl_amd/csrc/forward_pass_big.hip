@@ -111,6 +111,183 @@ __global__ __launch_bounds__(DDP_WAVE) void cost_rt_kernel(FBArgs a)
     if (lane == 0) a.csum[rho] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// n = 64, m = 8 (BASELINE config 4): the rollout is a stream of 41 KB per step (A_i, B_i, K_i) behind a short
+// dependent chain, so the kernel is organised around keeping one whole step of operands in flight per wave:
+//   * 16-byte loads only: lane (h, j') with h = lane/32 holds rows 2j', 2j'+1 of the columns [36h, 36h+36) of
+//     [A_i B_i] (36 loads), its share of K_i as 4 loads of two consecutive gain rows, and pairs of x, u, k;
+//   * the operands of step i+1 are requested before step i is computed (two register buffers, loop unrolled by 2);
+//   * x̂, dx and u go through LDS once per step; the two column halves are summed with one v_permlane32_swap per
+//     dword, K·dx is reduced over the 16 lanes that share a gain-row pair with four xor-shuffles.
+// Same arithmetic as forward_big_kernel (src/forward_pass.jl:9-33), sums in a different (fixed) order.
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double sum_halves(double v)      // v(lane) + v(lane ^ 32) in every lane
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u2v e = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);      // .x = lower half everywhere, .y = upper half
+    const u2v f = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)f.x, (int)e.x) + __hiloint2double((int)f.y, (int)e.y);
+}
+
+struct FB64Buf { d2 ab[36], kr[4], xo, uo, ko; };
+
+template <bool POL>
+__global__ __launch_bounds__(DDP_WAVE) void forward_big64_kernel(FBArgs a)
+{
+    constexpr int n = 64, m = 8, NC = 36;
+    const int N = a.N, B = a.B;
+    const long rho = blockIdx.x;
+    const int b = (int)(rho % B), ai = (int)(rho / B);
+    if (a.active && a.active[b] == 0) return;
+    const int lane = threadIdx.x, h = lane >> 5, r0 = 2 * (lane & 31), q0 = 2 * (lane & 3);
+    const double alpha = a.alpha[ai];
+    __shared__ __attribute__((aligned(16))) double zs[n + m], dxs[n];
+    constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    const double *ug = a.u + (size_t)m * N * b;
+    const double *xg = POL ? a.x + (size_t)n * N * b : nullptr;
+    const double *Kg = POL ? a.K + nm * N * b : nullptr;
+    const double *kg = POL ? a.k + (size_t)m * N * b : nullptr;
+    double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai);
+    double *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
+    const double *Ab = a.A + (a.dyn_batched ? nn * (a.dyn_tv ? N : 1) * b : 0);
+    const double *Bb = a.Bm + (a.dyn_batched ? nm * (a.dyn_tv ? N : 1) * b : 0);
+    const bool tv = a.dyn_tv, lims = a.has_lims;
+    const double lo0 = lims ? a.lims[q0] : 0.0, hi0 = lims ? a.lims[q0 + m] : 0.0;
+    const double lo1 = lims ? a.lims[q0 + 1] : 0.0, hi1 = lims ? a.lims[q0 + 1 + m] : 0.0;
+
+    auto fetch = [&](int i, FB64Buf &f) {
+        const double *Ai = Ab + (tv ? nn * i : 0), *Bi = Bb + (tv ? nm * i : 0);
+        const double *pa = Ai + n * NC * h + r0;                      // column 36h of A, my row pair
+        const double *pb = h ? Bi + r0 - n * (n - NC) : Ai + r0;   // t >= 28: half 1 continues in B (column 36+t-64), half 0 in A (column t)
+#pragma unroll
+        for (int t = 0; t < NC; ++t) f.ab[t] = *(const d2 *)((t < n - NC ? pa : pb) + n * t);
+        if (POL) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.kr[t] = *(const d2 *)(Kg + nm * i + 2 * lane + 2 * DDP_WAVE * t);
+            f.xo = *(const d2 *)(xg + (size_t)n * i + r0);
+            f.ko = *(const d2 *)(kg + (size_t)m * i + q0);
+        }
+        f.uo = *(const d2 *)(ug + (size_t)m * i + q0);
+    };
+    double xa = a.x0[(size_t)n * b + r0], xb = a.x0[(size_t)n * b + r0 + 1];
+    auto step = [&](int i, const FB64Buf &f) {
+        const d2 xh = d2{xa, xb};
+        if (h == 0) {
+            *(d2 *)(zs + r0) = xh;
+            if (POL) *(d2 *)(dxs + r0) = xh - f.xo;
+            *(d2 *)(xo + (size_t)n * i + r0) = xh;
+        }
+        wave_sync();
+        // x part of A x̂ + B u: columns [0,28) of my half are state columns for both halves
+        double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0;
+        const double *zp = zs + NC * h;
+        if (i < N - 1) {
+#pragma unroll
+            for (int t = 0; t < n - NC; t += 2) {
+                const d2 z = *(const d2 *)(zp + t);
+                sa0 += f.ab[t].x * z.x; sb0 += f.ab[t].y * z.x;
+                sa1 += f.ab[t + 1].x * z.y; sb1 += f.ab[t + 1].y * z.y;
+            }
+        }
+        // controls (forward_pass.jl:17-24): gain rows q0, q0+1, state columns (lane>>2) + 16t
+        double v0 = f.uo.x, v1 = f.uo.y;
+        if (POL) {
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const double d = dxs[(lane >> 2) + 16 * t]; p0 += f.kr[t].x * d; p1 += f.kr[t].y * d; }
+#pragma unroll
+            for (int off = 4; off < DDP_WAVE; off <<= 1) { p0 += __shfl_xor(p0, off, DDP_WAVE); p1 += __shfl_xor(p1, off, DDP_WAVE); }
+            v0 += f.ko.x * alpha; v1 += f.ko.y * alpha;              // unew .+= k*α
+            v0 += p0; v1 += p1;                                      // unew .+= K*dx
+        }
+        if (lims) { v0 = clampd(v0, lo0, hi0); v1 = clampd(v1, lo1, hi1); }
+        if (v0 != v0) v0 = 0.0;                                      // u[isnan.(u)] .= 0 inside f
+        if (v1 != v1) v1 = 0.0;
+        if (lane < 4) { *(d2 *)(zs + n + q0) = d2{v0, v1}; *(d2 *)(uo + (size_t)m * i + q0) = d2{v0, v1}; }
+        wave_sync();
+        if (i < N - 1) {                                             // the last 8 columns of each half: x̂[28..36) | u
+#pragma unroll
+            for (int t = n - NC; t < NC; t += 2) {
+                const d2 z = *(const d2 *)(zp + t);
+                sa0 += f.ab[t].x * z.x; sb0 += f.ab[t].y * z.x;
+                sa1 += f.ab[t + 1].x * z.y; sb1 += f.ab[t + 1].y * z.y;
+            }
+            xa = sum_halves(sa0 + sa1); xb = sum_halves(sb0 + sb1);
+        }
+        wave_sync();
+    };
+    FB64Buf f0, f1;
+    fetch(0, f0);
+    int i = 0;
+    for (; i + 1 < N; i += 2) {
+        fetch(i + 1, f1);
+        step(i, f0);
+        fetch(i + 2 < N ? i + 2 : i + 1, f0);                        // (re-reads the last step at the end: valid memory, unused)
+        step(i + 1, f1);
+    }
+    if (i < N) step(i, f0);
+}
+
+// cost of the n = 64, m = 8 rollouts: one wave per (rollout, 16 time steps); lane j keeps row j of Q in registers,
+// x̂_l comes from v_readlane as a scalar operand, the 64 products x_j·(Qx)_j of a time step are summed through LDS.
+__global__ __launch_bounds__(DDP_WAVE) void cost_big64_kernel(FBArgs a)
+{
+    constexpr int n = 64, m = 8, TB = 16;
+    const int N = a.N, B = a.B;
+    const long rho = blockIdx.x;
+    const int b = (int)(rho % B), t0 = blockIdx.y * TB;
+    if (a.active && a.active[b] == 0) return;
+    const int lane = threadIdx.x;
+    const double *x = a.xnew + (size_t)n * N * rho, *u = a.unew + (size_t)m * N * rho;
+    __shared__ double prod[TB][n + 1];
+    double q[n];
+#pragma unroll
+    for (int l = 0; l < n; ++l) q[l] = a.Q[lane + n * l];
+    const int nt = min(TB, N - t0);
+    for (int t = 0; t < nt; ++t) {
+        const double xj = x[(size_t)n * (t0 + t) + lane];
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int l = 0; l < n; l += 2) {
+            s0 += q[l] * __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xj), l), __builtin_amdgcn_readlane(__double2loint(xj), l));
+            s1 += q[l + 1] * __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xj), l + 1), __builtin_amdgcn_readlane(__double2loint(xj), l + 1));
+        }
+        prod[t][lane] = xj * (s0 + s1);
+    }
+    wave_sync();
+    if (lane < nt) {
+        double qx = 0.0, ru = 0.0;
+        for (int jj = 0; jj < n; ++jj) qx += prod[lane][jj];
+        const double *ut = u + (size_t)m * (t0 + lane);
+        double uu[m];
+#pragma unroll
+        for (int i = 0; i < m; ++i) uu[i] = ut[i];
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < m; ++jj) s += a.R[i + m * jj] * uu[jj];
+            ru += uu[i] * s;
+        }
+        a.cnew[(size_t)N * rho + t0 + lane] = 0.5 * qx + 0.5 * ru;
+    }
+}
+
+// csum[rho] = sum_t cnew[t, rho] in a fixed order (one wave per rollout)
+__global__ __launch_bounds__(DDP_WAVE) void cost_sum_kernel(FBArgs a)
+{
+    const int N = a.N;
+    const long rho = blockIdx.x;
+    if (a.active && a.active[(int)(rho % a.B)] == 0) return;
+    const int lane = threadIdx.x;
+    double acc = 0.0;
+    for (int t = lane; t < N; t += DDP_WAVE) acc += a.cnew[(size_t)N * rho + t];
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, DDP_WAVE);
+    if (lane == 0) a.csum[rho] = acc;
+}
+
 }   // namespace
 
 // returns 1 when not applicable (caller falls back), 0 launched, <0 error
@@ -127,6 +304,15 @@ int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, 
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.xnew = xnew; a.unew = unew; a.cnew = cnew; a.csum = csum;
     const dim3 grid((unsigned)((long)p->B * nalpha)), block(DDP_WAVE);
+    const char *env = getenv("DDP_FORWARD64");                       // DDP_FORWARD64=0: run-time-sized kernels also at n = 64, m = 8
+    if (p->n == 64 && p->m == 8 && !(env && env[0] == '0')) {
+        if (a.has_policy) hipLaunchKernelGGL(forward_big64_kernel<true>, grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL(forward_big64_kernel<false>, grid, block, 0, h->stream, a);
+        hipLaunchKernelGGL(cost_big64_kernel, dim3(grid.x, (unsigned)((p->N + 15) / 16)), block, 0, h->stream, a);
+        hipLaunchKernelGGL(cost_sum_kernel, grid, block, 0, h->stream, a);
+        DDP_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(forward_big_kernel, grid, block, 0, h->stream, a);
     const size_t shmem = ((size_t)p->n * p->n + (size_t)p->m * p->m) * sizeof(double);
     hipLaunchKernelGGL(cost_rt_kernel, grid, block, shmem, h->stream, a);

@@ -78,11 +78,13 @@ def test_back_pass_large_divergence(ddp):
     assert not Vxx[:, :, :4, 1].any()
 
 
+@pytest.mark.parametrize("fwd64", ["1", "0"])      # the n=64/m=8 streaming kernel, and the run-time-sized one on the same shape
 @pytest.mark.parametrize("lims", [False, True])
-def test_forward_pass_large(ddp, lims):
+def test_forward_pass_large(ddp, monkeypatch, lims, fwd64):
     from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_FORWARD64", fwd64)
     rng = np.random.default_rng(8)
-    n, m, N, B = 64, 8, 20, 3
+    n, m, N, B = 64, 8, 21, 3                      # odd N: the two-step unrolled loop ends on its tail
     cx, cu, cxx, cxu, cuu, fx, fu, u = _problem(rng, n, m, N, B, False)
     Q, R = cxx, cuu
     x0 = rng.standard_normal((n, B))
