@@ -15,7 +15,7 @@
 //   P3 | P2b  wave 0 reduces Quu and computes the gains (every lane factorises QuuF, lane c solves column c of K;
 //        or the boxQP) WHILE waves 1-3 compute the 10 upper Qxx tiles (+cxx) into Vs (Vxx_{i+1} is dead after P1)
 //   P4   Vxx_i = Qxx + ½(K'Y + Y'K): the rank-16 update [K;Y]'·½[Y;K] as 4 more MFMAs per upper tile with the
-//        Qxx tile as the C operand; diagonal tiles are symmetrised through LDS, the others mirrored.
+//        Qxx tile as the C operand; the upper triangle is mirrored (exactly symmetric Vxx).
 // Measured (profiles/microbench/mfma_f64_bench.hip): 30 ns per MFMA per wave with ONE wave per SIMD (66-70 TF/s of the
 // 78.6 TF/s peak) — unlike the fp64 VALU, the matrix pipe does not need several waves to fill.
 // Included by back_pass_mfma.hip (no control limits; built with -amdgpu-mfma-vgpr-form) and back_pass_mfma_lims.hip
@@ -45,7 +45,7 @@ constexpr int oVs = 0, oFs = oVs + n * LDV, oWT = oFs + PP * LDK, ovs = oWT + n 
 #ifdef DDP_MFPROF     // per-phase cycle counts (s_memtime) of block 0, printed per wave: profiling builds only
 #define MFP_DECL long long mfp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mfp_t = __builtin_amdgcn_s_memtime()
 #define MFP(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); mfp_[k] += t_ - mfp_t; mfp_t = t_; } while (0)
-#define MFP_PRINT do { if (b == 0 && lane == 0) printf("MFPROF wave %d steps %d: p1 %lld bar %lld p2a %lld bar %lld p3|p2b %lld bar %lld p4 %lld bar %lld | p1: gemm %lld wst %lld; p4: stF %lld tiles %lld; top %lld ldF %lld ctv %lld\n", wv, N - 1, \
+#define MFP_PRINT do { if (b == 0 && lane == 0) printf("MFPROF wave %d steps %d: p1 %lld bar %lld p2a %lld bar %lld p3|p2b %lld bar %lld p4 %lld bar %lld | p1: gemm %lld wst %lld; p4: stF %lld tiles %lld; p3: red+H %lld chol+k %lld Ksolve %lld\n", wv, N - 1, \
     mfp_[0] / (N - 1), mfp_[1] / (N - 1), mfp_[2] / (N - 1), mfp_[3] / (N - 1), mfp_[4] / (N - 1), mfp_[5] / (N - 1), mfp_[6] / (N - 1), mfp_[7] / (N - 1), mfp_[8] / (N - 1), mfp_[9] / (N - 1), mfp_[10] / (N - 1), mfp_[11] / (N - 1), mfp_[12] / (N - 1), mfp_[13] / (N - 1), mfp_[14] / (N - 1)); } while (0)
 #else
 #define MFP_DECL
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
     for (int i = N - 2; i >= 0; --i) {
         const double *cxxi = cxx + (CTV ? nn * i : 0), *cxui = cxu + (CTV ? nm * i : 0), *cuui = cuu + (CTV ? mm * i : 0);
         const bool ldF = FXTV && i > 0;                 // next step's Jacobian is fetched under this step's first product
-        MFP(13);
         if (CTV || i == N - 2) {                        // so do the cost terms: they become the C operands of the G tiles
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -168,9 +167,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 }
             }
         }
-        MFP(14);
         double gx[4] = {0.0, 0.0, 0.0, 0.0}, gu[2] = {0.0, 0.0};   // gradient entries riding in column 72: cx (rows of this wave), cu
-        MFP(12);
         // ================= P1: W = Vxx·F on the matrix cores; column 72 of W := Vx ===========================
         {
             d4 acc[5];
@@ -282,6 +279,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
 #pragma unroll
                 for (int q = 0; q < m; ++q) H[q + m * q] += lam;
             }
+            MFP(12);
             int fail;
             double ri[m];
             const bool use_ri = !LIMS || nolims;                     // division-free factor on the unconstrained path
@@ -301,6 +299,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 const int result = boxqp_dev<m>(m, H, g, lo, up, x0, qpo, kk, R, clamped, iters);
                 fail = (result < 1);
             }
+            MFP(13);
             if (lane == 0) flag[0] = fail ? 1.0 : 0.0;
             if (fail) {
                 Quug[mm * i + lane] = Quus[lane];
@@ -309,8 +308,13 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 double col[m], x2[m], qu[m];
 #pragma unroll
                 for (int q = 0; q < m; ++q) { x2[q] = Xs[q + m * lane]; col[q] = ((clamped >> q) & 1u) ? 0.0 : Xr[q + m * lane]; qu[q] = Qs[n + q]; }
+                // Unconstrained regType 1: (Quu + λI)·K = -Qux and (Quu + λI)·k = -Qu hold to the backward error of the solve,
+                // so Quu·K and Quu·k need no product with Quu (the other cases take it from LDS again: H is dead, R holds the factor)
+                const bool by_residual = use_ri && regType != 2;
+                if (!by_residual) {
 #pragma unroll
-                for (int e = 0; e < m * m; ++e) H[e] = Quus[e];       // the unregularised Quu (H is dead: R, ri hold the factor)
+                    for (int e = 0; e < m * m; ++e) H[e] = Quus[e];
+                }
                 const double quu_l = Quus[lane];
                 if (use_ri) ddp_rsolve_neg<m>(R, ri, col);           // K_i column `lane`
                 else {
@@ -318,16 +322,22 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
 #pragma unroll
                     for (int q = 0; q < m; ++q) col[q] = ((clamped >> q) & 1u) ? 0.0 : -col[q];
                 }
+                MFP(14);
                 double y[m], quuk[m], kQu = 0.0, kQuuk = 0.0;
 #pragma unroll
                 for (int q = 0; q < m; ++q) {                        // Y = Quu·K + 2·Qux;  Quu·k, dV (:64-68)
-                    double t = 2.0 * x2[q], t2 = 0.0;
+                    if (by_residual) {
+                        y[q] = fma(-lam, col[q], x2[q]);                 // Quu·K = -Qux - λK
+                        quuk[q] = -fma(lam, kk[q], qu[q]);               // Quu·k = -Qu - λk
+                    } else {
+                        double t = 2.0 * x2[q], t2 = 0.0;
 #pragma unroll
-                    for (int q2 = 0; q2 < m; ++q2) {
-                        const double hq = H[(q < q2 ? q : q2) + m * (q < q2 ? q2 : q)];      // upper triangle, like the factorisation
-                        t += hq * col[q2]; t2 += hq * kk[q2];
+                        for (int q2 = 0; q2 < m; ++q2) {
+                            const double hq = H[(q < q2 ? q : q2) + m * (q < q2 ? q2 : q)];  // upper triangle, like the factorisation
+                            t += hq * col[q2]; t2 += hq * kk[q2];
+                        }
+                        y[q] = t; quuk[q] = t2;
                     }
-                    y[q] = t; quuk[q] = t2;
                 }
 #pragma unroll
                 for (int q = 0; q < m; ++q) { kQu += kk[q] * qu[q]; kQuuk += kk[q] * quuk[q]; }
@@ -404,22 +414,14 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 if (!valid[u]) continue;
-                qp[u][0] = acc[u].x; qp[u][LDV * 4] = acc[u].y; qp[u][LDV * 8] = acc[u].z; qp[u][LDV * 12] = acc[u].w;
-                if (!diag[u]) { mp[u][0] = acc[u].x; mp[u][4] = acc[u].y; mp[u][8] = acc[u].z; mp[u][12] = acc[u].w; }
-            }
-            wave_sync();
-            double uu[3][4];
+                // Off-diagonal tiles exist once and are mirrored.  A diagonal tile holds both (i,j) and (j,i), equal up to rounding:
+                // its upper triangle is mirrored in the same way, so the result is exactly symmetric without an exchange
+                // (the reference averages the two halves, (:71-72); the difference is of the order of the rounding error of G).
+                const double av[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {                             // diagonal tiles: both halves exist, average them like the reference
-                if (!(valid[u] && diag[u])) continue;
-                uu[u][0] = mp[u][0]; uu[u][1] = mp[u][4]; uu[u][2] = mp[u][8]; uu[u][3] = mp[u][12];
-            }
-            wave_sync();
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                if (!(valid[u] && diag[u])) continue;
-                qp[u][0] = 0.5 * (acc[u].x + uu[u][0]); qp[u][LDV * 4] = 0.5 * (acc[u].y + uu[u][1]);
-                qp[u][LDV * 8] = 0.5 * (acc[u].z + uu[u][2]); qp[u][LDV * 12] = 0.5 * (acc[u].w + uu[u][3]);
+                for (int r = 0; r < 4; ++r) {
+                    if (!diag[u] || l4 + 4 * r <= l15) { qp[u][LDV * 4 * r] = av[r]; mp[u][4 * r] = av[r]; }
+                }
             }
         }
         MFP(11);
