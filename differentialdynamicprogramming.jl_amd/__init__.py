@@ -19,6 +19,7 @@ trajectories (``K[m,n,N,B]``), which the reference does not have.
 from __future__ import annotations
 
 import ctypes as _C
+import time as _time
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -26,7 +27,7 @@ import numpy as np
 from . import _lib
 from ._lib import DDPError, Handle, default_handle  # noqa: F401
 
-__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG",
+__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing",
            "df", "Handle", "DDPError", "DEFAULT_ALPHA"]
 
 DEFAULT_ALPHA = 10.0 ** np.linspace(0, -3, 11)     # iLQG.jl:145
@@ -253,6 +254,17 @@ def df(problem, x, u, *, handle=None):
 
 
 # ---------------------------------------------------------------------------------------- iLQG
+def print_timing(trace):
+    """The timing summary of iLQG.jl:343-366 from the trace keys ``time_derivs``, ``time_backward``, ``time_forward``."""
+    parts = [float(np.nansum(trace[k])) for k in ("time_derivs", "time_backward", "time_forward")]
+    total = float(trace.get("time_total", sum(parts)))
+    it = max(int(trace.get("global_iters", 1)), 1)
+    pct = [100.0 * t / total for t in parts] + [100.0 * (total - sum(parts)) / total]
+    print("\n iterations:   %-3d\n time / iter:  %-5.2f ms\n total time:   %-5.3f seconds, of which\n derivs:     %-4.1f%%\n"
+          " back pass:  %-4.1f%%\n fwd pass:   %-4.1f%%\n other:      %-4.1f%% (host, transfers)\n =========== end iLQG ==========="
+          % (it, 1e3 * total / it, total, pct[0], pct[1], pct[2], pct[3]))
+
+
 STATUS = {1: "SUCCESS: gradient norm < tol_grad", 2: "SUCCESS: cost change < tol_fun", 3: "EXIT: λ > λmax",
           4: "EXIT: Maximum iterations reached", -1: "EXIT: Initial control sequence caused divergence"}
 
@@ -305,17 +317,30 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     c0 = None if (not prerolled or cost is None or np.size(cost) == 0) else _lib.f64(np.reshape(cost, (CL, B), order="F"))
     cost = np.zeros((CL, B), order="F")
     tr7 = np.zeros((7, cap, B), order="F")
-    _lib.check(_lib.lib().ddp_ilqg_ex_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), int(prerolled), _lib.ptr(u0), _lib.ptr(c0),
-                                          _lib.ptr(L), *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap, _lib.ptr(tr7),
-                                          _C.byref(git)))
+    tcap = 4 * max_iter + 1000                                 # the driver's bound on global iterations
+    timing = np.full((3, tcap), np.nan)
+    t_start = _time.time()
+    _lib.check(_lib.lib().ddp_ilqg_set_timing(h.raw, _lib.ptr(timing), tcap))
+    try:
+        _lib.check(_lib.lib().ddp_ilqg_ex_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), int(prerolled), _lib.ptr(u0),
+                                              _lib.ptr(c0), _lib.ptr(L), *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap,
+                                              _lib.ptr(tr7), _C.byref(git)))
+    finally:
+        _lib.lib().ddp_ilqg_set_timing(h.raw, None, 0)
+    total_t = _time.time() - t_start
     tr = tr7[4]
     # the reference's trace keys (iLQG.jl:257,325-330), one row per iteration: trace["history"][key][iteration-1(, b)]
     hist = {key: tr7[c] for c, key in enumerate(("λ", "dλ", "α", "improvement", "cost", "reduce_ratio", "grad_norm"))}
     trace = dict(stats=stats, status=stats[0].astype(int), iter=stats[1].astype(int), λ=stats[5], grad_norm=stats[6],
                  cost=tr, global_iters=git.value, history=hist)
+    # time_derivs / time_backward / time_forward (iLQG.jl:227,241,281): GPU seconds per GLOBAL iteration of the batch
+    for r, key in enumerate(("time_derivs", "time_backward", "time_forward")):
+        trace[key] = timing[r, : git.value].copy()
+    trace["time_total"] = total_t
     if verbosity > 0:
         for b in range(min(B, 8)):
             print("[%d] %s after %d iterations, cost %.6g" % (b, STATUS.get(int(stats[0, b]), "?"), int(stats[1, b]), stats[7, b]))
+        print_timing(trace)
     if not batched:
         if int(stats[0, 0]) == -1:
             return None

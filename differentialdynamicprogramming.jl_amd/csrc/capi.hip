@@ -42,6 +42,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
     h->scratch = nullptr;
     h->scratch_bytes = 0;
     h->h_pinned = nullptr;
+    h->timing = nullptr; h->timing_cap = 0; h->tev_ok = false;
     h->owns_stream = !adopt;
     if (adopt) {
         h->stream = (hipStream_t)ext_stream;
@@ -65,6 +66,7 @@ int ddp_destroy(ddp_handle h)
     hipStreamSynchronize(h->stream);
     if (h->scratch) hipFree(h->scratch);
     if (h->h_pinned) hipHostFree(h->h_pinned);
+    if (h->tev_ok) for (int e = 0; e < 4; ++e) hipEventDestroy(h->tev[e]);
     if (h->owns_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;

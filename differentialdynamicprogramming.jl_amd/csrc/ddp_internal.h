@@ -17,6 +17,10 @@ struct ddp_handle_s {
     void        *scratch;
     size_t       scratch_bytes;
     int32_t     *h_pinned;        // small pinned buffer for polling
+    double      *timing;          // ddp_ilqg_set_timing: host buffer [3, timing_cap] or NULL
+    int          timing_cap;
+    hipEvent_t   tev[4];          // created on first use
+    bool         tev_ok;
 };
 
 void ddp_set_error(const char *fmt, ...);

@@ -363,20 +363,38 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
 
     int git = 0;
     const long hard_cap = 4L * oo->max_iter + 1000;      // every global iteration advances iter or λ of each running trajectory
+    // ddp_ilqg_set_timing: the time_derivs / time_backward / time_forward keys of the reference's trace (iLQG.jl:227,241,281)
+    // per global iteration, from HIP events on the stream (the loop synchronises once per iteration anyway)
+    const bool timed = h->timing != nullptr;
+    if (timed && !h->tev_ok) {
+        for (int e = 0; e < 4; ++e) DDP_HIP(hipEventCreate(&h->tev[e]));
+        h->tev_ok = true;
+    }
     while (running > 0 && git < hard_cap) {
+        if (timed) DDP_HIP(hipEventRecord(h->tev[0], st));
         rc = ddp_df_f64_dev(h, p, x, u, s.dodf, cx, cu, fxw, fuw);                                  // STEP 1
         if (rc) return rc;
+        if (timed) DDP_HIP(hipEventRecord(h->tev[1], st));
         rc = ddp_launch_back_pass(h, &d, cx, cu, p->Q, cxu, p->R, fx, fu, s.lam, lims, u, s.run, K, k, Quu, Vx, Vxx, dV, div);   // STEP 2
         if (rc) return rc;
         hipLaunchKernelGGL(post_bp_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)m, (int)N, o, div, k, u, s);
+        if (timed) DDP_HIP(hipEventRecord(h->tev[2], st));
         rc = ddp_forward_pass_f64_dev(h, p, K, k, x0, u, x, o.alpha, (int)na, lims, s.dofwd, xn, un, cn, cs);   // STEP 3
         if (rc) return rc;
+        if (timed) DDP_HIP(hipEventRecord(h->tev[3], st));
         DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
         hipLaunchKernelGGL(accept_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)B, (int)CL, o, dV, xn,
                            un, cn, cs, s, x, u, cost, k, trace_cap, trace_cost, trace7, counter);    // STEP 4
         DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
         DDP_HIP(hipStreamSynchronize(st));
         running = h->h_pinned[0];
+        if (timed && git < h->timing_cap) {
+            for (int e = 0; e < 3; ++e) {
+                float ms = 0.0f;
+                DDP_HIP(hipEventElapsedTime(&ms, h->tev[e], h->tev[e + 1]));
+                h->timing[(size_t)h->timing_cap * e + git] = 1e-3 * (double)ms;
+            }
+        }
         ++git;
     }
     hipLaunchKernelGGL(stats_kernel, dim3(gB), dim3(256), 0, st, (int)B, s, stats);
@@ -517,3 +535,12 @@ int ddp_ilqg_ex_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, 
 }
 
 }   // extern "C"
+
+int ddp_ilqg_set_timing(ddp_handle h, double *host_buf, int cap)
+{
+    DDP_CHECK(h, "ilqg_set_timing: null handle");
+    DDP_CHECK(host_buf == nullptr || cap > 0, "ilqg_set_timing: cap=%d", cap);
+    h->timing = host_buf;
+    h->timing_cap = host_buf ? cap : 0;
+    return 0;
+}

@@ -168,14 +168,19 @@ function iLQG(problem, x0, u0; lims=[], α=exp10.(range(0, stop=-3, length=11)),
     cap = 4max_iter + 64; tr = zeros(cap); git = Ref{Cint}(0)
     x0 = _f64(vec(x0)); u0 = _f64(u0)
     lp = isempty(lims) ? Ptr{Float64}(C_NULL) : pointer(_f64(lims))
-    GC.@preserve problem x0 u0 begin
+    tcap = 4max_iter + 1000; timing = fill(NaN, tcap, 3)     # C layout [3, tcap]: column r of the Julia array is row r
+    GC.@preserve problem x0 u0 timing begin
+        check(@ccall libddp.ddp_ilqg_set_timing(handle.ptr::Ptr{Cvoid}, timing::Ptr{Float64}, tcap::Cint)::Cint)
         check(@ccall libddp.ddp_ilqg_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGOpts},
             x0::Ptr{Float64}, u0::Ptr{Float64}, lp::Ptr{Float64}, x::Ptr{Float64}, u::Ptr{Float64}, K::Ptr{Float64},
             k::Ptr{Float64}, Quu::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64}, cost::Ptr{Float64},
             stats::Ptr{Float64}, cap::Cint, tr::Ptr{Float64}, git::Ptr{Cint})::Cint)
+        @ccall libddp.ddp_ilqg_set_timing(handle.ptr::Ptr{Cvoid}, C_NULL::Ptr{Float64}, 0::Cint)::Cint
     end
     stats[1] == -1 && return nothing                       # EXIT: Initial control sequence caused divergence
-    trace = Dict(:cost => tr[1:max(Int(stats[2]) - 1, 0)], :λ => stats[6], :grad_norm => stats[7], :status => Int(stats[1]))
+    g = Int(git[])
+    trace = Dict(:cost => tr[1:max(Int(stats[2]) - 1, 0)], :λ => stats[6], :grad_norm => stats[7], :status => Int(stats[1]),
+                 :time_derivs => timing[1:g, 1], :time_backward => timing[1:g, 2], :time_forward => timing[1:g, 3])   # iLQG.jl:227,241,281
     return x, u, GaussianPolicy(N, n, m, K, k, zeros(m, m, N), Quu), Vx, Vxx, cost, trace
 end
 

@@ -211,6 +211,11 @@ int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opt
                           const double *x0, const double *u0, const double *cost0, const double *lims,
                           double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
                           double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+/* Per-phase GPU time of the following ddp_ilqg_* calls on this handle — the time_derivs / time_backward / time_forward
+ * trace keys of the reference (src/iLQG.jl:227,241,281; print_timing :343-366): host_buf[3, cap] (row-major: row r at
+ * host_buf + cap*r), seconds per GLOBAL iteration (the batch advances in lock step; the call's *global_iters says how many
+ * columns were written), measured with HIP events on the handle's stream.  NULL switches it off. */
+int ddp_ilqg_set_timing(ddp_handle h, double *host_buf, int cap);
 /* The general entry: optional pre-rolled x0 (x0_prerolled != 0: x0[n,N,B] and cost0[CL,B] or NULL) and ALL per-iteration
  * trace keys of the reference (src/iLQG.jl:257,325-330) per trajectory: trace7[7, trace_cap, B] (may be NULL), rows
  * λ, dλ, α (NaN when no step was accepted), improvement (Δcost), cost (sum), reduce_ratio, grad_norm; entry `iter-1` of

@@ -219,3 +219,20 @@ def test_ilqg_trace_history_matches_oracle(ddp, kind):
             both_nan = np.isnan(got) & np.isnan(ref)
             scale = max(1e-300, np.nanmax(np.abs(ref))) if np.isfinite(ref).any() else 1.0
             assert np.all(both_nan | (np.abs(got - ref) <= 1e-7 * scale + 1e-12)), (key, b, got, ref)
+
+
+def test_ilqg_timing_trace_keys(ddp, capsys):
+    """time_derivs / time_backward / time_forward (iLQG.jl:227,241,281) and print_timing (:343-366)"""
+    rng = np.random.default_rng(5)
+    n, m, N, B = 10, 2, 60, 4
+    a0 = rng.standard_normal((n, n)); A = np.eye(n) + 0.01 * (a0 - a0.T); Bm = 0.01 * rng.standard_normal((n, m))
+    prob = ddp.LQProblem(A, Bm, 0.01 * np.eye(n), 0.001 * np.eye(m))
+    x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(prob, np.ones((n, B)), 0.1 * rng.standard_normal((m, N, B)), verbosity=1)
+    g = tr["global_iters"]
+    assert g >= 1
+    for key in ("time_derivs", "time_backward", "time_forward"):
+        t = tr[key]
+        assert t.shape == (g,) and np.all(np.isfinite(t)) and np.all(t > 0.0)
+    assert sum(tr[k].sum() for k in ("time_derivs", "time_backward", "time_forward")) <= tr["time_total"]
+    out = capsys.readouterr().out
+    assert "back pass:" in out and "fwd pass:" in out and "derivs:" in out
