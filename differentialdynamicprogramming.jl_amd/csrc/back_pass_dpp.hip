@@ -99,19 +99,30 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
 
     // ---- column j of F = [fx fu], of the cost Hessians, and of the state
     double Fcol[n], cxxcol[n], ccol[m];            // ccol: x-lanes cxu[j, :] (= column j of cxu'), u-lanes cuu[:, j-n]
+    // The idle lanes' columns are zeroed by mask_F / mask_C when the values are USED, not when they are loaded: any
+    // arithmetic on a loaded value puts the s_waitcnt at the load and would expose the HBM latency of the prefetch ring.
+    const double zF = (j < p) ? 1.0 : 0.0, zx = inx ? 1.0 : 0.0, zu = (inx || inu) ? 1.0 : 0.0;
     auto load_F = [&](int i, double (&F)[n]) {
         const double *src = (j < n) ? fx + (FXTV ? nn * i : 0) + (size_t)n * jx : fu + (FXTV ? nm * i : 0) + (size_t)n * ja;
-        const double z = (j < p) ? 1.0 : 0.0;
 #pragma unroll
-        for (int r = 0; r < n; ++r) F[r] = z * src[r];
+        for (int r = 0; r < n; ++r) F[r] = src[r];
+    };
+    auto mask_F = [&](double (&F)[n], const double (&raw)[n]) {
+#pragma unroll
+        for (int r = 0; r < n; ++r) F[r] = zF * raw[r];
     };
     auto load_C = [&](int i, double (&cc)[n], double (&c2)[m]) {
-        const double zx = inx ? 1.0 : 0.0;
 #pragma unroll
-        for (int r = 0; r < n; ++r) cc[r] = zx * cxx[(CTV ? nn * i : 0) + (size_t)n * jx + r];
+        for (int r = 0; r < n; ++r) cc[r] = cxx[(CTV ? nn * i : 0) + (size_t)n * jx + r];
+        const double *src = inx ? cxu + (CTV ? nm * i : 0) + jx : cuu + (CTV ? mm * i : 0) + (size_t)m * ja;     // stride n | 1
 #pragma unroll
-        for (int q = 0; q < m; ++q)
-            c2[q] = inx ? cxu[(CTV ? nm * i : 0) + jx + (size_t)n * q] : (inu ? cuu[(CTV ? mm * i : 0) + q + (size_t)m * ja] : 0.0);
+        for (int q = 0; q < m; ++q) c2[q] = src[inx ? (size_t)n * q : (size_t)q];
+    };
+    auto mask_C = [&](double (&cc)[n], double (&c2)[m], const double (&rawc)[n], const double (&raw2)[m]) {
+#pragma unroll
+        for (int r = 0; r < n; ++r) cc[r] = zx * rawc[r];
+#pragma unroll
+        for (int q = 0; q < m; ++q) c2[q] = zu * raw2[q];
     };
     double Vcol[n], vj;
     // terminal step (backward_pass.jl:234-236 / :197-199)
@@ -142,7 +153,9 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
     int diverge = 0;
     if (N >= 2) {
         load_F(FXTV ? N - 2 : 0, Fcol);
+        mask_F(Fcol, Fcol);
         load_C(CTV ? N - 2 : 0, cxxcol, ccol);
+        mask_C(cxxcol, ccol, cxxcol, ccol);
         // regType 2 adds λ·F_u'F to the u-rows (backward_pass.jl:245-247): FuF[a] = Σ_k F[k,n+a]·F[k,j]
         double FuF[m];
         auto make_FuF = [&]() {
@@ -169,8 +182,21 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
         };
 #pragma unroll
         for (int d = 0; d < D; ++d) { const int i = N - 2 - d; fetch_c(i >= 0 ? i : 0, d); }
-        // time-varying operands two steps ahead
-        double Fn[FXTV ? n : 1], cxxn[CTV ? n : 1], ccn[CTV ? m : 1];
+        // Time-varying operands: a ring DF steps deep.  The loads are UNCONDITIONAL (clamped index) and sit behind the stores of
+        // the step: a load inside a branch makes the compiler drain the in-order vmcnt at the join (s_waitcnt vmcnt(0) — the
+        // step's own output stores included, ~1 us), and a ring one step deep exposes the HBM latency on every step.
+        constexpr int DF = (n <= 6) ? 4 : 2;
+        static_assert(D % DF == 0, "ring slots must be fixed registers of the unrolled loop");
+        double Fr[FXTV ? DF : 1][FXTV ? n : 1], cxxr[CTV ? DF : 1][CTV ? n : 1], ccr[CTV ? DF : 1][CTV ? m : 1];
+        // slot of the operands of step (N-2) - e  is  e % DF
+        if constexpr (FXTV) {
+#pragma unroll
+            for (int e = 1; e <= DF; ++e) load_F(N - 2 - e >= 0 ? N - 2 - e : 0, Fr[e % DF]);
+        }
+        if constexpr (CTV) {
+#pragma unroll
+            for (int e = 1; e <= DF; ++e) load_C(N - 2 - e >= 0 ? N - 2 - e : 0, cxxr[e % DF], ccr[e % DF]);
+        }
         bool have_prev = false;                       // a column of the previous step waits in the transpose buffer
         int prev_i = 0;
         // Symmetric Vxx_i = ½(V + V') from the transpose buffer, written as 16-byte pieces that are CONTIGUOUS
@@ -198,8 +224,6 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
         };
 
         auto step = [&](int i, int d) __attribute__((always_inline)) {
-            if constexpr (FXTV) { if (i > 0) load_F(i - 1, Fn); }
-            if constexpr (CTV) { if (i > 0) load_C(i - 1, cxxn, ccn); }
             // ================= P1: w = Vxx·F[:,j],  q = c + F[:,j]'Vx ==================================
             double w[n], qj = 0.0;
 #pragma unroll
@@ -240,7 +264,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
             });
             unsigned clamped = 0u;
             int fail;
-            double Kc[m], ri[m];
+            double Kc[m], ri[m], rH1 = 0.0;
+            bool use_rh = false;
             if constexpr (!LIMS) {
                 // cholesky(Hermitian(QuuF)) (:35) with reciprocal pivots (v_rsq_f64 + 2 Newton steps): the whole
                 // factor-and-solve is division-free, which matters because every lane of the row repeats it
@@ -294,8 +319,13 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
                 static_for<0, m>([&](auto qc) { constexpr int q = decltype(qc)::value; uq[q] = row_bcast<n + q>(ru[LIMS ? d : 0]); });
 #pragma unroll
                 for (int q = 0; q < m; ++q) { lo[q] = limlo[q] - uq[q]; up[q] = limhi[q] - uq[q]; }   // (:45-46)
-                int iters;
-                const int result = boxqp_dev<m>(m, H, Qu, lo, up, kprev, qpo, kk, R, clamped, iters);  // (:49)
+                int iters, result;
+                if constexpr (m == 1) {                                  // scalar, division-free restatement (boxqp_dev.h)
+                    result = boxqp_dev1(H[0], Qu[0], lo[0], up[0], kprev[0], qpo, kk[0], rH1, clamped, iters);
+                    use_rh = true;
+                } else {
+                    result = boxqp_dev<m>(m, H, Qu, lo, up, kprev, qpo, kk, R, clamped, iters);         // (:49)
+                }
                 fail = (result < 1);                                     // (:53)
             }
             const bool alive = diverge == 0 && !fail;
@@ -304,11 +334,15 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
             // x-columns carry don't-care values: they are never a broadcast source and never stored.
             double Y[m];
             if constexpr (LIMS) {
+                if (m == 1 && use_rh) {
+                    Kc[0] = (clamped & 1u) ? 0.0 : -(gr[0] * rH1);
+                } else {
 #pragma unroll
-                for (int q = 0; q < m; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : gr[q];
-                chol_solve<m>(m, R, Kc);
+                    for (int q = 0; q < m; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : gr[q];
+                    chol_solve<m>(m, R, Kc);
 #pragma unroll
-                for (int q = 0; q < m; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : -Kc[q];
+                    for (int q = 0; q < m; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : -Kc[q];
+                }
             }
             double Quuk[m];
 #pragma unroll
@@ -367,33 +401,31 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
 #pragma unroll
             for (int q = 0; q < m; ++q) kprev[q] = kk[q];
             fetch_c(i - D >= 0 ? i - D : 0, d);
-            if constexpr (FXTV) {
-                if (i > 0) {
-#pragma unroll
-                    for (int r = 0; r < n; ++r) Fcol[r] = Fn[r];
-                }
+            if constexpr (FXTV) {                                        // operands of step i-1 leave the ring, those of i-1-DF enter
+                mask_F(Fcol, Fr[(d + 1) % DF]);
+                load_F(i - 1 - DF >= 0 ? i - 1 - DF : 0, Fr[(d + 1) % DF]);
             }
             if constexpr (CTV) {
-                if (i > 0) {
-#pragma unroll
-                    for (int r = 0; r < n; ++r) cxxcol[r] = cxxn[r];
-#pragma unroll
-                    for (int q = 0; q < m; ++q) ccol[q] = ccn[q];
-                }
+                mask_C(cxxcol, ccol, cxxr[(d + 1) % DF], ccr[(d + 1) % DF]);
+                load_C(i - 1 - DF >= 0 ? i - 1 - DF : 0, cxxr[(d + 1) % DF], ccr[(d + 1) % DF]);
             }
             dpp_fence(Vcol);
             asm volatile("s_nop 1" : "+v"(vj));
-            if constexpr (FXTV) { if (i > 0) { dpp_fence(Fcol); make_FuF(); } }
+            if constexpr (FXTV) { dpp_fence(Fcol); make_FuF(); }
             wave_sync();                                                 // orders the transpose buffer writes/reads
         };
         dpp_fence(Vcol);
         asm volatile("s_nop 1" : "+v"(vj));
-        for (int i0 = N - 2; i0 >= 0; i0 -= D) {
+        // Whole groups of D steps run without a guard: inside a conditional the waitcnt pass cannot count the memory operations
+        // of the other steps as "issued after" a ring slot's load and falls back to s_waitcnt vmcnt(0/1) for every slot.
+        int i0 = N - 2;
+        for (; i0 - (D - 1) >= 0; i0 -= D) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int i = i0 - d;
-                if (i >= 0) step(i, d);
-            }
+            for (int d = 0; d < D; ++d) step(i0 - d, d);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (i0 - d >= 0) step(i0 - d, d);
         }
         // flush the last queued column (step 0)
         if (have_prev && act) store_sym(&tr[grp][prev_i & 1][0], prev_i);

@@ -193,3 +193,62 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
     iters = iter;
     return result;
 }
+
+// m = 1 (the reference's own limited case, pendcart): the same control flow as boxqp_dev<1> written on scalars and
+// without divisions or square roots —  (g/R)/R with R = sqrt(H) becomes g·(1/H) (v_rcp_f64 + 2 Newton steps), the
+// gradient norm sqrt(grad²) is |grad|, and the Armijo test (vc - old)/(step·sdotg) < Armijo is multiplied through by
+// step·sdotg < 0.  Differences to the generic routine are of rounding order (decisions can differ only when a tested
+// quantity sits within an ulp of its threshold).  `rH` = 1/H[free] of the returned factor replaces R (0 if none).
+__device__ __forceinline__ double ddp_rcp_nr(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+__device__ __forceinline__ int boxqp_dev1(double H, double g, double lower, double upper, double x0, const QPOptsDev &o,
+                                          double &x, double &rH, unsigned &clamped, int &iters)
+{
+    int result = 0, iter = 1;
+    double oldvalue = 0.0, value;
+    clamped = 0u;
+    rH = 0.0;
+    x = ddp_clamp(x0, lower, upper);                                                           // :58
+    auto val = [&](double xx) { return xx * g + ((0.5 * xx) * H) * xx; };                      // :63 (same association as qp_value)
+    value = val(x);
+    while (iter <= o.maxIter) {                                                                // :71
+        if (result != 0) break;
+        if (iter > 1 && (oldvalue - value) < o.minRelImprove * fabs(oldvalue)) { result = 4; break; }
+        oldvalue = value;
+        const double grad = g + H * x;                                                         // :85
+        const unsigned newc = (((x == lower) && (grad > 0)) || ((x == upper) && (grad < 0))) ? 1u : 0u;
+        const unsigned oldc = clamped;
+        clamped = newc;
+        if (clamped == 1u) { result = 6; break; }                                              // :98-101
+        if (iter == 1 || oldc != clamped) {                                                    // :104-117
+            if (!(H > 0.0)) { result = 0; break; }                                             // PosDefException -> 0
+            rH = ddp_rcp_nr(H);
+        }
+        if (fabs(grad) < o.minGrad) { result = 5; break; }                                     // :120-124
+        const double search = -(g * rH) - x;                                                   // :127-129 (nothing clamped here)
+        const double sdotg = search * grad;                                                    // :132
+        if (sdotg >= 0) break;                                                                 // :133-135
+        double step = 1.0;                                                                     // :138-151
+        double xc = ddp_clamp(x + step * search, lower, upper), vc = val(xc);
+        while ((vc - oldvalue) > o.Armijo * (step * sdotg)) {                                  // ratio < Armijo with step·sdotg < 0
+            step = step * o.stepDec;
+            xc = ddp_clamp(x + step * search, lower, upper);
+            vc = val(xc);
+            if (step < o.minStep) { result = 2; break; }
+        }
+        x = xc;                                                                                // :161-163
+        value = vc;
+        iter += 1;
+    }
+    if (iter == o.maxIter) result = 1;                                                         // :167-169
+    iters = iter;
+    return result;
+}
