@@ -185,7 +185,9 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
             } else {                                                     // system_pendcart.jl:83-89
                 const double x0v = row_bcast<0>(xh), x1v = row_bcast<1>(xh), x3v = row_bcast<3>(xh);
                 const double gl = a.g / a.l, h = a.h;
-                const double f1 = x1v + h * (-gl * sin(x0v) + uu[0] / a.l * cos(x0v) - a.d * x1v);
+                double sn, cs;
+                sincos(x0v, &sn, &cs);                                   // one argument reduction for both
+                const double f1 = x1v + h * (-gl * sn + uu[0] / a.l * cs - a.d * x1v);
                 xp = (j == 0) ? x0v + h * x1v : (j == 1) ? f1 : (j == 2) ? xh + h * x3v : x3v + h * uu[0];
                 xp = inx ? xp : 0.0;
             }

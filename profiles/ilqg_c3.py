@@ -15,3 +15,7 @@ for it in range(2):
     st = r[6]["stats"]
     print("C3 iLQG pendcart B=%d: %.3f s, %d batch iterations, exit reasons %s, mean iterations %.1f, mean cost %.1f"
           % (B, dt, r[6]["global_iters"], dict(zip(*np.unique(st[0].astype(int), return_counts=True))), st[1].mean(), st[7].mean()))
+    tr = r[6]
+    parts = {k: float(np.nansum(tr[k])) for k in ("time_derivs", "time_backward", "time_forward")}
+    print("   GPU phases (HIP events, s): derivs %.3f  back %.3f  forward(+cost, %d alphas) %.3f  | other (host, H2D/D2H, state machine) %.3f"
+          % (parts["time_derivs"], parts["time_backward"], len(kw["α"]), parts["time_forward"], tr["time_total"] - sum(parts.values())))
