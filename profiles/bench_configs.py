@@ -99,7 +99,7 @@ def c3(B=4096):
     u0 = 2.0 * np.sin(np.arange(N) / 37.0)[None, :, None] * np.ones((1, 1, B))
     nolims = os.environ.get("DDP_C3_NOLIMS") == "1"            # A/B: what the control limits (boxQP) cost
     run("C3 pendcart" + (" (no lims)" if nolims else " lims"), prob, n, m, N, B, f64(x0), f64(u0),
-        None if nolims else 5.0 * np.array([[-1.0, 1.0]]), 2, None)
+        None if nolims else float(os.environ.get("DDP_C3_LIMSCALE", "5.0")) * np.array([[-1.0, 1.0]]), 2, None)
 
 
 def c4(B=1024):
