@@ -27,7 +27,7 @@ import numpy as np
 from . import _lib
 from ._lib import DDPError, Handle, default_handle  # noqa: F401
 
-__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing",
+__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing", "mpc_shift",
            "df", "Handle", "DDPError", "DEFAULT_ALPHA"]
 
 DEFAULT_ALPHA = 10.0 ** np.linspace(0, -3, 11)     # iLQG.jl:145
@@ -190,6 +190,29 @@ def boxQP(H, g, lower, upper, x0, *, maxIter=100, minGrad=1e-8, minRelImprove=1e
         nf = int(free.sum())
         return x[:, 0], int(res[0]), Hf[:nf, :nf, 0], free
     return x, res, Hf, fr.astype(bool)
+
+
+# ------------------------------------------------------------------------------- MPC warm start
+def mpc_shift(a, shift=1, *, zero_tail=False, batched=None, handle=None):
+    """Receding-horizon shift of a time-major array ``a[...,N(,B)]`` (controls, nominal states, gains; ``batched`` says whether the
+    last axis is the batch — default: yes for more than two axes) by ``shift`` steps through
+    ``ddp_mpc_shift_f64_dev``: ``out[:,i] = a[:,i+shift]``, the vacated tail repeats the last column (or is zero).  New — the
+    reference has no MPC loop; its hook is the pre-rolled ``x0[n,N]`` + ``cost`` warm start (iLQG.jl:193-197)."""
+    h = handle or default_handle()
+    a = _lib.f64(a)
+    if batched is None:
+        batched = a.ndim > 2
+    lead = a.shape[:-2] if batched else a.shape[:-1]
+    N, B = (a.shape[-2], a.shape[-1]) if batched else (a.shape[-1], 1)
+    d = int(np.prod(lead))
+    src = h.to_device(a)
+    dst = h.malloc(a.nbytes)
+    try:
+        _lib.check(_lib.lib().ddp_mpc_shift_f64_dev(h.raw, d, N, B, int(shift), int(bool(zero_tail)), src, dst))
+        out = h.to_host(dst, a.shape)
+    finally:
+        h.free(src); h.free(dst)
+    return out
 
 
 # ------------------------------------------------------------------------------- forward_pass

@@ -457,6 +457,30 @@ int ddp_ilqg_ex_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts 
                      x0_prerolled ? cost0 : nullptr, trace7);
 }
 
+namespace {
+// dst[:, i, b] = src[:, min(i + shift, N-1), b]  (tail: the last column repeated, or zeros)
+__global__ __launch_bounds__(256) void mpc_shift_kernel(int d, int N, long total, int shift, int zero_tail, const double *src, double *dst)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long per = (long)d * N;
+    const long b = e / per, r = e % per;
+    const int i = (int)(r / d), c = (int)(r % d);
+    const int is = i + shift;
+    dst[e] = (is < N) ? src[b * per + (long)is * d + c] : (zero_tail ? 0.0 : src[b * per + (long)(N - 1) * d + c]);
+}
+}   // namespace
+
+int ddp_mpc_shift_f64_dev(ddp_handle h, int d, int N, int B, int shift, int zero_tail, const double *src, double *dst)
+{
+    DDP_CHECK(h && src && dst && src != dst, "mpc_shift: null or aliased argument (out of place only)");
+    DDP_CHECK(d > 0 && N > 0 && B > 0 && shift >= 0, "mpc_shift: d=%d N=%d B=%d shift=%d", d, N, B, shift);
+    const long total = (long)d * N * B;
+    hipLaunchKernelGGL(mpc_shift_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, d, N, total, shift, zero_tail, src, dst);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
 int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
                         double *cost, double *csum)
 {

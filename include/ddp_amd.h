@@ -231,6 +231,11 @@ int ddp_ilqg_ex_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts 
 /* batch-level statistics of one pass in one launch: out4 = [sum(csum[B]), sum(dV[1,:]), sum(dV[2,:]), #(diverge != 0)];
  * any input may be NULL.  This is the vector a multi-GPU job all-reduces (one small collective per pass).               */
 int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const double *dV, const int32_t *diverge, double *out4);
+/* Receding-horizon warm start between two MPC solves (new, the reference has no MPC loop — its hook is
+ * the pre-rolled `x0[n,N]` + `cost` of src/iLQG.jl:193-197, see ddp_ilqg_warm_f64): a time-major array a[d, N, B] moves
+ * `shift` steps towards the present, dst[:, i, b] = src[:, i+shift, b]; the vacated tail repeats the last column
+ * (zero_tail = 0: controls, nominal states) or is zero (zero_tail = 1: gains).  Out of place, device pointers.        */
+int ddp_mpc_shift_f64_dev(ddp_handle h, int d, int N, int B, int shift, int zero_tail, const double *src, double *dst);
 /* the `costfun` closure of the registered families on given trajectories: cost[CL,B], csum[B] (may be NULL)          */
 int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
                         double *cost, double *csum);

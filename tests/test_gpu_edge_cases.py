@@ -236,3 +236,31 @@ def test_ilqg_timing_trace_keys(ddp, capsys):
     assert sum(tr[k].sum() for k in ("time_derivs", "time_backward", "time_forward")) <= tr["time_total"]
     out = capsys.readouterr().out
     assert "back pass:" in out and "fwd pass:" in out and "derivs:" in out
+
+
+def test_mpc_shift_and_receding_horizon_loop(ddp):
+    """ddp_mpc_shift_f64_dev against NumPy, then three receding-horizon solves warm-started from the shifted solution"""
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(21)
+    a = rng.standard_normal((3, 2, 7, 4))                          # K-like [m,n,N,B]
+    for sh, zt in ((1, False), (2, True), (9, False), (0, False)):
+        out = ddp.mpc_shift(a, sh, zero_tail=zt)
+        ref = np.empty_like(a)
+        for i in range(7):
+            ref[:, :, i] = a[:, :, i + sh] if i + sh < 7 else (0.0 if zt else a[:, :, 6])
+        assert np.array_equal(out, ref)
+    assert np.array_equal(ddp.mpc_shift(a[..., 0], 1, batched=False), np.concatenate([a[:, :, 1:, 0], a[:, :, -1:, 0]], axis=2))
+    # receding horizon on the LQ family: solve, apply u[:,0], shift, re-solve from the measured state; every solve is checked
+    n, m, N = 10, 2, 40
+    a0 = rng.standard_normal((n, n)); A = np.eye(n) + 0.01 * (a0 - a0.T); Bm = 0.01 * rng.standard_normal((n, m))
+    Q, R = 0.01 * np.eye(n), 0.001 * np.eye(m)
+    prob = ddp.LQProblem(A, Bm, Q, R)
+    p = oc.make_problem("lq", n, m, N, A=A, B=Bm, Q=Q, R=R)
+    xm = np.ones(n); u = 0.1 * rng.standard_normal((m, N))
+    for step in range(3):
+        x, us, pol, Vx, Vxx, cost, tr = ddp.iLQG(prob, xm, u)
+        xr, ur, polr, vxr, vxxr, cr, info = oc.ilqg(p, xm, u)
+        assert relerr(us, ur) < RTOL and relerr(x, xr) < RTOL and int(tr["iter"][0]) == info["iter"]
+        xm = A @ xm + Bm @ us[:, 0] + 1e-3 * rng.standard_normal(n)      # the plant moved on (with a disturbance)
+        u = ddp.mpc_shift(us, 1)
+    assert np.array_equal(u[:, :-1], us[:, 1:]) and np.array_equal(u[:, -1], us[:, -1])
