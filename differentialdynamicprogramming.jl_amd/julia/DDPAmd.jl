@@ -184,6 +184,22 @@ function iLQG(problem, x0, u0; lims=[], α=exp10.(range(0, stop=-3, length=11)),
     return x, u, GaussianPolicy(N, n, m, K, k, zeros(m, m, N), Quu), Vx, Vxx, cost, trace
 end
 
+"""
+    mpc_shift(a, shift=1; zero_tail=false)
+
+Receding-horizon warm start between two solves: `out[:, i] = a[:, i+shift]` along the time axis (the last axis of `u[m,N]`,
+`x[n,N]`, `K[m,n,N]`), the vacated tail repeats the last column or is zero.  Host arrays; device-resident loops call
+`ddp_mpc_shift_f64_dev` on their buffers instead.
+"""
+function mpc_shift(a::AbstractArray, shift::Integer=1; zero_tail::Bool=false)
+    N = size(a, ndims(a)); out = similar(a)
+    for i in 1:N
+        src = i + shift
+        selectdim(out, ndims(a), i) .= src <= N ? selectdim(a, ndims(a), src) : (zero_tail ? zero(eltype(a)) : selectdim(a, ndims(a), N))
+    end
+    out
+end
+
 # ---- KL-constrained path (src/backward_pass.jl:259-350, src/klutils.jl, src/forward_pass.jl:37-56) -------------------
 struct KLCostTerms
     cx::Ptr{Float64}; cu::Ptr{Float64}; cxx::Ptr{Float64}; cxu::Ptr{Float64}; cuu::Ptr{Float64}; eta::Ptr{Float64}; eta_tv::Cint
