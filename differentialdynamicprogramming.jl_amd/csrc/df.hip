@@ -190,6 +190,47 @@ __global__ void df_lq_kernel(int n, int m, int N, int B, const double *Q, const 
     }
 }
 
+// cx = Q x, cu = R u for n <= 64: Q and R live in LDS, a work-group walks tiles of 256/n trajectory columns — the x tile is
+// read and the cx tile written as one contiguous 2 KB piece, thread (i, c) forms row i of column c (the one-thread-per-column
+// kernel above reads and writes with a stride of n doubles between lanes: 8 ms for the 64 x 262 144 columns of BASELINE
+// config 4, as long as the whole backward pass).  Same summation order as df_lq_kernel.
+__global__ __launch_bounds__(256) void df_lq_tiled_kernel(int n, int m, int N, long cols, const double *Q, const double *R, const double *x,
+                                                           const double *u, const int32_t *active, double *cx, double *cu)
+{
+    extern __shared__ double sm[];
+    double *Qs = sm, *Rs = sm + n * n, *xs = Rs + m * m;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) Qs[e] = Q[e];
+    for (int e = tid; e < m * m; e += 256) Rs[e] = R[e];
+    const int cpb = 256 / n, i = tid % n, c = tid / n;
+    const long ntiles = (cols + cpb - 1) / cpb;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long col = tile * cpb + c;
+        const bool valid = c < cpb && col < cols;
+        __syncthreads();                                           // Qs/Rs ready; previous tile's xs consumed
+        if (valid) xs[tid] = x[(size_t)n * col + i];
+        __syncthreads();
+        if (valid && !(active && active[(int)(col / N)] == 0)) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += Qs[i + n * j] * xs[j + n * c];
+            cx[(size_t)n * col + i] = s;
+        }
+    }
+    const long nu = (long)m * cols;
+    for (long e = (long)blockIdx.x * 256 + tid; e < nu; e += (long)gridDim.x * 256) {
+        const long col = e / m;
+        const int q = (int)(e % m);
+        if (active && active[(int)(col / N)] == 0) continue;
+        double s = 0.0;
+        for (int j = 0; j < m; ++j) {
+            double uj = u[(size_t)m * col + j];
+            if (uj != uj) uj = 0.0;                                   // u[isnan.(u)] .= 0
+            s += Rs[q + m * j] * uj;
+        }
+        cu[e] = s;
+    }
+}
+
 __global__ __launch_bounds__(64) void df_pendcart_kernel(int N, int B, double g, double l, double h, double d,
                                                          double g0, double g1, double g2, double g3, const double *Q,
                                                          const double *R, const double *x, const double *u,
@@ -243,8 +284,16 @@ int ddp_df_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const do
     DDP_CHECK(h && p && x && u && cx && cu, "df: null argument");
     const long cols = (long)p->N * p->B;
     if (p->kind == DDP_PROBLEM_LQ) {
-        const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
-        hipLaunchKernelGGL(df_lq_kernel, grid, block, 0, h->stream, p->n, p->m, p->N, p->B, p->Q, p->R, x, u, active, cx, cu);
+        if (p->n <= 64 && p->m <= 16) {
+            const int cpb = 256 / p->n;
+            const long ntiles = (cols + cpb - 1) / cpb;
+            const dim3 grid((unsigned)(ntiles < 8192 ? ntiles : 8192)), block(256);
+            const size_t shmem = ((size_t)p->n * p->n + (size_t)p->m * p->m + 256) * sizeof(double);
+            hipLaunchKernelGGL(df_lq_tiled_kernel, grid, block, shmem, h->stream, p->n, p->m, p->N, cols, p->Q, p->R, x, u, active, cx, cu);
+        } else {
+            const dim3 grid((unsigned)((cols + 255) / 256)), block(256);
+            hipLaunchKernelGGL(df_lq_kernel, grid, block, 0, h->stream, p->n, p->m, p->N, p->B, p->Q, p->R, x, u, active, cx, cu);
+        }
     } else if (p->kind == DDP_PROBLEM_PENDCART) {
         DDP_CHECK(p->n == 4 && p->m == 1, "df: pendcart needs n=4, m=1");
         DDP_CHECK(fx && fu, "df: pendcart needs fx and fu outputs");
