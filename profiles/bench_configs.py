@@ -123,6 +123,40 @@ def c4(B=1024):
     x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
     u0 = 0.1 * rng.standard_normal((m, N, B))
     run("C4 large-state LTV", prob, n, m, N, B, f64(x0), f64(u0), None, 1, (dA, dB, 1, 1), steps=5, warmup=1)
+    if os.environ.get("DDP_C4_SOLVE", "1") == "1":
+        solve("C4 full iLQG solves (device-resident driver)", prob, n, m, N, B, f64(x0), f64(u0), nalpha=4)
+
+
+def solve(name, prob, n, m, N, B, dx0, du0, nalpha=11, max_iter=50):
+    """whole iLQG solves through ddp_ilqg_f64_dev with device buffers; phase split from the :time_* trace keys"""
+    o = _lib.ILQGOpts()
+    L.ddp_ilqg_default_opts(C.byref(o))
+    o.max_iter = max_iter
+    al = 10.0 ** np.linspace(0, -3, nalpha)
+    o.n_alpha = nalpha
+    for i, a in enumerate(al):
+        o.alpha[i] = a
+    CL = N
+    x, u = empty(n * N * B), empty(m * N * B)
+    K, k, Quu = empty(m * n * N * B), empty(m * N * B), empty(m * m * N * B)
+    Vx, Vxx, cost, stats = empty(n * N * B), empty(n * n * N * B), empty(CL * B), empty(8 * B)
+    cap = 4 * max_iter + 1000
+    timing = np.full((3, cap), np.nan)
+    git = C.c_int(0)
+    _lib.check(L.ddp_ilqg_set_timing(h.raw, _lib.ptr(timing), cap))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _lib.check(L.ddp_ilqg_f64_dev(h.raw, C.byref(prob), C.byref(o), p(dx0), p(du0), None, p(x), p(u), p(K), p(k), p(Quu), p(Vx), p(Vxx),
+                                  p(cost), p(stats), 0, None, C.byref(git)))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L.ddp_ilqg_set_timing(h.raw, None, 0)
+    st = stats.cpu().numpy().reshape(B, 8).T if False else stats.cpu().numpy().reshape(8, B, order="F")
+    g = git.value
+    print(json.dumps({"config": name, "batch": B, "seconds": round(el, 4), "batch_iterations": g,
+                      "mean_iterations": round(float(st[1].mean()), 2), "exit_reasons": {int(a): int(b) for a, b in zip(*np.unique(st[0].astype(int), return_counts=True))},
+                      "time_derivs_s": round(float(np.nansum(timing[0, :g])), 4), "time_backward_s": round(float(np.nansum(timing[1, :g])), 4),
+                      "time_forward_s": round(float(np.nansum(timing[2, :g])), 4), "n_alpha": nalpha, "mean_cost": round(float(st[7].mean()), 4)}))
 
 
 if __name__ == "__main__":
