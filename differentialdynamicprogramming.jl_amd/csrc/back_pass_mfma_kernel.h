@@ -44,7 +44,7 @@ constexpr int oVs = 0, oFs = oVs + n * LDV, oWT = oFs + PP * LDK, ovs = oWT + n 
 
 #ifdef DDP_MFPROF     // per-phase cycle counts (s_memtime) of block 0, printed per wave: profiling builds only
 #define MFP_DECL long long mfp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mfp_t = __builtin_amdgcn_s_memtime()
-#define MFP(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); mfp_[k] += t_ - mfp_t; mfp_t = t_; } while (0)
+#define MFP(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); mfp_[k] += t_ - mfp_t; mfp_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MFP_PRINT do { if (b == 0 && lane == 0) printf("MFPROF wave %d steps %d: p1 %lld bar %lld p2a %lld bar %lld p3|p2b %lld bar %lld p4 %lld bar %lld | p1: gemm %lld wst %lld; p4: stF %lld tiles %lld; p3: red+H %lld chol+k %lld Ksolve %lld\n", wv, N - 1, \
     mfp_[0] / (N - 1), mfp_[1] / (N - 1), mfp_[2] / (N - 1), mfp_[3] / (N - 1), mfp_[4] / (N - 1), mfp_[5] / (N - 1), mfp_[6] / (N - 1), mfp_[7] / (N - 1), mfp_[8] / (N - 1), mfp_[9] / (N - 1), mfp_[10] / (N - 1), mfp_[11] / (N - 1), mfp_[12] / (N - 1), mfp_[13] / (N - 1), mfp_[14] / (N - 1)); } while (0)
 #else
