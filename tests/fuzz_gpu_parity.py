@@ -1,4 +1,5 @@
-"""Randomised GPU-vs-oracle parity sweep (not collected by pytest; run on a GPU box: python tests/fuzz_gpu_parity.py [cases] [seed]).
+"""Randomised GPU-vs-oracle parity sweep (not collected by pytest; run on a GPU box: python tests/fuzz_gpu_parity.py [cases] [seed];
+`--cond seed case` runs on the CPU and prints how far the two CPU restatements are apart on that case).
 Draws shapes, operand layouts (LTI / LTV, shared / per-trajectory, time-varying cost), regType, λ, limits and horizon, runs
 back_pass and forward_pass through the C ABI and compares every output with the C restatement at 1e-8."""
 import os
@@ -18,7 +19,7 @@ def spd(rng, d, s):
     return s * (a @ a.T / d + 0.5 * np.eye(d))
 
 
-def one_case(ddp, oc, rng, case):
+def gen_case(rng):
     n, m = [(10, 2), (4, 1), (6, 3), (64, 8), (7, 2), (12, 4), (40, 4)][rng.integers(0, 7)]
     big = rng.integers(0, 6) == 0                                 # now and then a long horizon / several waves
     N = (int(rng.integers(1, 300 if big else 40))) if n < 40 else int(rng.integers(2, 14))
@@ -35,7 +36,6 @@ def one_case(ddp, oc, rng, case):
         fx_tv = True; shp = (N, B)              # per-trajectory operands use the time-varying layout (a3)
     fx = np.eye(n).reshape((n, n) + (1,) * len(shp)) + h * rng.standard_normal((n, n) + shp) / np.sqrt(n)
     fu = h * rng.standard_normal((n, m) + shp)
-    cshp = (N, B) if c_tv else ()
     if c_tv:
         cxx = np.stack([np.stack([spd(rng, n, h) for _ in range(N)], -1) for _ in range(B)], -1)
         cuu = np.stack([np.stack([spd(rng, m, 0.1 * h) for _ in range(N)], -1) for _ in range(B)], -1)
@@ -47,36 +47,93 @@ def one_case(ddp, oc, rng, case):
     lam = 10.0 ** rng.uniform(-4, 1, B)
     if rng.integers(0, 8) == 0 and N > 3 and c_tv:                 # provoke a divergence somewhere
         cuu[:, :, int(rng.integers(0, N - 1)), int(rng.integers(0, B))] = -np.eye(m)
-    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, lims, None, u)
+    Q, R = spd(rng, n, h), spd(rng, m, 0.1 * h)
+    x0 = rng.standard_normal((n, B)); xnom = rng.standard_normal((n, N, B))
+    return dict(n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, c_tv=c_tv, regType=regType, lims=lims, fx=fx, fu=fu, cxx=cxx, cuu=cuu, cxu=cxu,
+                cx=cx, cu=cu, u=u, lam=lam, Q=Q, R=R, x0=x0, xnom=xnom)
+
+
+def ref_back_pass(bp, c, b):
+    sl = lambda a_, nd: a_[..., b] if a_.ndim == nd + 1 else a_          # noqa: E731
+    fxb = c["fx"][..., b] if c["fx_b"] else c["fx"]
+    fub = c["fu"][..., b] if c["fx_b"] else c["fu"]
+    return bp(c["cx"][..., b], c["cu"][..., b], sl(c["cxx"], 3), sl(c["cxu"], 3), sl(c["cuu"], 3), fxb, fub, c["lam"][b], c["regType"],
+              c["lims"], None, c["u"][..., b])
+
+
+def one_case(ddp, oc, rng, case):
+    c = gen_case(rng)
+    n, m, N, B, lims = c["n"], c["m"], c["N"], c["B"], c["lims"]
+    tag = (case, {k: c[k] for k in ("n", "m", "N", "B", "fx_tv", "fx_b", "c_tv", "regType")}, "lims" if lims is not None else "no lims")
+    div, pol, Vx, Vxx, dV = ddp.back_pass(c["cx"], c["cu"], c["cxx"], c["cxu"], c["cuu"], c["fx"], c["fu"], c["lam"], c["regType"], lims, None, c["u"])
     worst = 0.0
     for b in range(B):
-        sl = lambda a_, nd: a_[..., b] if a_.ndim == nd + 1 else a_          # noqa: E731
-        fxb = fx[..., b] if fx_b else fx
-        fub = fu[..., b] if fx_b else fu
-        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], sl(cxx, 3), sl(cxu, 3), sl(cuu, 3), fxb, fub,
-                                                  lam[b], regType, lims, None, u[..., b])
-        assert div[b] == d, ("diverge", case, n, m, N, B, div[b], d)
+        d, (K, k, Quu), vx, vxx, dv = ref_back_pass(oc.back_pass, c, b)
+        assert div[b] == d, ("diverge", tag, div[b], d)
         for got, ref, name in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (Vx[..., b], vx, "Vx"), (Vxx[..., b], vxx, "Vxx"),
                                (dV[:, b], dv, "dV")):
             e = relerr(got, ref)
             worst = max(worst, e)
-            assert e < RTOL, (name, e, case, dict(n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, c_tv=c_tv, regType=regType, lims=lims is not None))
+            assert e < RTOL, (name, e, tag, "trajectory %d" % b)
     # forward rollout with the gains just computed (LQ family), two step sizes
-    if not fx_b or fx_tv:
-        Q, R = spd(rng, n, h), spd(rng, m, 0.1 * h)
-        prob = ddp.LQProblem(fx, fu, Q, R, dyn_batched=fx_b) if fx_tv else ddp.LQProblem(fx, fu, Q, R)
-        x0 = rng.standard_normal((n, B)); xnom = rng.standard_normal((n, N, B))
-        Kc = np.where(np.isfinite(pol.K), pol.K, 0.0); kc = np.where(np.isfinite(pol.k), pol.k, 0.0)
-        al = np.array([1.0, 0.3])
-        xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(N, n, m, Kc, kc), x0, u, xnom, al, prob, lims)
-        for b in range(B):
-            p = oc.make_problem("lq", n, m, N, A=fx[..., b] if fx_b else fx, B=fu[..., b] if fx_b else fu, Q=Q, R=R)
-            for j, a in enumerate(al):
-                xr, ur, cr = oc.forward_pass(p, (Kc[..., b], kc[..., b]), x0[:, b], u[..., b], xnom[..., b], float(a), lims)
-                for got, ref, name in ((xn[..., b, j], xr, "xnew"), (un[..., b, j], ur, "unew"), (cn[..., b, j], cr, "cnew")):
-                    e = relerr(got, ref)
-                    worst = max(worst, e)
-                    assert e < RTOL, (name, e, case, dict(n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, lims=lims is not None))
+    fx, fu, fx_b, fx_tv, Q, R = c["fx"], c["fu"], c["fx_b"], c["fx_tv"], c["Q"], c["R"]
+    prob = ddp.LQProblem(fx, fu, Q, R, dyn_batched=fx_b) if fx_tv else ddp.LQProblem(fx, fu, Q, R)
+    Kc = np.where(np.isfinite(pol.K), pol.K, 0.0); kc = np.where(np.isfinite(pol.k), pol.k, 0.0)
+    al = np.array([1.0, 0.3])
+    xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(N, n, m, Kc, kc), c["x0"], c["u"], c["xnom"], al, prob, lims)
+    for b in range(B):
+        p = oc.make_problem("lq", n, m, N, A=fx[..., b] if fx_b else fx, B=fu[..., b] if fx_b else fu, Q=Q, R=R)
+        for j, a in enumerate(al):
+            xr, ur, cr = oc.forward_pass(p, (Kc[..., b], kc[..., b]), c["x0"][:, b], c["u"][..., b], c["xnom"][..., b], float(a), lims)
+            for got, ref, name in ((xn[..., b, j], xr, "xnew"), (un[..., b, j], ur, "unew"), (cn[..., b, j], cr, "cnew")):
+                e = relerr(got, ref)
+                worst = max(worst, e)
+                assert e < RTOL, (name, e, tag, "trajectory %d" % b)
+    return worst
+
+
+def conditioning(seed, case):
+    """CPU only: how far the two independent CPU restatements (C and NumPy/LAPACK) are apart on a case — the rounding-error
+    amplification of the problem itself, to tell an ill-conditioned draw from a kernel defect"""
+    from oracle import oracle_ctypes as oc
+    from oracle import np_restatement as npr
+    c = gen_case(np.random.default_rng([seed, case]))
+    worst = {}
+    for b in range(c["B"]):
+        d1, (K1, k1, Q1), vx1, vxx1, dv1 = ref_back_pass(oc.back_pass, c, b)
+        d2, (K2, k2, Q2), vx2, vxx2, dv2 = ref_back_pass(npr.back_pass, c, b)
+        for name, g, r in (("K", K1, K2), ("k", k1, k2), ("Vx", vx1, vx2), ("Vxx", vxx1, vxx2)):
+            worst[name] = max(worst.get(name, 0.0), relerr(g, r))
+    print("case (%d, %d): %s  C vs NumPy restatement: %s" % (seed, case, {k: c[k] for k in ("n", "m", "N", "B", "regType")}, worst))
+
+
+def ilqg_case(ddp, oc, rng, case):
+    """whole iLQG solves on random LQ problems (own λ schedule, line search and exit per trajectory)"""
+    n, m = [(10, 2), (6, 3), (4, 1), (12, 4)][rng.integers(0, 4)]
+    N, B = int(rng.integers(5, 60)), int(rng.integers(1, 5))
+    h = 0.02
+    a0 = rng.standard_normal((n, n)); A = np.eye(n) + h * (a0 - a0.T); Bm = h * rng.standard_normal((n, m))
+    Q, R = spd(rng, n, h), spd(rng, m, 0.1 * h)
+    lims = None if rng.integers(0, 2) else np.stack([-rng.uniform(0.2, 2.0, m), rng.uniform(0.2, 2.0, m)], 1)
+    x0 = rng.standard_normal((n, B)); u0 = 0.2 * rng.standard_normal((m, N, B))
+    regType = int(rng.integers(1, 3))
+    x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(ddp.LQProblem(A, Bm, Q, R), x0, u0, lims=lims, regType=regType)
+    p = oc.make_problem("lq", n, m, N, A=A, B=Bm, Q=Q, R=R)
+    worst = 0.0
+    for b in range(B):
+        xr, ur, polr, vxr, vxxr, cr, info = oc.ilqg(p, x0[:, b], u0[..., b], lims=lims, regType=regType)
+        st = tr["stats"][:, b]
+        same_path = (int(st[0]), int(st[1])) == (info["status"], info["iter"])
+        # The accept / terminate tests (tol_fun, tol_grad) and, with limits, boxQP's own stopping tests sit at thresholds: a
+        # rounding-level difference can move a solve one iteration or change the exit reason.  The SOLUTION must agree either way;
+        # the whole trajectory to 1e-8 only when both took the same decisions and no QP tolerance is involved.
+        cg, cr_ = float(cost[:, b].sum()), float(cr.sum())
+        assert abs(cg - cr_) <= 1e-6 * abs(cr_), ("cost", cg, cr_, case, dict(n=n, m=m, N=N, B=B, lims=lims is not None, regType=regType))
+        if same_path and lims is None:
+            for got, ref, name in ((x[..., b], xr, "x"), (u[..., b], ur, "u"), (Vxx[..., b], vxxr, "Vxx")):
+                e = relerr(got, ref)
+                worst = max(worst, e)
+                assert e < RTOL, (name, e, case, dict(n=n, m=m, N=N, B=B, regType=regType))
     return worst
 
 
@@ -89,9 +146,16 @@ def main():
     rng = np.random.default_rng(seed)
     worst = 0.0
     for c in range(cases):
-        worst = max(worst, one_case(ddp, oc, rng, c))
+        worst = max(worst, one_case(ddp, oc, np.random.default_rng([seed, c]), c))          # every case reproducible on its own
     print("fuzz: %d cases passed, worst relative error %.3g" % (cases, worst))
+    worst = 0.0
+    for c in range(cases // 10):
+        worst = max(worst, ilqg_case(ddp, oc, rng, c))
+    print("fuzz: %d iLQG solves passed, worst relative error %.3g" % (cases // 10, worst))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cond":
+        conditioning(int(sys.argv[2]), int(sys.argv[3]))
+    else:
+        main()
