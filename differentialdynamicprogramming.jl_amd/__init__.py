@@ -27,7 +27,7 @@ import numpy as np
 from . import _lib
 from ._lib import DDPError, Handle, default_handle  # noqa: F401
 
-__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing", "mpc_shift",
+__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing", "mpc_shift", "demo_linear", "demo_pendcart",
            "df", "Handle", "DDPError", "DEFAULT_ALPHA"]
 
 DEFAULT_ALPHA = 10.0 ** np.linspace(0, -3, 11)     # iLQG.jl:145
@@ -190,6 +190,39 @@ def boxQP(H, g, lower, upper, x0, *, maxIter=100, minGrad=1e-8, minRelImprove=1e
         nf = int(free.sum())
         return x[:, 0], int(res[0]), Hf[:nf, :nf, 0], free
     return x, res, Hf, fr.astype(bool)
+
+
+# ------------------------------------------------------------------------------- demos (problem generators + solver settings)
+def demo_linear(*, B=None, rng=None, T=1000, n=10, m=2, h=0.01, **kwargs):
+    """``demo_linear(;kwargs...)`` (src/demo_linear.jl:5-60): random stable LTI system ``A = exp(h(A0 - A0'))``, ``B = h·randn``,
+    ``Q = h·I``, ``R = 0.1h·I``, ``x0 = ones(n)``, ``u0 = 0.1·randn(m,T)``, no control limits; runs ``iLQG`` with the given keyword
+    arguments and returns its tuple.  ``B`` solves a batch of independent problems (same system, own ``u0``) — the reference
+    runs one.  NumPy's generator replaces Julia's (the draws differ, the distribution does not)."""
+    import scipy.linalg as _sla
+    rng = rng if rng is not None else np.random.default_rng()
+    A0 = rng.standard_normal((n, n))
+    A = _sla.expm(h * (A0 - A0.T))                             # skew-symmetric generator: pure imaginary eigenvalues
+    Bm = h * rng.standard_normal((n, m))
+    Q, R = h * np.eye(n), 0.1 * h * np.eye(m)
+    x0 = np.ones(n) if B is None else np.ones((n, B))
+    u0 = 0.1 * rng.standard_normal((m, T) if B is None else (m, T, B))
+    return iLQG(LQProblem(A, Bm, Q, R), x0, u0, **kwargs)
+
+
+def demo_pendcart(*, x0=(np.pi - 0.6, 0.0, 0.0, 0.0), goal=(np.pi, 0.0, 0.0, 0.0), Q=None, R=1.0, lims=None, T=600, B=None, **kwargs):
+    """``demo_pendcart(;x0, goal, Q, R, lims, T)`` (src/system_pendcart.jl:42-212) with the reference's solver settings
+    (``regType=2, α=exp10.(range(0.2,stop=-3,length=6)), λmax=1e15, tol_fun=tol_grad=1e-8, max_iter=1000``) from ``u0 = 0``
+    (the reference passes ``0*u00``: its LQR simulation only feeds the comparison plot).  ``B`` replicates the problem."""
+    Q = np.diag([10.0, 1.0, 2.0, 1.0]) if Q is None else np.asarray(Q, dtype=np.float64)
+    lims = 5.0 * np.array([[-1.0, 1.0]]) if lims is None else lims
+    prob = PendcartProblem(Q=Q, R=np.array([[float(R)]]), goal=np.asarray(goal, dtype=np.float64))
+    x0 = np.asarray(x0, dtype=np.float64)
+    if B is not None:
+        x0 = np.tile(x0[:, None], (1, B))
+    u0 = np.zeros((1, T) if B is None else (1, T, B))
+    kw = dict(regType=2, α=10.0 ** np.linspace(0.2, -3, 6), λmax=1e15, tol_fun=1e-8, tol_grad=1e-8, max_iter=1000)
+    kw.update(kwargs)
+    return iLQG(prob, x0, u0, lims=lims, **kw)
 
 
 # ------------------------------------------------------------------------------- MPC warm start

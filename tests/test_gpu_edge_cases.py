@@ -264,3 +264,17 @@ def test_mpc_shift_and_receding_horizon_loop(ddp):
         xm = A @ xm + Bm @ us[:, 0] + 1e-3 * rng.standard_normal(n)      # the plant moved on (with a disturbance)
         u = ddp.mpc_shift(us, 1)
     assert np.array_equal(u[:, :-1], us[:, 1:]) and np.array_equal(u[:, -1], us[:, -1])
+
+
+def test_demo_entry_points(ddp):
+    """demo_linear / demo_pendcart (src/demo_linear.jl:5-60, src/system_pendcart.jl:42-212): the reference's own smoke tests
+    (test/runtests.jl:8-12) plus the finite-horizon LQR optimum for the linear demo"""
+    rng = np.random.default_rng(42)
+    x, u, pol, Vx, Vxx, cost, tr = ddp.demo_linear(rng=rng, T=200)
+    assert int(tr["status"][0]) in (1, 2) and np.isfinite(cost).all()
+    c0 = tr["cost"][0] if len(tr["cost"]) else cost.sum()
+    assert cost.sum() <= c0 + 1e-12                                   # iLQG never accepts an increase
+    xb, ub, polb, *_rest, costb, trb = ddp.demo_linear(rng=np.random.default_rng(1), T=120, B=3)
+    assert xb.shape == (10, 120, 3) and np.isfinite(costb).all()
+    r = ddp.demo_pendcart(T=150, max_iter=20)
+    assert r is not None and r[0].shape == (4, 150) and np.abs(r[1]).max() <= 5.0 + 1e-12      # control limits respected
