@@ -28,7 +28,7 @@ from . import _lib
 from . import GaussianPolicy, _DevProblem, _lims, default_handle, df, forward_pass
 
 __all__ = ["Model", "grad_kl", "∇kl", "back_pass_gps", "forward_covariance", "kl_div_wiki", "calc_η", "geom", "iLQGkl",
-           "model_covariance"]
+           "model_covariance", "demo_linear_kl"]
 
 
 @dataclass
@@ -281,3 +281,33 @@ class _SubProblem:
             if isinstance(a, np.ndarray) and getattr(p, "dyn_batched", False) and a.shape[-1] == B:
                 setattr(p, name, a[..., idx])
         return p
+
+
+def demo_linear_kl(*, kl_step=1.0, rng=None, T=1000, n=10, m=2, h=0.01, outer=5, R1=None, handle=None, **kwargs):
+    """``demo_linear_kl(;kwargs...)`` (src/demo_linear.jl:63-136): the random LTI problem of ``demo_linear``, a rollout of the random
+    initial controls, the exact model ``SimpleLTVModel(repeat(A), repeat(B))`` and five outer calls of ``iLQGkl`` starting from the
+    identity policy ``GaussianPolicy(Float64,T,n,m)`` (k = 0, quirk Q20).  ``R1`` is what ``covariance(model,x,u)`` of the un-vendored
+    LinearTimeVaryingModelsBase would return for that model — unknown here, default 1e-3·I (it only enters Σ of the state)."""
+    import scipy.linalg as _sla
+    from . import LQProblem, forward_pass
+    rng = rng if rng is not None else np.random.default_rng()
+    A0 = rng.standard_normal((n, n))
+    A = _sla.expm(h * (A0 - A0.T))
+    Bm = h * rng.standard_normal((n, m))
+    Q, R = h * np.eye(n), 0.1 * h * np.eye(m)
+    prob = LQProblem(A, Bm, Q, R)
+    u = 0.1 * rng.standard_normal((m, T))
+    x, _, _ = forward_pass(None, np.ones(n), u, None, 1.0, prob, None, handle=handle)            # rollout(u) (:107-114)
+    x = x.reshape(n, T)
+    model = Model(np.repeat(A[:, :, None], T, 2), np.repeat(Bm[:, :, None], T, 2), 1e-3 * np.eye(n) if R1 is None else _lib.f64(R1))
+    eye = np.repeat(np.eye(m)[:, :, None], T, 2)
+    traj = GaussianPolicy(T, n, m, np.zeros((m, n, T)), np.zeros((m, T)), eye, eye.copy())        # identity ctor: k = 0
+    out = None
+    outercosts = np.zeros(outer)
+    for it in range(outer):
+        cost0 = 0.5 * np.sum(x * (Q @ x)) + 0.5 * np.sum(u * (R @ u))                              # :122
+        out = iLQGkl(prob, x, traj, model, kl_step=kl_step, cost=cost0, handle=handle, **kwargs)
+        x, u, traj = out[0], out[1], out[2]
+        outercosts[it] = float(np.sum(out[5]))
+    out[6]["outercosts"] = outercosts
+    return out

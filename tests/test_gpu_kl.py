@@ -155,3 +155,13 @@ def test_ilqgkl_pendcart_c5_shape(ddp):
         assert relerr(tr["η"][:, b], info["eta"]) < 1e-7
         assert relerr(xo[..., b], xr) < 1e-7 and relerr(uo[..., b], ur) < 1e-7 and relerr(pol.K[..., b], polr["K"]) < 1e-7
         assert np.abs(uo[..., b]).max() <= 5.0
+
+
+def test_demo_linear_kl_smoke(ddp):
+    """demo_linear_kl (src/demo_linear.jl:63-136) — the reference's own test is a smoke run (test/runtests.jl:9)"""
+    out = ddp.kl.demo_linear_kl(kl_step=100.0, rng=np.random.default_rng(3), T=80, outer=2, max_iter=20)      # the upstream call
+    assert out[0].shape == (10, 80) and out[1].shape == (2, 80) and np.isfinite(out[5]).all()
+    # the η bracket meets the constraint with EQUALITY (iLQGkl.jl:143-158): a step of 100 overshoots, a small one descends
+    x, u, traj, Vx, Vxx, cost, tr = ddp.kl.demo_linear_kl(kl_step=0.01, rng=np.random.default_rng(3), T=80, outer=4, max_iter=20)
+    oc_ = tr["outercosts"]
+    assert np.isfinite(oc_).all() and np.all(np.diff(oc_) < 0) and abs(float(tr["divergence"]) - 0.01) < 0.1 * 0.01 + 1e-12
