@@ -133,24 +133,33 @@ __device__ __forceinline__ double sum_halves(double v)      // v(lane) + v(lane 
 
 struct FB64Buf { d2 ab[36], kr[4], xo, uo, ko; };
 
-template <bool POL>
+// NA line-search candidates (step sizes α) of ONE trajectory share a wave: A_i, B_i, K_i, x_i, u_i, k_i are the same for all of
+// them, so the 41 KB per step are fetched once per NA rollouts (the full line search of an iLQG iteration evaluates 4-11 α).
+template <bool POL, int NA>
 __global__ __launch_bounds__(DDP_WAVE) void forward_big64_kernel(FBArgs a)
 {
     constexpr int n = 64, m = 8, NC = 36;
     const int N = a.N, B = a.B;
-    const long rho = blockIdx.x;
-    const int b = (int)(rho % B), ai = (int)(rho / B);
+    const int b = blockIdx.x, a0 = NA * blockIdx.y;              // candidates a0 .. a0+NA-1 (those >= nalpha compute, never store)
     if (a.active && a.active[b] == 0) return;
     const int lane = threadIdx.x, h = lane >> 5, r0 = 2 * (lane & 31), q0 = 2 * (lane & 3);
-    const double alpha = a.alpha[ai];
-    __shared__ __attribute__((aligned(16))) double zs[n + m], dxs[n];
+    double alpha[NA];
+    bool live[NA];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) { live[c] = a0 + c < a.nalpha; alpha[c] = a.alpha[live[c] ? a0 + c : a0]; }
+    __shared__ __attribute__((aligned(16))) double zs[NA][n + m], dxs[NA][n];
     constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m;
     const double *ug = a.u + (size_t)m * N * b;
     const double *xg = POL ? a.x + (size_t)n * N * b : nullptr;
     const double *Kg = POL ? a.K + nm * N * b : nullptr;
     const double *kg = POL ? a.k + (size_t)m * N * b : nullptr;
-    double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai);
-    double *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
+    double *xo[NA], *uo[NA];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) {
+        const size_t rho = (size_t)b + (size_t)B * (live[c] ? a0 + c : a0);
+        xo[c] = a.xnew + (size_t)n * N * rho;
+        uo[c] = a.unew + (size_t)m * N * rho;
+    }
     const double *Ab = a.A + (a.dyn_batched ? nn * (a.dyn_tv ? N : 1) * b : 0);
     const double *Bb = a.Bm + (a.dyn_batched ? nm * (a.dyn_tv ? N : 1) * b : 0);
     const bool tv = a.dyn_tv, lims = a.has_lims;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_big64_kernel(FBArgs a)
     auto fetch = [&](int i, FB64Buf &f) {
         const double *Ai = Ab + (tv ? nn * i : 0), *Bi = Bb + (tv ? nm * i : 0);
         const double *pa = Ai + n * NC * h + r0;                      // column 36h of A, my row pair
-        const double *pb = h ? Bi + r0 - n * (n - NC) : Ai + r0;   // t >= 28: half 1 continues in B (column 36+t-64), half 0 in A (column t)
+        const double *pb = h ? Bi + r0 - n * (n - NC) : Ai + r0;      // t >= 28: half 1 continues in B (column 36+t-64), half 0 in A (column t)
 #pragma unroll
         for (int t = 0; t < NC; ++t) f.ab[t] = *(const d2 *)((t < n - NC ? pa : pb) + n * t);
         if (POL) {
@@ -171,50 +180,81 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_big64_kernel(FBArgs a)
         }
         f.uo = *(const d2 *)(ug + (size_t)m * i + q0);
     };
-    double xa = a.x0[(size_t)n * b + r0], xb = a.x0[(size_t)n * b + r0 + 1];
+    double xa[NA], xb[NA];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) { xa[c] = a.x0[(size_t)n * b + r0]; xb[c] = a.x0[(size_t)n * b + r0 + 1]; }
     auto step = [&](int i, const FB64Buf &f) {
-        const d2 xh = d2{xa, xb};
-        if (h == 0) {
-            *(d2 *)(zs + r0) = xh;
-            if (POL) *(d2 *)(dxs + r0) = xh - f.xo;
-            *(d2 *)(xo + (size_t)n * i + r0) = xh;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            const d2 xh = d2{xa[c], xb[c]};
+            if (h == 0) {
+                *(d2 *)(zs[c] + r0) = xh;
+                if (POL) *(d2 *)(dxs[c] + r0) = xh - f.xo;
+                if (live[c]) *(d2 *)(xo[c] + (size_t)n * i + r0) = xh;
+            }
         }
         wave_sync();
         // x part of A x̂ + B u: columns [0,28) of my half are state columns for both halves
-        double sa0 = 0.0, sa1 = 0.0, sb0 = 0.0, sb1 = 0.0;
-        const double *zp = zs + NC * h;
+        double sa0[NA], sa1[NA], sb0[NA], sb1[NA];
+#pragma unroll
+        for (int c = 0; c < NA; ++c) { sa0[c] = 0.0; sa1[c] = 0.0; sb0[c] = 0.0; sb1[c] = 0.0; }
         if (i < N - 1) {
 #pragma unroll
             for (int t = 0; t < n - NC; t += 2) {
-                const d2 z = *(const d2 *)(zp + t);
-                sa0 += f.ab[t].x * z.x; sb0 += f.ab[t].y * z.x;
-                sa1 += f.ab[t + 1].x * z.y; sb1 += f.ab[t + 1].y * z.y;
+#pragma unroll
+                for (int c = 0; c < NA; ++c) {
+                    const d2 z = *(const d2 *)(zs[c] + NC * h + t);
+                    sa0[c] += f.ab[t].x * z.x; sb0[c] += f.ab[t].y * z.x;
+                    sa1[c] += f.ab[t + 1].x * z.y; sb1[c] += f.ab[t + 1].y * z.y;
+                }
             }
         }
         // controls (forward_pass.jl:17-24): gain rows q0, q0+1, state columns (lane>>2) + 16t
-        double v0 = f.uo.x, v1 = f.uo.y;
+        double v0[NA], v1[NA];
+#pragma unroll
+        for (int c = 0; c < NA; ++c) { v0[c] = f.uo.x; v1[c] = f.uo.y; }
         if (POL) {
-            double p0 = 0.0, p1 = 0.0;
+            double p0[NA], p1[NA];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { const double d = dxs[(lane >> 2) + 16 * t]; p0 += f.kr[t].x * d; p1 += f.kr[t].y * d; }
+            for (int c = 0; c < NA; ++c) {
+                p0[c] = 0.0; p1[c] = 0.0;
 #pragma unroll
-            for (int off = 4; off < DDP_WAVE; off <<= 1) { p0 += __shfl_xor(p0, off, DDP_WAVE); p1 += __shfl_xor(p1, off, DDP_WAVE); }
-            v0 += f.ko.x * alpha; v1 += f.ko.y * alpha;              // unew .+= k*α
-            v0 += p0; v1 += p1;                                      // unew .+= K*dx
+                for (int t = 0; t < 4; ++t) { const double d = dxs[c][(lane >> 2) + 16 * t]; p0[c] += f.kr[t].x * d; p1[c] += f.kr[t].y * d; }
+            }
+#pragma unroll
+            for (int off = 4; off < DDP_WAVE; off <<= 1) {
+#pragma unroll
+                for (int c = 0; c < NA; ++c) { p0[c] += __shfl_xor(p0[c], off, DDP_WAVE); p1[c] += __shfl_xor(p1[c], off, DDP_WAVE); }
+            }
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                v0[c] += f.ko.x * alpha[c]; v1[c] += f.ko.y * alpha[c];   // unew .+= k*α
+                v0[c] += p0[c]; v1[c] += p1[c];                           // unew .+= K*dx
+            }
         }
-        if (lims) { v0 = clampd(v0, lo0, hi0); v1 = clampd(v1, lo1, hi1); }
-        if (v0 != v0) v0 = 0.0;                                      // u[isnan.(u)] .= 0 inside f
-        if (v1 != v1) v1 = 0.0;
-        if (lane < 4) { *(d2 *)(zs + n + q0) = d2{v0, v1}; *(d2 *)(uo + (size_t)m * i + q0) = d2{v0, v1}; }
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            if (lims) { v0[c] = clampd(v0[c], lo0, hi0); v1[c] = clampd(v1[c], lo1, hi1); }
+            if (v0[c] != v0[c]) v0[c] = 0.0;                              // u[isnan.(u)] .= 0 inside f
+            if (v1[c] != v1[c]) v1[c] = 0.0;
+            if (lane < 4) {
+                *(d2 *)(zs[c] + n + q0) = d2{v0[c], v1[c]};
+                if (live[c]) *(d2 *)(uo[c] + (size_t)m * i + q0) = d2{v0[c], v1[c]};
+            }
+        }
         wave_sync();
         if (i < N - 1) {                                             // the last 8 columns of each half: x̂[28..36) | u
 #pragma unroll
             for (int t = n - NC; t < NC; t += 2) {
-                const d2 z = *(const d2 *)(zp + t);
-                sa0 += f.ab[t].x * z.x; sb0 += f.ab[t].y * z.x;
-                sa1 += f.ab[t + 1].x * z.y; sb1 += f.ab[t + 1].y * z.y;
+#pragma unroll
+                for (int c = 0; c < NA; ++c) {
+                    const d2 z = *(const d2 *)(zs[c] + NC * h + t);
+                    sa0[c] += f.ab[t].x * z.x; sb0[c] += f.ab[t].y * z.x;
+                    sa1[c] += f.ab[t + 1].x * z.y; sb1[c] += f.ab[t + 1].y * z.y;
+                }
             }
-            xa = sum_halves(sa0 + sa1); xb = sum_halves(sb0 + sb1);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) { xa[c] = sum_halves(sa0[c] + sa1[c]); xb[c] = sum_halves(sb0[c] + sb1[c]); }
         }
         wave_sync();
     };
@@ -306,8 +346,16 @@ int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, 
     const dim3 grid((unsigned)((long)p->B * nalpha)), block(DDP_WAVE);
     const char *env = getenv("DDP_FORWARD64");                       // DDP_FORWARD64=0: run-time-sized kernels also at n = 64, m = 8
     if (p->n == 64 && p->m == 8 && !(env && env[0] == '0')) {
-        if (a.has_policy) hipLaunchKernelGGL(forward_big64_kernel<true>, grid, block, 0, h->stream, a);
-        else hipLaunchKernelGGL(forward_big64_kernel<false>, grid, block, 0, h->stream, a);
+        // up to 4 step sizes of a trajectory per wave (operands fetched once); a single α keeps the one-rollout instantiation
+        const int na = nalpha >= 3 ? 4 : (nalpha == 2 ? 2 : 1);
+        const dim3 g64((unsigned)p->B, (unsigned)((nalpha + na - 1) / na));
+        if (a.has_policy) {
+            if (na == 4) hipLaunchKernelGGL((forward_big64_kernel<true, 4>), g64, block, 0, h->stream, a);
+            else if (na == 2) hipLaunchKernelGGL((forward_big64_kernel<true, 2>), g64, block, 0, h->stream, a);
+            else hipLaunchKernelGGL((forward_big64_kernel<true, 1>), g64, block, 0, h->stream, a);
+        } else {
+            hipLaunchKernelGGL((forward_big64_kernel<false, 1>), dim3((unsigned)p->B, (unsigned)nalpha), block, 0, h->stream, a);
+        }
         hipLaunchKernelGGL(cost_big64_kernel, dim3(grid.x, (unsigned)((p->N + 15) / 16)), block, 0, h->stream, a);
         hipLaunchKernelGGL(cost_sum_kernel, grid, block, 0, h->stream, a);
         DDP_HIP(hipGetLastError());

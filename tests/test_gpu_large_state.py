@@ -79,8 +79,9 @@ def test_back_pass_large_divergence(ddp):
 
 
 @pytest.mark.parametrize("fwd64", ["1", "0"])      # the n=64/m=8 streaming kernel, and the run-time-sized one on the same shape
+@pytest.mark.parametrize("nalpha", [1, 2, 5])       # 1 / 2 / 4 step sizes per wave (5 = one full group + a group with dead slots)
 @pytest.mark.parametrize("lims", [False, True])
-def test_forward_pass_large(ddp, monkeypatch, lims, fwd64):
+def test_forward_pass_large(ddp, monkeypatch, lims, fwd64, nalpha):
     from oracle import oracle_ctypes as oc
     monkeypatch.setenv("DDP_FORWARD64", fwd64)
     rng = np.random.default_rng(8)
@@ -93,7 +94,7 @@ def test_forward_pass_large(ddp, monkeypatch, lims, fwd64):
     L = np.stack([-0.3 * np.ones(m), 0.35 * np.ones(m)], 1) if lims else None
     prob = ddp.LQProblem(fx, fu, Q, R, dyn_batched=True)
     pol = ddp.GaussianPolicy(N, n, m, K, k)
-    alphas = np.array([1.0, 0.4])
+    alphas = np.array([1.0, 0.4, 0.1, 0.03, 0.55])[:nalpha]
     xn, un, cn = ddp.forward_pass(pol, x0, u, x, alphas, prob, L)
     for b in range(B):
         p = oc.make_problem("lq", n, m, N, A=fx[..., b], B=fu[..., b], Q=Q, R=R)
