@@ -389,7 +389,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
         }
 
         // ================= P3: gains (backward_pass.jl:30-62) =====================================
-        double H[MM * MM], R[MM * MM], kk[MM];
+        double H[MM * MM], R[MM * MM], kk[MM], ri[MM];
         unsigned clamped = 0u;
 #pragma unroll
         for (int c2 = 0; c2 < MM; ++c2)
@@ -397,10 +397,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
             for (int r2 = 0; r2 < MM; ++r2) H[r2 + MM * c2] = (r2 < m && c2 < m) ? QuuFs[r2 + m * c2] : 0.0;
         int fail;
         if (!LIMS || nolims) {
-            fail = chol_masked<MM>(m, H, 0u, R);                 // cholesky(Hermitian(QuuF)), :35
+            fail = chol_masked_ri<MM>(m, H, 0u, R, ri);                // cholesky(Hermitian(QuuF)), :35
 #pragma unroll
             for (int q = 0; q < MM; ++q) kk[q] = (q < m) ? Qs[n + q] : 0.0;
-            chol_solve<MM>(m, R, kk);
+            chol_solve_ri<MM>(m, R, ri, kk);
 #pragma unroll
             for (int q = 0; q < MM; ++q) kk[q] = -kk[q];         // k_i = -(R\Qu), :41
         } else {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
                 x0[q] = (q < m) ? ks[q] : 0.0;                   // k[:,min(i+1,N-1)], :49 (Q9)
             }
             int iters;
-            const int result = boxqp_dev<MM>(m, H, g, lo, up, x0, qpo, kk, R, clamped, iters);
+            const int result = boxqp_dev_ri<MM>(m, H, g, lo, up, x0, qpo, kk, R, ri, clamped, iters);
             fail = (result < 1);                                 // :53
         }
         if (fail) {                                              // wave-uniform: diverge = i (:37-38,54-55)
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_kernel(BPArgs a)
             double col[MM];
 #pragma unroll
             for (int q = 0; q < MM; ++q) col[q] = (q < m && !((clamped >> q) & 1u)) ? Quxrs[q + m * lane] : 0.0;
-            chol_solve<MM>(m, R, col);                           // :42 / :59
+            chol_solve<MM>(m, R, col);                           // :42 / :59  (IEEE divisions: with the reciprocal-pivot solve the
+                                                                 //  GPS + limits instantiation, 550 spilled VGPRs, faults on gfx950)
 #pragma unroll
             for (int q = 0; q < MM; ++q) col[q] = ((clamped >> q) & 1u) ? 0.0 : -col[q];
 #pragma unroll

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NT) void back_pass_big_kernel(BPBArgs a)
         __syncthreads();
 
         // ================= P3: gains (backward_pass.jl:30-62) =================================================
-        double H[MMAX * MMAX], R[MMAX * MMAX], kk[MMAX];
+        double H[MMAX * MMAX], R[MMAX * MMAX], kk[MMAX], ri[MMAX];
         unsigned clamped = 0u;
 #pragma unroll
         for (int c2 = 0; c2 < MMAX; ++c2)
@@ -220,10 +220,10 @@ __global__ __launch_bounds__(NT) void back_pass_big_kernel(BPBArgs a)
             for (int r2 = 0; r2 < MMAX; ++r2) H[r2 + MMAX * c2] = (r2 < m && c2 < m) ? QuuFs[r2 + m * c2] : 0.0;
         int fail;
         if (!LIMS || nolims) {
-            fail = chol_masked<MMAX>(m, H, 0u, R);
+            fail = chol_masked_ri<MMAX>(m, H, 0u, R, ri);
 #pragma unroll
             for (int q = 0; q < MMAX; ++q) kk[q] = (q < m) ? Qs[n + q] : 0.0;
-            chol_solve<MMAX>(m, R, kk);
+            chol_solve_ri<MMAX>(m, R, ri, kk);
 #pragma unroll
             for (int q = 0; q < MMAX; ++q) kk[q] = -kk[q];
         } else {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NT) void back_pass_big_kernel(BPBArgs a)
                 x0[q] = (q < m) ? ks[q] : 0.0;
             }
             int iters;
-            const int result = boxqp_dev<MMAX>(m, H, g, lo, up, x0, qpo, kk, R, clamped, iters);
+            const int result = boxqp_dev_ri<MMAX>(m, H, g, lo, up, x0, qpo, kk, R, ri, clamped, iters);
             fail = (result < 1);
         }
         if (fail) {                                              // block-uniform: diverge = i
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NT) void back_pass_big_kernel(BPBArgs a)
             double col[MMAX];
 #pragma unroll
             for (int q = 0; q < MMAX; ++q) col[q] = (q < m && !((clamped >> q) & 1u)) ? Xrs[q + m * tid] : 0.0;
-            chol_solve<MMAX>(m, R, col);
+            chol_solve_ri<MMAX>(m, R, ri, col);
 #pragma unroll
             for (int q = 0; q < MMAX; ++q) col[q] = ((clamped >> q) & 1u) ? 0.0 : -col[q];
 #pragma unroll

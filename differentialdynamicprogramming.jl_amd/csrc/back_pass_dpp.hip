@@ -308,10 +308,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
                 rsolve(kk);                                              // k_i = -(R\Qu)        (:41)
                 rsolve(Kc);                                              // K_i[:, j] = -(R\Qux_reg[:, j])  (:42)
             } else if (nolims) {
-                fail = chol_masked<m>(m, H, 0u, R);                      // cholesky(Hermitian(QuuF))  (:35)
+                fail = chol_masked_ri<m>(m, H, 0u, R, ri);                   // cholesky(Hermitian(QuuF))  (:35)
 #pragma unroll
                 for (int q = 0; q < m; ++q) kk[q] = Qu[q];
-                chol_solve<m>(m, R, kk);
+                chol_solve_ri<m>(m, R, ri, kk);
 #pragma unroll
                 for (int q = 0; q < m; ++q) kk[q] = -kk[q];              // k_i = -(R\Qu)  (:41)
             } else {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
                     result = boxqp_dev1(H[0], Qu[0], lo[0], up[0], kprev[0], qpo, kk[0], rH1, clamped, iters);
                     use_rh = true;
                 } else {
-                    result = boxqp_dev<m>(m, H, Qu, lo, up, kprev, qpo, kk, R, clamped, iters);         // (:49)
+                    result = boxqp_dev_ri<m>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);        // (:49)
                 }
                 fail = (result < 1);                                     // (:53)
             }
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
                 } else {
 #pragma unroll
                     for (int q = 0; q < m; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : gr[q];
-                    chol_solve<m>(m, R, Kc);
+                    chol_solve_ri<m>(m, R, ri, Kc);
 #pragma unroll
                     for (int q = 0; q < m; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : -Kc[q];
                 }
@@ -390,12 +390,19 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
             // ---- symmetric Vxx output of the PREVIOUS step from its transpose buffer, then queue this step
             double *tb0 = &tr[grp][i & 1][0], *tb1 = &tr[grp][(i + 1) & 1][0];
             if (have_prev && act) store_sym(tb1, prev_i);
+            double vnew[n];
 #pragma unroll
             for (int r = 0; r < n; ++r) {
-                const double vnew = (g[r] + 0.5 * (P1a[r] + P2a[r]));   // Qxx + ½(S+S')
-                Vcol[r] = vnew;
-                if (inx) tb0[j * LD + r] = vnew;
+                vnew[r] = (g[r] + 0.5 * (P1a[r] + P2a[r]));             // Qxx + ½(S+S')
+                if (inx) tb0[j * LD + r] = vnew[r];
             }
+            // The recursion continues with the SYMMETRISED value like the reference (:71-72), read back as row j of the buffer.
+            // Carrying the column as computed looks harmless (it is symmetric up to rounding) but the antisymmetric rounding
+            // residue then obeys δ_i = F_cl'·δ_{i+1}·F_cl and grows geometrically for non-contractive dynamics: 5e-8 after 210
+            // steps of ρ(A) ≈ 1.1 in the randomised sweep (tests/fuzz_gpu_parity.py), unbounded for longer horizons.
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < n; ++r) Vcol[r] = 0.5 * (vnew[r] + tb0[r * LD + jx]);
             vj = vx;
             have_prev = true; prev_i = i;
 #pragma unroll

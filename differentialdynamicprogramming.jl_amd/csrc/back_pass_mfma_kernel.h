@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                     g[q] = Qs[n + q]; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; x0[q] = ks[q];
                 }
                 int iters;
-                const int result = boxqp_dev<m>(m, H, g, lo, up, x0, qpo, kk, R, clamped, iters);
+                const int result = boxqp_dev_ri<m>(m, H, g, lo, up, x0, qpo, kk, R, ri, clamped, iters);
                 fail = (result < 1);
             }
             MFP(13);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 const double quu_l = Quus[lane];
                 if (use_ri) ddp_rsolve_neg<m>(R, ri, col);           // K_i column `lane`
                 else {
-                    chol_solve<m>(m, R, col);
+                    chol_solve_ri<m>(m, R, ri, col);
 #pragma unroll
                     for (int q = 0; q < m; ++q) col[q] = ((clamped >> q) & 1u) ? 0.0 : -col[q];
                 }

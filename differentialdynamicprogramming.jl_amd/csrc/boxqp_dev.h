@@ -10,6 +10,7 @@
 // loop bound static, and therefore keeps H, R and the vectors in registers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "ddp_internal.h"   // ddp_rsqrt
 
 struct QPOptsDev {
     int    maxIter;
@@ -51,6 +52,66 @@ __device__ __forceinline__ int chol_masked(int m, const double (&H)[MM * MM], un
         }
     }
     return fail;
+}
+
+// The same factorisation with RECIPROCAL pivots ri[j] = 1/R[j][j] (v_rsq_f64 + Newton steps): no square root and no division.
+// Every lane of a wave repeats these solves, and an IEEE fp64 division is ~20 instructions: with limits at m = 8 the
+// divisions of the generic routines were most of a backward step.  R keeps the true factor (diagonal = ajj·ri).
+template <int MM>
+__device__ __forceinline__ int chol_masked_ri(int m, const double (&H)[MM * MM], unsigned clamped,
+                                              double (&R)[MM * MM], double (&ri)[MM])
+{
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        if (j < m) {
+            const bool cj = (clamped >> j) & 1u;
+            double ajj = cj ? 1.0 : H[j + MM * j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) ajj -= R[k + MM * j] * R[k + MM * j];
+            if (!(ajj > 0.0) && fail == 0) fail = j + 1;
+            const double r = ddp_rsqrt(ajj);
+            ri[j] = r;
+            R[j + MM * j] = ajj * r;
+#pragma unroll
+            for (int i = j + 1; i < MM; ++i) {
+                if (i < m) {
+                    const bool ci = (clamped >> i) & 1u;
+                    double s = (cj || ci) ? 0.0 : H[j + MM * i];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) s -= R[k + MM * j] * R[k + MM * i];
+                    R[j + MM * i] = s * r;
+                }
+            }
+        } else {
+            ri[j] = 0.0;
+        }
+    }
+    return fail;
+}
+
+template <int MM>
+__device__ __forceinline__ void chol_solve_ri(int m, const double (&R)[MM * MM], const double (&ri)[MM], double (&b)[MM])
+{
+#pragma unroll
+    for (int i = 0; i < MM; ++i) {
+        if (i < m) {
+            double s = b[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= R[k + MM * i] * b[k];
+            b[i] = s * ri[i];
+        }
+    }
+#pragma unroll
+    for (int i = MM - 1; i >= 0; --i) {
+        if (i < m) {
+            double s = b[i];
+#pragma unroll
+            for (int k = i + 1; k < MM; ++k)
+                if (k < m) s -= R[i + MM * k] * b[k];
+            b[i] = s * ri[i];
+        }
+    }
 }
 
 // solve (R'R) b = b in place (potrs)
@@ -103,12 +164,13 @@ __device__ __forceinline__ double qp_value(int m, const double (&H)[MM * MM], co
 // backward_pass.jl:48-52).  On return x is the solution, `clamped` the bit mask of clamped
 // coordinates belonging to the returned factor R (quirk Q12: on result 4 both are from the
 // previous iteration), `iters` the final value of `iter`.
+// `ri`: reciprocal pivots of the returned factor (chol_solve_ri); zeros if nothing was factorised.
 template <int MM>
-__device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], const double (&g)[MM],
-                                         const double (&lower)[MM], const double (&upper)[MM],
-                                         const double (&x0)[MM], const QPOptsDev &o,
-                                         double (&x)[MM], double (&R)[MM * MM], unsigned &clamped,
-                                         int &iters)
+__device__ __forceinline__ int boxqp_dev_ri(int m, const double (&H)[MM * MM], const double (&g)[MM],
+                                            const double (&lower)[MM], const double (&upper)[MM],
+                                            const double (&x0)[MM], const QPOptsDev &o,
+                                            double (&x)[MM], double (&R)[MM * MM], double (&ri)[MM], unsigned &clamped,
+                                            int &iters)
 {
     const unsigned all = (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
     double grad[MM], search[MM], xc[MM];
@@ -117,6 +179,8 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
     clamped = 0u;
 #pragma unroll
     for (int i = 0; i < MM * MM; ++i) R[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < MM; ++i) ri[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < MM; ++i) x[i] = (i < m) ? ddp_clamp(x0[i], lower[i], upper[i]) : 0.0;   // :58
     value = qp_value<MM>(m, H, g, x);                                                          // :63
@@ -144,13 +208,13 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
         clamped = newc;
         if (clamped == all) { result = 6; break; }                                             // :98-101
         if (iter == 1 || oldc != clamped) {                                                    // :104-117
-            if (chol_masked<MM>(m, H, clamped, R) != 0) { result = 0; break; }                 // throw -> 0
+            if (chol_masked_ri<MM>(m, H, clamped, R, ri) != 0) { result = 0; break; }          // throw -> 0
         }
         double gn = 0.0;                                                                       // :120-124
 #pragma unroll
         for (int i = 0; i < MM; ++i)
             if (i < m && !((clamped >> i) & 1u)) gn += grad[i] * grad[i];
-        if (sqrt(gn) < o.minGrad) { result = 5; break; }
+        if (gn < o.minGrad * o.minGrad) { result = 5; break; }                                 // norm(grad[free]) < minGrad
 #pragma unroll
         for (int i = 0; i < MM; ++i) {                                                         // :127-129
             if (i < m) {
@@ -163,7 +227,7 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
                 search[i] = 0.0;
             }
         }
-        chol_solve<MM>(m, R, search);
+        chol_solve_ri<MM>(m, R, ri, search);
         double sdotg = 0.0;
 #pragma unroll
         for (int i = 0; i < MM; ++i) {
@@ -177,7 +241,7 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
 #pragma unroll
         for (int i = 0; i < MM; ++i) xc[i] = (i < m) ? ddp_clamp(x[i] + step * search[i], lower[i], upper[i]) : 0.0;
         vc = qp_value<MM>(m, H, g, xc);
-        while ((vc - oldvalue) / (step * sdotg) < o.Armijo) {
+        while ((vc - oldvalue) > o.Armijo * (step * sdotg)) {                                  // ratio < Armijo, step·sdotg < 0
             step = step * o.stepDec;
 #pragma unroll
             for (int i = 0; i < MM; ++i) xc[i] = (i < m) ? ddp_clamp(x[i] + step * search[i], lower[i], upper[i]) : 0.0;
@@ -192,6 +256,17 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
     if (iter == o.maxIter) result = 1;                                                         // :167-169
     iters = iter;
     return result;
+}
+
+template <int MM>
+__device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], const double (&g)[MM],
+                                         const double (&lower)[MM], const double (&upper)[MM],
+                                         const double (&x0)[MM], const QPOptsDev &o,
+                                         double (&x)[MM], double (&R)[MM * MM], unsigned &clamped,
+                                         int &iters)
+{
+    double ri[MM];
+    return boxqp_dev_ri<MM>(m, H, g, lower, upper, x0, o, x, R, ri, clamped, iters);
 }
 
 // m = 1 (the reference's own limited case, pendcart): the same control flow as boxqp_dev<1> written on scalars and

@@ -122,7 +122,9 @@ def c4(B=1024):
     prob.dyn_tv, prob.dyn_batched = 1, 1
     x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
     u0 = 0.1 * rng.standard_normal((m, N, B))
-    run("C4 large-state LTV", prob, n, m, N, B, f64(x0), f64(u0), None, 1, (dA, dB, 1, 1), steps=5, warmup=1)
+    c4lims = os.environ.get("DDP_C4_LIMS")                      # e.g. DDP_C4_LIMS=0.05: control limits ±0.05 (boxQP path)
+    lims = None if not c4lims else float(c4lims) * np.stack([-np.ones(m), np.ones(m)], 1)
+    run("C4 large-state LTV" + (" lims" if c4lims else ""), prob, n, m, N, B, f64(x0), f64(u0), lims, 1, (dA, dB, 1, 1), steps=5, warmup=1)
     if os.environ.get("DDP_C4_SOLVE", "1") == "1":
         solve("C4 full iLQG solves (device-resident driver)", prob, n, m, N, B, f64(x0), f64(u0), nalpha=4)
 

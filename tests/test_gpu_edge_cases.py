@@ -278,3 +278,29 @@ def test_demo_entry_points(ddp):
     assert xb.shape == (10, 120, 3) and np.isfinite(costb).all()
     r = ddp.demo_pendcart(T=150, max_iter=20)
     assert r is not None and r[0].shape == (4, 150) and np.abs(r[1]).max() <= 5.0 + 1e-12      # control limits respected
+
+
+@pytest.mark.parametrize("impl", ["auto", "dpp", "general"])
+@pytest.mark.parametrize("n,m", [(4, 1), (10, 2)])
+def test_long_unstable_horizon_error_does_not_grow(ddp, monkeypatch, impl, n, m):
+    """The value recursion must carry the SYMMETRISED Vxx (backward_pass.jl:71-72): with the column as computed the antisymmetric
+    rounding residue grows like ρ(A)^(2·steps) — the row-per-trajectory kernel was at 5e-8 after 210 steps of this problem
+    (found by tests/fuzz_gpu_parity.py); every kernel stays at the 1e-12 level now."""
+    from oracle import oracle_ctypes as oc
+    if impl != "auto":
+        monkeypatch.setenv("DDP_BACKPASS", impl)
+    rng = np.random.default_rng(333)
+    N, B, h = 240, 6, 0.05
+    fx = np.eye(n) + h * rng.standard_normal((n, n)) / np.sqrt(n)             # spectral radius > 1
+    fu = h * rng.standard_normal((n, m))
+    a = rng.standard_normal((n, n)); cxx = h * (a @ a.T / n + 0.5 * np.eye(n))
+    a = rng.standard_normal((m, m)); cuu = 0.1 * h * (a @ a.T / m + 0.5 * np.eye(m))
+    cxu = 0.01 * h * rng.standard_normal((n, m))
+    cx = h * rng.standard_normal((n, N, B)); cu = 0.1 * h * rng.standard_normal((m, N, B))
+    lam = 10.0 ** rng.uniform(-3, 0, B)
+    for regType in (1, 2):
+        div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, None, None, np.zeros((m, N, B)))
+        for b in range(B):
+            d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], cxx, cxu, cuu, fx, fu, lam[b], regType, None, None, np.zeros((m, N)))
+            assert div[b] == d == 0
+            assert relerr(pol.K[..., b], K) < 1e-10 and relerr(Vxx[..., b], vxx) < 1e-10 and relerr(Vx[..., b], vx) < 1e-10
