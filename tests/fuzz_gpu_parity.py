@@ -22,7 +22,7 @@ def spd(rng, d, s):
 def gen_case(rng):
     n, m = [(10, 2), (4, 1), (6, 3), (64, 8), (7, 2), (12, 4), (40, 4)][rng.integers(0, 7)]
     big = rng.integers(0, 6) == 0                                 # now and then a long horizon / several waves
-    N = (int(rng.integers(1, 300 if big else 40))) if n < 40 else int(rng.integers(2, 14))
+    N = (int(rng.integers(1, 300 if big else 40))) if n < 40 else int(rng.integers(2, 50 if big else 14))
     B = int(rng.integers(1, 70 if (big and n < 40) else 6))
     fx_tv, fx_b = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     c_tv = bool(rng.integers(0, 2))
@@ -49,7 +49,8 @@ def gen_case(rng):
         cuu[:, :, int(rng.integers(0, N - 1)), int(rng.integers(0, B))] = -np.eye(m)
     Q, R = spd(rng, n, h), spd(rng, m, 0.1 * h)
     x0 = rng.standard_normal((n, B)); xnom = rng.standard_normal((n, N, B))
-    return dict(n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, c_tv=c_tv, regType=regType, lims=lims, fx=fx, fu=fu, cxx=cxx, cuu=cuu, cxu=cxu,
+    impl = [None, None, None, "x", "fast", "dpp", "general", "big"][rng.integers(0, 8)]     # forced kernel (falls back when it has no such shape)
+    return dict(impl=impl, n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, c_tv=c_tv, regType=regType, lims=lims, fx=fx, fu=fu, cxx=cxx, cuu=cuu, cxu=cxu,
                 cx=cx, cu=cu, u=u, lam=lam, Q=Q, R=R, x0=x0, xnom=xnom)
 
 
@@ -64,8 +65,12 @@ def ref_back_pass(bp, c, b):
 def one_case(ddp, oc, rng, case):
     c = gen_case(rng)
     n, m, N, B, lims = c["n"], c["m"], c["N"], c["B"], c["lims"]
-    tag = (case, {k: c[k] for k in ("n", "m", "N", "B", "fx_tv", "fx_b", "c_tv", "regType")}, "lims" if lims is not None else "no lims")
+    tag = (case, {k: c[k] for k in ("n", "m", "N", "B", "fx_tv", "fx_b", "c_tv", "regType", "impl")}, "lims" if lims is not None else "no lims")
+    os.environ.pop("DDP_BACKPASS", None)
+    if c["impl"]:
+        os.environ["DDP_BACKPASS"] = c["impl"]
     div, pol, Vx, Vxx, dV = ddp.back_pass(c["cx"], c["cu"], c["cxx"], c["cxu"], c["cuu"], c["fx"], c["fu"], c["lam"], c["regType"], lims, None, c["u"])
+    os.environ.pop("DDP_BACKPASS", None)
     worst = 0.0
     for b in range(B):
         d, (K, k, Quu), vx, vxx, dv = ref_back_pass(oc.back_pass, c, b)
@@ -137,6 +142,41 @@ def ilqg_case(ddp, oc, rng, case):
     return worst
 
 
+def pendcart_case(ddp, oc, rng, case):
+    """the pendcart family (C3 path): rollout with limits, df (5x5 expm, all Padé orders via random h), limited back_pass"""
+    N, B = int(rng.integers(3, 120)), int(rng.integers(1, 9))
+    hstep = float(10.0 ** rng.uniform(-3, -1.3))                    # the reference uses 0.01; much larger Euler steps make the
+                                                                    # rollout itself chaotic (sin/cos of huge angles) and nothing is comparable
+    prob = ddp.PendcartProblem(h=hstep, Q=np.diag(rng.uniform(0.5, 10.0, 4)), R=np.array([[float(rng.uniform(0.1, 2.0))]]))
+    lims = np.array([[-1.0, 1.0]]) * float(rng.uniform(0.5, 6.0))
+    x0 = np.array([np.pi, 0, 0, 0])[:, None] + rng.uniform(-1.0, 1.0, (4, B))
+    u = rng.uniform(-3.0, 3.0, (1, N, B))
+    pend = dict(g=prob.g, l=prob.l, h=prob.h, d=prob.d, goal=prob.goal)
+    p = oc.make_problem("pendcart", 4, 1, N, Q=prob.Q, R=prob.R, pend=pend)
+    x, un, cn = ddp.forward_pass(None, x0, u, None, 1.0, prob, lims)
+    x = x.reshape(4, N, B); un = un.reshape(1, N, B)
+    fx, fu, _, _, _, cx, cu, cxx, cxu, cuu = ddp.df(prob, x, un)
+    lam = 10.0 ** rng.uniform(-3, 1, B)
+    regType = int(rng.integers(1, 3))
+    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, lims, None, un)
+    worst = 0.0
+    for b in range(B):
+        xr, ur, cr = oc.forward_pass(p, None, x0[:, b], u[..., b], None, 1.0, lims)
+        dr = oc.df(p, xr, ur)
+        for got, ref, name in ((x[..., b], xr, "x"), (un[..., b], ur, "u"), (fx[..., b], dr[0], "fx"), (fu[..., b], dr[1], "fu"),
+                               (cx[..., b], dr[2], "cx"), (cu[..., b], dr[3], "cu")):
+            e = relerr(got, ref)
+            worst = max(worst, e)
+            assert e < RTOL, (name, e, case, dict(N=N, B=B, h=hstep))
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(dr[2], dr[3], prob.Q, np.zeros((4, 1)), prob.R, dr[0], dr[1], lam[b], regType, lims, None, ur)
+        assert div[b] == d, ("diverge", case, div[b], d)
+        for got, ref, name in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (Vxx[..., b], vxx, "Vxx"), (Vx[..., b], vx, "Vx")):
+            e = relerr(got, ref)
+            worst = max(worst, e)
+            assert e < RTOL, (name, e, case, dict(N=N, B=B, h=hstep, regType=regType))
+    return worst
+
+
 def main():
     import ddp_amd as ddp
     from oracle import oracle_ctypes as oc
@@ -152,6 +192,10 @@ def main():
     for c in range(cases // 10):
         worst = max(worst, ilqg_case(ddp, oc, rng, c))
     print("fuzz: %d iLQG solves passed, worst relative error %.3g" % (cases // 10, worst))
+    worst = 0.0
+    for c in range(cases // 4):
+        worst = max(worst, pendcart_case(ddp, oc, np.random.default_rng([seed, 100000 + c]), c))
+    print("fuzz: %d pendcart cases passed, worst relative error %.3g" % (cases // 4, worst))
 
 
 if __name__ == "__main__":
