@@ -177,6 +177,59 @@ def pendcart_case(ddp, oc, rng, case):
     return worst
 
 
+def gps_case(ddp, oc, rng, case):
+    """KL path: ∇kl, back_pass_gps (scalar or per-step η, limits or not), forward_covariance, kl_div_wiki on a random chain"""
+    import ddp_amd.kl as kl
+    n, m = [(4, 2), (4, 1), (10, 2), (6, 3), (7, 2)][rng.integers(0, 5)]
+    N = int(rng.integers(2, 60))
+    h = 0.05
+    # contractive dynamics: there is no λ on this path, and on growing ones V reaches 1e10-1e16 within the horizon, where the
+    # boxQP exit codes (hence `diverge`) turn on the last bit of the KL terms
+    fx = 0.97 * np.eye(n)[:, :, None] + 0.3 * h * rng.standard_normal((n, n, N)) / np.sqrt(n)
+    fu = h * rng.standard_normal((n, m, N))
+    cxx = np.stack([spd(rng, n, h) for _ in range(N)], -1); cuu = np.stack([spd(rng, m, 0.1 * h) for _ in range(N)], -1)
+    cxu = 0.01 * h * rng.standard_normal((n, m, N))
+    cx = h * rng.standard_normal((n, N)); cu = 0.1 * h * rng.standard_normal((m, N))
+    x = rng.standard_normal((n, N)); u = 0.3 * rng.standard_normal((m, N))
+    lims = None if rng.integers(0, 2) else np.stack([-rng.uniform(0.2, 1.0, m), rng.uniform(0.2, 1.0, m)], 1)
+    Sp = np.stack([spd(rng, m, 1.0) for _ in range(N)], -1)
+    Sip = np.stack([np.linalg.inv(Sp[:, :, t]) for t in range(N)], -1)
+    Kp = 0.1 * rng.standard_normal((m, n, N)); kp = 0.1 * rng.standard_normal((m, N))
+    prev = ddp.GaussianPolicy(N, n, m, Kp, kp, Sp, Sip)
+    eta = 10.0 ** rng.uniform(0, 2)
+    etab = np.array([1e-8, eta, 1e16]) if rng.integers(0, 2) else np.stack([np.full(N, 1e-8), 10.0 ** rng.uniform(0, 2, N), np.full(N, 1e16)])
+    terms = kl.grad_kl(prev)
+    tr = oc.kl_terms(Kp, kp, Sip)
+    worst = 0.0
+    for got, ref in zip(terms, tr):
+        worst = max(worst, relerr(got, ref))
+        assert relerr(got, ref) < RTOL, ("kl terms", case)
+    d, pol, Vx, Vxx, dV = kl.back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, (terms, etab))
+    dr, (Kr, kr, Quuir, Quur), vxr, vxxr, dvr = oc.back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, (tr, etab))
+    if np.abs(vxxr).max() > 1e8 or not np.isfinite(vxxr).all():
+        gps_case.skipped = getattr(gps_case, "skipped", 0) + 1
+        return worst                      # the recursion has no λ here: a draw whose value function explodes has nothing left to compare
+    if d != dr:
+        # boxQP leaves with result 0 (= diverge) when its search direction is not a descent direction, `sdotg >= 0` (boxQP.jl:133):
+        # at a minimiser whose gradient is rounding noise above the ABSOLUTE threshold minGrad the sign of sdotg is noise too.
+        # Such a case is not comparable — it counts as a mismatch only if the C restatement keeps its answer under 1e-15 perturbations.
+        alt = {oc.back_pass_gps(cx * (1 + s_), cu, cxx, cxu, cuu, fx, fu, lims, x, u, (terms if s_ == 0 else tr, etab))[0] for s_ in (0.0, 1e-15, -1e-15, 3e-15)}
+        assert d in alt, ("diverge", case, d, dr, alt)
+        return worst
+    if d == 0:
+        for got, ref, name in ((pol.K, Kr, "K"), (pol.k, kr, "k"), (pol.Σ, Quuir, "Quui"), (pol.Σi, Quur, "Quu"), (Vx, vxr, "Vx"), (Vxx, vxxr, "Vxx")):
+            e = relerr(got, ref)
+            worst = max(worst, e)
+            # with limits k is boxQP's iterate, exact to ITS stopping tests only (1e-8 relative improvement of the QP value)
+            assert e < (1e-6 if (lims is not None and name in ("k", "Vx")) else RTOL), (name, e, case, dict(n=n, m=m, N=N, lims=lims is not None, eta_tv=etab.ndim == 2))
+        R1 = spd(rng, n, 1e-3)
+        sig = kl.forward_covariance(kl.Model(fx, fu, R1), x, u, pol)
+        sr = oc.forward_covariance(fx, R1, Kr, Quuir)
+        worst = max(worst, relerr(sig, sr))
+        assert relerr(sig, sr) < RTOL, ("sigma", case)
+    return worst
+
+
 def main():
     import ddp_amd as ddp
     from oracle import oracle_ctypes as oc
@@ -196,6 +249,10 @@ def main():
     for c in range(cases // 4):
         worst = max(worst, pendcart_case(ddp, oc, np.random.default_rng([seed, 100000 + c]), c))
     print("fuzz: %d pendcart cases passed, worst relative error %.3g" % (cases // 4, worst))
+    worst = 0.0
+    for c in range(cases // 4):
+        worst = max(worst, gps_case(ddp, oc, np.random.default_rng([seed, 200000 + c]), c))
+    print("fuzz: %d KL-path cases passed (%d exploded draws not compared), worst relative error %.3g" % (cases // 4, getattr(gps_case, "skipped", 0), worst))
 
 
 if __name__ == "__main__":
