@@ -84,7 +84,7 @@ def one_case(ddp, oc, rng, case):
     fx, fu, fx_b, fx_tv, Q, R = c["fx"], c["fu"], c["fx_b"], c["fx_tv"], c["Q"], c["R"]
     prob = ddp.LQProblem(fx, fu, Q, R, dyn_batched=fx_b) if fx_tv else ddp.LQProblem(fx, fu, Q, R)
     Kc = np.where(np.isfinite(pol.K), pol.K, 0.0); kc = np.where(np.isfinite(pol.k), pol.k, 0.0)
-    al = np.array([1.0, 0.3])
+    al = np.array([1.0, 0.3, 0.55, 0.1, 0.03, 0.8, 0.2, 0.01, 0.4, 0.6, 0.05])[: 1 + (case * 7) % 11]        # 1..11 step sizes
     xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(N, n, m, Kc, kc), c["x0"], c["u"], c["xnom"], al, prob, lims)
     for b in range(B):
         p = oc.make_problem("lq", n, m, N, A=fx[..., b] if fx_b else fx, B=fu[..., b] if fx_b else fu, Q=Q, R=R)
