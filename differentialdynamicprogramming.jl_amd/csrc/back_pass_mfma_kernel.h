@@ -3,19 +3,26 @@
 // back_pass.hip / back_pass_big.hip (src/backward_pass.jl:179-215 + :28-79).
 //
 // One 256-thread work-group (4 waves = the 4 SIMDs of a CU) per trajectory.  LDS:
-//     Vs [64 x 64]  Vxx_{i+1}, symmetric, leading dimension LD = 80   (A operand of W = Vxx·F)
+//     Vs [64 x 64]  Vxx_{i+1}, symmetric, leading dimension LDV = 65  (A operand of W = Vxx·F)
 //     Fs [64 x 80]  F = [fx fu 0], state index fastest, leading dimension LDK = 66 — the coalesced global
 //                   layout goes to LDS untransposed (conflict-free writes) and LDK ≡ 2 (mod 32) makes the
 //                   k-major operand reads (B of W = Vxx·F, A of G = F'W) conflict-free too
-//     WT [80 x 64]  W' (column index of W fastest, LD = 80); column 72 carries Vx_{i+1}, so G[:,72] = F'Vx
-// Per step, 4 barriers:
-//   P1   wave w: W[16w..16w+15, :] = 5 column tiles x 16 k-steps = 80 MFMAs, operands software-pipelined one
-//        k-step ahead; Vxx_{i+1} streams to global from Vs in the same phase
-//   P2a  wave w: tile (w,4) of G = F'W (Qux', Qx) + a quarter of the k-range of tile (4,4) (Quu, Qu) = 20 MFMAs
-//   P3 | P2b  wave 0 reduces Quu and computes the gains (every lane factorises QuuF, lane c solves column c of K;
-//        or the boxQP) WHILE waves 1-3 compute the 10 upper Qxx tiles (+cxx) into Vs (Vxx_{i+1} is dead after P1)
-//   P4   Vxx_i = Qxx + ½(K'Y + Y'K): the rank-16 update [K;Y]'·½[Y;K] as 4 more MFMAs per upper tile with the
-//        Qxx tile as the C operand; the upper triangle is mirrored (exactly symmetric Vxx).
+//     WT [64 x 64]  W' (column index of W fastest, LD = 80)
+//     PT            per-wave partial sums of the u/Vx columns of G = F'W (9 of 16 tile columns, compact)
+// The dependent chain of a step is  Vxx_{i+1} -> W_u = Vxx·fu -> Quu, Qux, Qu -> gains -> Vxx_i;  the phases are cut so
+// that the serial gain computation (one wave, VALU) runs beside the bulk of W = Vxx·fx (three waves, matrix cores):
+//   phase 1  wave w: rows 16w.. of W for the column tiles {u | Vx} and 0 (32 MFMAs, A shared); the u tile never
+//            leaves the registers: with the k index permuted to the accumulator layout it is the B operand of the
+//            wave's k-slice of ALL FIVE row tiles of G[:, u | Vx] (20 MFMAs); column 72 of W is Vx_{i+1}, so
+//            G[:,72] = F'Vx.  Vxx_{i+1} streams to global and the next Jacobian is requested under these MFMAs.
+//   phase 2  wave 0 sums the four partial tiles and computes the gains (every lane factorises QuuF, lane c solves
+//            column c of K; or the boxQP)  |  wave w = 1..3: column tile w of W for all four row tiles (64 MFMAs, B shared)
+//   phase 3  the 10 upper tiles of Vxx_i = cxx + fx'W + ½(K'Y + Y'K): 16 + 4 MFMAs per tile (the rank-16 update
+//            [K;Y]'·½[Y;K] rides on the same accumulator).  The tiles of a wave SHARE an operand (waves 0-2 a row of the
+//            upper triangle, wave 3 the column-3 left-overs): with all four waves in a product phase it is the LDS that
+//            saturates at two operand reads per MFMA (measured 115 cycles per MFMA against 72 of the pipe), not the
+//            matrix cores.  The upper triangle is mirrored (exactly symmetric Vxx); Vx_i on wave 3
+//   then the next Jacobian goes to Fs (two more barriers: everybody is done reading Fs / before it is read again).
 // Measured (profiles/microbench/mfma_f64_bench.hip): 30 ns per MFMA per wave with ONE wave per SIMD (66-70 TF/s of the
 // 78.6 TF/s peak) — unlike the fp64 VALU, the matrix pipe does not need several waves to fill.
 // Included by back_pass_mfma.hip (no control limits; built with -amdgpu-mfma-vgpr-form) and back_pass_mfma_lims.hip
@@ -34,19 +41,27 @@ struct BPMArgs {
     int32_t *diverge;
 };
 
+#ifndef DDP_PF2
+#define DDP_PF2 2
+#endif
+#ifndef DDP_PF3
+#define DDP_PF3 4
+#endif
+
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int NT = 256, n = 64, m = 8, p = 72, PP = 80, LD = 80, LDK = 66, LDV = 65, KS = 10;
+constexpr int NT = 256, n = 64, m = 8, p = 72, PP = 80, LD = 80, LDK = 66, LDV = 65, KS = 10, PTS = 36;   // PTS: lanes (l4, l15 < 9) of a partial tile register
 constexpr int oVs = 0, oFs = oVs + n * LDV, oWT = oFs + PP * LDK, ovs = oWT + n * LD, oQs = ovs + n, oXs = oQs + PP,
               oXrs = oXs + m * n, oQuus = oXrs + m * n, oRadd = oQuus + m * m, oKs = oRadd + m * m, oYs = oKs + KS * n,
-              oks = oYs + KS * n, oQuuks = oks + m, oPq = oQuuks + m, oFlag = oPq + 4 * 2 * 64, oTot = oFlag + 2;
+              oks = oYs + KS * n, oQuuks = oks + m, oPT = oQuuks + m, oFlag = oPT + 4 * 5 * 4 * PTS, oTot = oFlag + 2;
 
 #ifdef DDP_MFPROF     // per-phase cycle counts (s_memtime) of block 0, printed per wave: profiling builds only
 #define MFP_DECL long long mfp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mfp_t = __builtin_amdgcn_s_memtime()
 #define MFP(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); mfp_[k] += t_ - mfp_t; mfp_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define MFP_PRINT do { if (b == 0 && lane == 0) printf("MFPROF wave %d steps %d: p1 %lld bar %lld p2a %lld bar %lld p3|p2b %lld bar %lld p4 %lld bar %lld | p1: gemm %lld wst %lld; p4: stF %lld tiles %lld; p3: red+H %lld chol+k %lld Ksolve %lld\n", wv, N - 1, \
-    mfp_[0] / (N - 1), mfp_[1] / (N - 1), mfp_[2] / (N - 1), mfp_[3] / (N - 1), mfp_[4] / (N - 1), mfp_[5] / (N - 1), mfp_[6] / (N - 1), mfp_[7] / (N - 1), mfp_[8] / (N - 1), mfp_[9] / (N - 1), mfp_[10] / (N - 1), mfp_[11] / (N - 1), mfp_[12] / (N - 1), mfp_[13] / (N - 1), mfp_[14] / (N - 1)); } while (0)
+#define MFP_PRINT do { if (b == 0 && lane == 0) printf("MFPROF wave %d steps %d: ph1 %lld bar %lld ph2 %lld bar %lld ph3 %lld bar %lld stF %lld bar %lld | ph1: gemm %lld fused %lld; p3: red %lld chol+k %lld Ksolve %lld\n", wv, N - 1, \
+    mfp_[0] / (N - 1), mfp_[1] / (N - 1), mfp_[2] / (N - 1), mfp_[3] / (N - 1), mfp_[4] / (N - 1), mfp_[5] / (N - 1), mfp_[6] / (N - 1), mfp_[7] / (N - 1), \
+    mfp_[8] / (N - 1), mfp_[9] / (N - 1), mfp_[12] / (N - 1), mfp_[13] / (N - 1), mfp_[14] / (N - 1)); } while (0)
 #else
 #define MFP_DECL
 #define MFP(k)
@@ -70,24 +85,77 @@ __device__ __forceinline__ void mfma_chain2(const double *aA, const double *bA, 
             r[j][0] = aA[SA * (kk + PF)]; r[j][1] = bA[SB * (kk + PF)]; r[j][2] = aB[SA * (kk + PF)]; r[j][3] = bB[SB * (kk + PF)];
         }
         const int c = kk % (PF + 1);
+        __builtin_amdgcn_sched_barrier(0);            // keep the fetch of step kk+PF in front of the products of step kk
         cA = mf(r[c][0], r[c][1], cA);
         cB = mf(r[c][2], r[c][3], cB);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <bool LIMS>
+template <int NK, int PF, int SA, int SB>
+__device__ __forceinline__ void mfma_chain3(const double *aA, const double *bA, const double *aB, const double *bB, const double *aC, const double *bC,
+                                            d4 &cA, d4 &cB, d4 &cC)
+{
+    double r[PF + 1][6];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) { r[j][0] = aA[SA * j]; r[j][1] = bA[SB * j]; r[j][2] = aB[SA * j]; r[j][3] = bB[SB * j]; r[j][4] = aC[SA * j]; r[j][5] = bC[SB * j]; }
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        if (kk + PF < NK) {
+            const int j = (kk + PF) % (PF + 1);
+            r[j][0] = aA[SA * (kk + PF)]; r[j][1] = bA[SB * (kk + PF)]; r[j][2] = aB[SA * (kk + PF)]; r[j][3] = bB[SB * (kk + PF)];
+            r[j][4] = aC[SA * (kk + PF)]; r[j][5] = bC[SB * (kk + PF)];
+        }
+        const int c = kk % (PF + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        cA = mf(r[c][0], r[c][1], cA);
+        cB = mf(r[c][2], r[c][3], cB);
+        cC = mf(r[c][4], r[c][5], cC);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// NTL MFMA chains that share one operand (A if SHA, else B): 1 + NTL LDS reads per k-step instead of 2·NTL — with all four
+// waves in a product phase the LDS, not the matrix pipe, is what saturates at two reads per MFMA.
+template <int NK, int PF, int NTL, int SS, int SO, bool SHA>
+__device__ __forceinline__ void mfma_chain_shared(const double *sp, const double *const (&op)[3], d4 (&c)[3])
+{
+    double r[PF + 1][1 + NTL];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        r[j][0] = sp[SS * j];
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) r[j][1 + u] = op[u][SO * j];
+    }
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        if (kk + PF < NK) {
+            const int j = (kk + PF) % (PF + 1);
+            r[j][0] = sp[SS * (kk + PF)];
+#pragma unroll
+            for (int u = 0; u < NTL; ++u) r[j][1 + u] = op[u][SO * (kk + PF)];
+        }
+        const int q = kk % (PF + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) c[u] = SHA ? mf(r[q][0], r[q][1 + u], c[u]) : mf(r[q][1 + u], r[q][0], c[u]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool LIMS, bool CTV>
 __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (a.active && a.active[b] == 0) return;
     const int N = a.N, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Vs = lds + oVs, *Fs = lds + oFs, *WT = lds + oWT, *vs = lds + ovs, *Qs = lds + oQs, *Xs = lds + oXs, *Xrs = lds + oXrs,
+    double *Vs = lds + oVs, *Fs = lds + oFs, *WT = lds + oWT, *vs = lds + ovs, *Qs = lds + oQs, *Xs = lds + oXs, *Xadd = lds + oXrs,
            *Quus = lds + oQuus, *Radd = lds + oRadd, *Ks = lds + oKs, *Ys = lds + oYs, *ks = lds + oks, *Quuks = lds + oQuuks,
-           *Pq = lds + oPq, *flag = lds + oFlag;
+           *PT = lds + oPT, *flag = lds + oFlag;
 
     constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
-    const bool FXTV = a.fx_tv, CTV = a.cost_tv;
+    const bool FXTV = a.fx_tv;
     const double *cx = a.cx + (size_t)n * N * b, *cu = a.cu + (size_t)m * N * b;
     const double *ug = LIMS ? a.u + (size_t)m * N * b : nullptr;
     const double *fx = a.fx + (a.fx_batched ? nn * (FXTV ? N : 1) * b : 0);
@@ -140,132 +208,145 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
     __syncthreads();
 
     // upper-triangle tile t = 0..9 of the 4 x 4 Qxx tiling, column-major: (0,0) (0,1) (1,1) (0,2) ...
-    auto tile_of = [](int t, int &ti, int &tj) { tj = (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0; ti = t - tj * (tj + 1) / 2; };
+    // phase-3 tiles of a wave share an operand: wave w < 3 takes row w of the upper triangle ((0,0) (0,1) (0,2) | (1,1) (1,2) (1,3) |
+    // (2,2) (2,3)), A = F[:, 16w..] shared; wave 3 the two left-over tiles of column 3, (0,3) and (3,3), B = W[:, 48..] shared
+    auto tile_w = [](int w, int u, int &ti, int &tj) -> bool {
+        if (w < 3) { ti = w; tj = min(w + u, 3); return u < (w == 2 ? 2 : 3); }
+        ti = (u == 0) ? 0 : 3; tj = 3; return u < 2;
+    };
     double dV0 = 0.0, dV1 = 0.0;
     int diverge = 0;
-    double cxxr[4][4], pre2a[4], preq[2];             // cost-Hessian operands of this thread's tiles (reloaded per step only if CTV)
+    double cxxr[3][4], cxur[m], preq[2];              // cost-Hessian operands of this thread (reloaded per step only if CTV)
+    auto load_cost = [&](int i) {
+        const double *cxxi = cxx + (CTV ? nn * i : 0), *cxui = cxu + (CTV ? nm * i : 0), *cuui = cuu + (CTV ? mm * i : 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {               // C operands of this wave's Vxx tiles (phase 3)
+            int ti, tj;
+            tile_w(wv, u, ti, tj);
+            const double *cp = cxxi + 16 * ti + l4 + n * (16 * tj + l15);
+            cxxr[u][0] = cp[0]; cxxr[u][1] = cp[4]; cxxr[u][2] = cp[8]; cxxr[u][3] = cp[12];
+        }
+        if (wv == 0) {                              // wave 0 adds cxu (column `lane`), cuu to the reduced partial tiles (phase 2)
+#pragma unroll
+            for (int q = 0; q < m; ++q) cxur[q] = cxui[lane + n * q];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) preq[r] = (l15 < m) ? cuui[l4 + 4 * r + m * l15] : 0.0;
+        }
+    };
+    if (!CTV) load_cost(0);
     MFP_DECL;
     for (int i = N - 2; i >= 0; --i) {
-        const double *cxxi = cxx + (CTV ? nn * i : 0), *cxui = cxu + (CTV ? nm * i : 0), *cuui = cuu + (CTV ? mm * i : 0);
         const bool ldF = FXTV && i > 0;                 // next step's Jacobian is fetched under this step's first product
-        if (CTV || i == N - 2) {                        // so do the cost terms: they become the C operands of the G tiles
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = 16 * wv + l4 + 4 * r;
-                pre2a[r] = (l15 < m) ? cxui[gi + n * l15] : 0.0;
-            }
-            if (wv == 0) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) preq[r] = (l15 < m) ? cuui[l4 + 4 * r + m * l15] : 0.0;
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int ti, tj;
-                    tile_of(min(wv - 1 + 3 * u, 9), ti, tj);
-                    const double *cp = cxxi + 16 * ti + l4 + n * (16 * tj + l15);
-                    cxxr[u][0] = cp[0]; cxxr[u][1] = cp[4]; cxxr[u][2] = cp[8]; cxxr[u][3] = cp[12];
-                }
-            }
-        }
-        double gx[4] = {0.0, 0.0, 0.0, 0.0}, gu[2] = {0.0, 0.0};   // gradient entries riding in column 72: cx (rows of this wave), cu
-        // ================= P1: W = Vxx·F on the matrix cores; column 72 of W := Vx ===========================
+        if (CTV) load_cost(i);
+        double gxc = 0.0, gu[2] = {0.0, 0.0};           // gradient entries: cx[lane], cu (wave 0)
+
+        // ================= phase 1: W[16w.., {u|Vx, 0}] = Vxx·F; partial G[:, u|Vx] from the registers ==========
         {
-            d4 acc[5];
-#pragma unroll
-            for (int c = 0; c < 5; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+            d4 accU = d4{0.0, 0.0, 0.0, 0.0}, acc0 = d4{0.0, 0.0, 0.0, 0.0};
             const double *ap = Vs + 16 * wv + l15 + LDV * l4;          // A[i][k] = Vxx[16w+i, k]
             const double *bp = Fs + l4 + LDK * l15;                   // B[k][j] = F[k, 16c+j]
-            double a0 = ap[0], b0[5];
-#pragma unroll
-            for (int c = 0; c < 5; ++c) b0[c] = bp[LDK * 16 * c];
-            const double *vout = Vs + lane + LDV * wv;                // Vxx_{i+1} streams out under the MFMAs (:72 of step i+1)
+            double a0 = ap[0], bU0 = bp[LDK * 64], b00 = bp[0];
+            // Global traffic rides in the MFMA shadow, at most one instruction per k-step: the address unit takes ~16 cycles per
+            // wave instruction and all four waves share it (a burst at the top of the step costs ~2k cycles).  Here: columns
+            // 0..31 of Vxx_{i+1} (:72 of step i+1; the rest goes out in phase 2), wave 0's share of the next Jacobian.
+            const double *vout = Vs + lane + LDV * wv;
             double *gout = Vxxg + nn * (i + 1) + tid;
             double vprev = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                if (kk > 0) gout[NT * (kk - 1)] = vprev;
-                vprev = vout[LDV * 4 * kk];
-                // global loads ride in the MFMA shadow too, one per k-step: the address unit takes ~16 cycles per wave
-                // instruction and all four waves share it, so a burst at the top of the step costs ~2k cycles
-                if (kk < 4) { if (l15 == m) gx[kk] = cx[(size_t)n * i + 16 * wv + l4 + 4 * kk]; }        // needed first (P2a)
-                else if (kk < 6) { if (wv == 0 && l15 == m) gu[kk - 4] = cu[(size_t)m * i + l4 + 4 * (kk - 4)]; }
-                else if (kk < 6 + RF) { if (ldF) pfF[kk - 6] = load_F1(i - 1, kk - 6); }
-                double a1 = 0.0, b1[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-                if (kk < 15) {
-                    a1 = ap[LDV * 4 * (kk + 1)];
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) b1[c] = bp[LDK * 16 * c + 4 * (kk + 1)];
+                if (kk & 1) gout[NT * (kk >> 1)] = vprev;
+                else vprev = vout[LDV * 4 * (kk >> 1)];
+                if (wv == 0) {
+                    if (kk == 0) gxc = cx[(size_t)n * i + lane];
+                    else if (kk < 3) { if (l15 == m) gu[kk - 1] = cu[(size_t)m * i + l4 + 4 * (kk - 1)]; }
+                    else if (kk < 3 + RF) { if (ldF) pfF[kk - 3] = load_F1(i - 1, kk - 3); }
                 }
-#pragma unroll
-                for (int c = 0; c < 5; ++c) acc[c] = mf(a0, b0[c], acc[c]);
-                a0 = a1;
-#pragma unroll
-                for (int c = 0; c < 5; ++c) b0[c] = b1[c];
+                double a1 = 0.0, bU1 = 0.0, b01 = 0.0;
+                if (kk < 15) { a1 = ap[LDV * 4 * (kk + 1)]; bU1 = bp[LDK * 64 + 4 * (kk + 1)]; b01 = bp[4 * (kk + 1)]; }
+                __builtin_amdgcn_sched_barrier(0);                    // fetches of step kk+1 stay in front of the products of step kk
+                accU = mf(a0, bU0, accU);
+                acc0 = mf(a0, b00, acc0);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = a1; bU0 = bU1; b00 = b01;
             }
             MFP(8);
-            gout[NT * 15] = vprev;
-            const bool vcol = (l15 == 8);
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {                             // D[row = l4 + 4r][col = l15] -> WT[col + LD*row]
-                double *wp = WT + 16 * c + l15 + LD * (16 * wv + l4);
-                double w0 = acc[c].x, w1 = acc[c].y, w2 = acc[c].z, w3 = acc[c].w;
-                if (c == 4 && vcol) { const double *vp = vs + 16 * wv + l4; w0 = vp[0]; w1 = vp[4]; w2 = vp[8]; w3 = vp[12]; }
-                wp[0] = w0; wp[LD * 4] = w1; wp[LD * 8] = w2; wp[LD * 12] = w3;
+            {                                                         // D[row = l4 + 4r][col = l15] -> WT[col + LD*row]
+                double *wp = WT + l15 + LD * (16 * wv + l4);
+                wp[0] = acc0.x; wp[LD * 4] = acc0.y; wp[LD * 8] = acc0.z; wp[LD * 12] = acc0.w;
             }
-        }
-        MFP(9);
-        MFP(0);
-        __syncthreads();
-        MFP(1);
-
-        // ================= P2a: the u/Vx columns of G = F'W: Qux' (:208), Qx (:203), partial Quu/Qu ===========
-        {
-            d4 acc0 = d4{pre2a[0] + gx[0], pre2a[1] + gx[1], pre2a[2] + gx[2], pre2a[3] + gx[3]}, acc1 = d4{0.0, 0.0, 0.0, 0.0}, accq = d4{0.0, 0.0, 0.0, 0.0};
-            const double *ap = Fs + l4 + LDK * (16 * wv + l15);       // A[i][k] = F[k, 16w+i]
-            const double *aq = Fs + l4 + LDK * (n + l15) + 16 * wv;   // A[i][k] = F[k, 64+i], k-range [16w, 16w+16)
-            const double *bp = WT + n + l15 + LD * l4;                // B[k][j] = W[k, 64+j]
-            double qa[4], qb[4];
+            // The u|Vx tile of W as B operand: k-step r uses k = 16w + l4 + 4r, which is the accumulator register r of this lane
+            double bu[4] = {accU.x, accU.y, accU.z, accU.w};
+            if (l15 == m) { const double *vp = vs + 16 * wv + l4; bu[0] = vp[0]; bu[1] = vp[4]; bu[2] = vp[8]; bu[3] = vp[12]; }   // column 72 := Vx_{i+1}
+            d4 pg[5];
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) { qa[k2] = aq[4 * k2]; qb[k2] = bp[LD * 4 * (4 * wv + k2)]; }
-            mfma_chain2<8, 2, 8, LD * 8>(ap, bp, ap + 4, bp + LD * 4, acc0, acc1);    // even / odd k-steps
+            for (int ti = 0; ti < 5; ++ti) pg[ti] = d4{0.0, 0.0, 0.0, 0.0};
+            const double *fp = Fs + 16 * wv + l4 + LDK * l15;         // A[i][k] = F[16w + l4 + 4r, 16ti + i]
+            double fa[5], fb[5];
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) accq = mf(qa[k2], qb[k2], accq);
-            const d4 g = acc0 + acc1;
-            const double gv[4] = {g.x, g.y, g.z, g.w};
+            for (int ti = 0; ti < 5; ++ti) fa[ti] = fp[LDK * 16 * ti];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = 16 * wv + l4 + 4 * r;
-                if (l15 < m) Xs[l15 + m * gi] = gv[r];
-                else if (l15 == m) Qs[gi] = gv[r];
+                if (r < 3) {
+#pragma unroll
+                    for (int ti = 0; ti < 5; ++ti) fb[ti] = fp[LDK * 16 * ti + 4 * (r + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti) pg[ti] = mf(fa[ti], bu[r], pg[ti]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti) fa[ti] = fb[ti];
             }
-            Pq[(2 * wv) * 64 + lane] = accq.x;                        // rows l4, l4+4 of the (4,4) tile: the 8 u rows
-            Pq[(2 * wv + 1) * 64 + lane] = accq.y;
+            if (l15 <= m) {                                           // columns u | Vx of the five partial tiles, compact
+                double *pp = PT + (wv * 5 * 4) * PTS + l4 * 9 + l15;
+#pragma unroll
+                for (int ti = 0; ti < 5; ++ti) {
+                    pp[(ti * 4 + 0) * PTS] = pg[ti].x; pp[(ti * 4 + 1) * PTS] = pg[ti].y;
+                    if (ti < 4) { pp[(ti * 4 + 2) * PTS] = pg[ti].z; pp[(ti * 4 + 3) * PTS] = pg[ti].w; }     // tile 4: rows 0..7 only
+                }
+            }
+            MFP(9);
         }
-        MFP(2);
-        __syncthreads();
-        MFP(3);
-        if (regType == 2) {     // (:205-207): QuuF = Quu + λ·fu'fu, Qux_reg = Qux + λ·fu'fx
+        if (regType == 2) {     // (:205-207): QuuF = Quu + λ·fu'fu, Qux_reg = Qux + λ·fu'fx — the λ terms only, added in phase 2
             for (int e = tid; e < m * n + m * m; e += NT) {
                 const bool isx = e < m * n;
                 const int q = isx ? (e & 7) : ((e - m * n) & 7), j = isx ? (e >> 3) : n + ((e - m * n) >> 3);
                 double s = 0.0;
 #pragma unroll 8
                 for (int kq = 0; kq < n; ++kq) s += Fs[kq + LDK * (n + q)] * Fs[kq + LDK * j];
-                if (isx) Xrs[e] = Xs[e] + lam * s;
+                if (isx) Xadd[e] = lam * s;
                 else Radd[e - m * n] = lam * s;
             }
-            __syncthreads();
         }
-        const double *Xr = (regType == 2) ? Xrs : Xs;
+        MFP(0);
+        __syncthreads();
+        MFP(1);
 
         if (wv == 0) {
-            // ================= P3 (wave 0): Quu/Qu reduction, gains (backward_pass.jl:30-68) ===================
+            // ================= phase 2, wave 0: reduce the partial tiles, gains (backward_pass.jl:30-68) =========
+            double x2[m], xr[m];
+            {
+                // row `lane` of G[:, u|Vx]: tile lane/16, register (lane%16)/4, tile row lane%4 -> offset 9*lane
+                const double *pp = PT + 9 * lane;
+                double s[m + 1];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+                for (int q = 0; q <= m; ++q) s[q] = ((pp[q] + pp[q + 20 * PTS]) + pp[q + 40 * PTS]) + pp[q + 60 * PTS];
+#pragma unroll
+                for (int q = 0; q < m; ++q) {
+                    x2[q] = s[q] + cxur[q];                                       // Qux[q, lane]  (:208)
+                    xr[q] = (regType == 2) ? x2[q] + Xadd[q + m * lane] : x2[q];
+                }
+                Qs[lane] = s[m] + gxc;                                            // Qx[lane]  (:203)
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {                                         // tile 4, rows l4 + 4r < 8
                 const int aq = l4 + 4 * r;
-                const double s = ((Pq[r * 64 + lane] + Pq[(2 + r) * 64 + lane]) + Pq[(4 + r) * 64 + lane]) + Pq[(6 + r) * 64 + lane];
-                if (l15 < m) Quus[aq + m * l15] = s + preq[r];                     // (:209)
-                else if (l15 == m) Qs[n + aq] = s + gu[r];                        // (:204)
+                if (l15 <= m) {
+                    const double *pp = PT + (16 + r) * PTS + l4 * 9 + l15;
+                    const double s = ((pp[0] + pp[20 * PTS]) + pp[40 * PTS]) + pp[60 * PTS];
+                    if (l15 < m) Quus[aq + m * l15] = s + preq[r];                // (:209)
+                    else Qs[n + aq] = s + gu[r];                                  // (:204)
+                }
             }
             wave_sync();
             double H[m * m], R[m * m], kk[m];
@@ -283,17 +364,20 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             int fail;
             double ri[m];
             const bool use_ri = !LIMS || nolims;                     // division-free factor on the unconstrained path
+            double qu[m];
+#pragma unroll
+            for (int q = 0; q < m; ++q) qu[q] = Qs[n + q];
             if (use_ri) {
                 fail = ddp_chol_rinv<m>(H, R, ri);                   // cholesky(Hermitian(QuuF))  (:35)
 #pragma unroll
-                for (int q = 0; q < m; ++q) kk[q] = Qs[n + q];
+                for (int q = 0; q < m; ++q) kk[q] = qu[q];
                 ddp_rsolve_neg<m>(R, ri, kk);                        // k_i = -(R\Qu)  (:41)
             } else {
                 double g[m], lo[m], up[m], x0[m];
 #pragma unroll
                 for (int q = 0; q < m; ++q) {
                     const double uq = ug[(size_t)m * i + q];
-                    g[q] = Qs[n + q]; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; x0[q] = ks[q];
+                    g[q] = qu[q]; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; x0[q] = ks[q];
                 }
                 int iters;
                 const int result = boxqp_dev_ri<m>(m, H, g, lo, up, x0, qpo, kk, R, ri, clamped, iters);
@@ -305,9 +389,9 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 Quug[mm * i + lane] = Quus[lane];
             } else {
                 // every LDS read first, every write last: the compiler cannot prove the K/Y writes do not alias Quus
-                double col[m], x2[m], qu[m];
+                double col[m];
 #pragma unroll
-                for (int q = 0; q < m; ++q) { x2[q] = Xs[q + m * lane]; col[q] = ((clamped >> q) & 1u) ? 0.0 : Xr[q + m * lane]; qu[q] = Qs[n + q]; }
+                for (int q = 0; q < m; ++q) col[q] = ((clamped >> q) & 1u) ? 0.0 : xr[q];
                 // Unconstrained regType 1: (Quu + λI)·K = -Qux and (Quu + λI)·k = -Qu hold to the backward error of the solve,
                 // so Quu·K and Quu·k need no product with Quu (the other cases take it from LDS again: H is dead, R holds the factor)
                 const bool by_residual = use_ri && regType != 2;
@@ -344,6 +428,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 dV0 += kQu; dV1 += 0.5 * kQuuk;                      // (every lane; lane 0 reports)
 #pragma unroll
                 for (int q = 0; q < m; ++q) {
+                    Xs[q + m * lane] = x2[q];
                     Ks[q + KS * lane] = col[q];
                     Ys[q + KS * lane] = y[q];
                     Kg[nm * i + q + (size_t)m * lane] = col[q];      // (:76)
@@ -355,56 +440,77 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 }
             }
         } else {
-            // ================= P2b (waves 1-3): the 10 upper Qxx tiles of G = F'W, + cxx, into Vs (:210) =======
+            // ================= phase 2, wave c = 1..3: column tile c of W = Vxx·F for the four row tiles ==========
+            d4 acc[4];
 #pragma unroll
-            for (int u = 0; u < 4; u += 2) {                          // two tiles at a time: two independent MFMA chains
-                const int tA = wv - 1 + 3 * u, tB = tA + 3;           // tA <= 8 always, tB may run past the last tile
-                const bool vB = tB < 10;
-                int tiA, tjA, tiB, tjB;
-                tile_of(tA, tiA, tjA);
-                tile_of(vB ? tB : tA, tiB, tjB);
-                d4 accA = d4{cxxr[u][0], cxxr[u][1], cxxr[u][2], cxxr[u][3]};
-                d4 accB = d4{cxxr[u + 1][0], cxxr[u + 1][1], cxxr[u + 1][2], cxxr[u + 1][3]};
-                const double *apA = Fs + l4 + LDK * (16 * tiA + l15), *apB = Fs + l4 + LDK * (16 * tiB + l15);   // A[i][k] = F[k, 16ti+i]
-                const double *bpA = WT + 16 * tjA + l15 + LD * l4, *bpB = WT + 16 * tjB + l15 + LD * l4;         // B[k][j] = W[k, 16tj+j]
-                mfma_chain2<16, 2, 4, LD * 4>(apA, bpA, apB, bpB, accA, accB);
-                double *qA = Vs + 16 * tjA + l15 + LDV * (16 * tiA + l4);   // Qxx[gi, gj] stored at (gj, gi): lanes contiguous
-                qA[0] = accA.x; qA[LDV * 4] = accA.y; qA[LDV * 8] = accA.z; qA[LDV * 12] = accA.w;
-                if (vB) {
-                    double *qB = Vs + 16 * tjB + l15 + LDV * (16 * tiB + l4);
-                    qB[0] = accB.x; qB[LDV * 4] = accB.y; qB[LDV * 8] = accB.z; qB[LDV * 12] = accB.w;
+            for (int rb = 0; rb < 4; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
+            const double *ap = Vs + l15 + LDV * l4;                   // A[i][k] = Vxx[16rb+i, k]
+            const double *bp = Fs + l4 + LDK * (16 * wv + l15);       // B[k][j] = F[k, 16c+j]
+            constexpr int PF = DDP_PF2;                               // operands fetched PF k-steps ahead
+            double bq[PF + 1], aq_[PF + 1][4];
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                bq[j] = bp[4 * j];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) aq_[j][rb] = ap[16 * rb + LDV * 4 * j];
+            }
+            const double *vout = Vs + lane + LDV * (31 + wv);          // columns 32.. of Vxx_{i+1}: 31 + w + 3j, j = 0..10
+            double *gout = Vxxg + nn * (i + 1) + lane + n * (31 + wv);
+            double vprev = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                if (kk >= 1 && kk <= 11 && (kk < 11 || wv < 3)) gout[n * 3 * (kk - 1)] = vprev;
+                if (kk < 11 && (kk < 10 || wv < 3)) vprev = vout[LDV * 3 * kk];
+                if (kk >= 7 && ldF) pfF[kk - 7] = load_F1(i - 1, kk - 7);
+                if (kk + PF < 16) {
+                    const int j = (kk + PF) % (PF + 1);
+                    bq[j] = bp[4 * (kk + PF)];
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) aq_[j][rb] = ap[16 * rb + LDV * 4 * (kk + PF)];
                 }
+                const int c = kk % (PF + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb] = mf(aq_[c][rb], bq[c], acc[rb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                double *wp = WT + 16 * wv + l15 + LD * (16 * rb + l4);
+                wp[0] = acc[rb].x; wp[LD * 4] = acc[rb].y; wp[LD * 8] = acc[rb].z; wp[LD * 12] = acc[rb].w;
             }
         }
-        MFP(4);
+        MFP(2);
         __syncthreads();
-        MFP(5);
+        MFP(3);
         if (flag[0] != 0.0) { diverge = i + 1; break; }              // block-uniform
-        if (FXTV && i > 0) store_F(pfF);                             // Fs is dead from here on
-        MFP(10);
 
-        // ================= P4: Vxx_i = Qxx + ½(K'Y + Y'K), symmetrised (:69-72); Vx_i ==========================
+        // ================= phase 3: Vxx_i = cxx + fx'W + ½(K'Y + Y'K), symmetrised (:69-72, :210); Vx_i ==========
         {
             d4 acc[3];
+            const double *apt[3], *bpt[3];
             double kA[3][2], yA[3][2], kB[3][2], yB[3][2], *qp[3], *mp[3];
             bool diag[3], valid[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {                             // all operands of this wave's (up to) 3 tiles first ...
-                const int t = wv + 4 * u;
-                valid[u] = t < 10;
+            for (int u = 0; u < 3; ++u) {
                 int ti, tj;
-                tile_of(valid[u] ? t : 9, ti, tj);
+                valid[u] = tile_w(wv, u, ti, tj);
                 diag[u] = ti == tj;
                 const int gj = 16 * tj + l15, gi0 = 16 * ti + l4;
-                qp[u] = Vs + gj + LDV * gi0;
+                qp[u] = Vs + gj + LDV * gi0;                          // Vxx[gi, gj] stored at (gj, gi): lanes contiguous
                 mp[u] = Vs + gi0 + LDV * gj;                          // mirror position (gi, gj)
-                acc[u] = d4{qp[u][0], qp[u][LDV * 4], qp[u][LDV * 8], qp[u][LDV * 12]};
+                acc[u] = d4{cxxr[u][0], cxxr[u][1], cxxr[u][2], cxxr[u][3]};
+                apt[u] = Fs + l4 + LDK * (16 * ti + l15);             // A[i][k] = F[k, 16ti+i]
+                bpt[u] = WT + gj + LD * l4;                           // B[k][j] = W[k, 16tj+j]
                 const int ia = l4 + KS * (16 * ti + l15), ib = l4 + KS * gj;
                 kA[u][0] = Ks[ia]; kA[u][1] = Ks[ia + 4]; yA[u][0] = Ys[ia]; yA[u][1] = Ys[ia + 4];
                 kB[u][0] = 0.5 * Ks[ib]; kB[u][1] = 0.5 * Ks[ib + 4]; yB[u][0] = 0.5 * Ys[ib]; yB[u][1] = 0.5 * Ys[ib + 4];
             }
+            if (wv < 2) mfma_chain_shared<16, 2, 3, 4, LD * 4, true>(apt[0], bpt, acc);           // rows 0, 1: three tiles
+            else if (wv == 2) mfma_chain_shared<16, 2, 2, 4, LD * 4, true>(apt[0], bpt, acc);     // row 2: two tiles
+            else mfma_chain_shared<16, 2, 2, LD * 4, 4, false>(bpt[0], apt, acc);                // column 3: (0,3), (3,3)
 #pragma unroll
-            for (int u = 0; u < 3; ++u) acc[u] = mf(kA[u][0], yB[u][0], acc[u]);      // ... then three interleaved chains
+            for (int u = 0; u < 3; ++u) acc[u] = mf(kA[u][0], yB[u][0], acc[u]);      // the rank-16 update on the same accumulators
 #pragma unroll
             for (int u = 0; u < 3; ++u) acc[u] = mf(kA[u][1], yB[u][1], acc[u]);
 #pragma unroll
@@ -424,7 +530,6 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 }
             }
         }
-        MFP(11);
         if (wv == 3) {                                               // Vx_i (:69)
             double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -436,6 +541,10 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             const double v = ((Qs[lane] + s1) + s2) + s3;
             vs[lane] = v; Vxg[(size_t)n * i + lane] = v;
         }
+        MFP(4);
+        __syncthreads();                                             // every wave is done reading Fs
+        MFP(5);
+        if (ldF) store_F(pfF);
         MFP(6);
         __syncthreads();
         MFP(7);
@@ -456,18 +565,22 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
 
 }   // namespace
 
-template <bool LIMS>
-static int ddp_bpm_launch(ddp_handle h, const BPMArgs &a)
+template <bool LIMS, bool CTV>
+static int ddp_bpm_launch_tv(ddp_handle h, const BPMArgs &a)
 {
     const size_t shmem = (size_t)oTot * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mfma_kernel<LIMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mfma_kernel<LIMS, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(back_pass_mfma_kernel<LIMS>, dim3(a.B), dim3(NT), shmem, h->stream, a);
+    hipLaunchKernelGGL((back_pass_mfma_kernel<LIMS, CTV>), dim3(a.B), dim3(NT), shmem, h->stream, a);
     DDP_HIP(hipGetLastError());
     return 0;
 }
+
+// time-invariant cost: its terms are loaded once, before the loop — no load (and no s_waitcnt on the in-order vmcnt) inside
+template <bool LIMS>
+static int ddp_bpm_launch(ddp_handle h, const BPMArgs &a) { return a.cost_tv ? ddp_bpm_launch_tv<LIMS, true>(h, a) : ddp_bpm_launch_tv<LIMS, false>(h, a); }
 
 int ddp_bpm_launch_lims(ddp_handle h, const BPMArgs &a);      // back_pass_mfma_lims.hip
