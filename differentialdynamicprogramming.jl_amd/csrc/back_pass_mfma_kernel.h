@@ -41,13 +41,6 @@ struct BPMArgs {
     int32_t *diverge;
 };
 
-#ifndef DDP_PF2
-#define DDP_PF2 2
-#endif
-#ifndef DDP_PF3
-#define DDP_PF3 4
-#endif
-
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -69,51 +62,6 @@ constexpr int oVs = 0, oFs = oVs + n * LDV, oWT = oFs + PP * LDK, ovs = oWT + n 
 #endif
 
 __device__ __forceinline__ d4 mf(double x, double y, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); }
-
-// Two independent NK-step MFMA chains; the four operands of a k-step are fetched from LDS PF steps ahead of their use
-// (the scheduler otherwise issues each ds_read right before its MFMA and exposes the LDS latency on every step).
-template <int NK, int PF, int SA, int SB>
-__device__ __forceinline__ void mfma_chain2(const double *aA, const double *bA, const double *aB, const double *bB, d4 &cA, d4 &cB)
-{
-    double r[PF + 1][4];
-#pragma unroll
-    for (int j = 0; j < PF; ++j) { r[j][0] = aA[SA * j]; r[j][1] = bA[SB * j]; r[j][2] = aB[SA * j]; r[j][3] = bB[SB * j]; }
-#pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-        if (kk + PF < NK) {
-            const int j = (kk + PF) % (PF + 1);
-            r[j][0] = aA[SA * (kk + PF)]; r[j][1] = bA[SB * (kk + PF)]; r[j][2] = aB[SA * (kk + PF)]; r[j][3] = bB[SB * (kk + PF)];
-        }
-        const int c = kk % (PF + 1);
-        __builtin_amdgcn_sched_barrier(0);            // keep the fetch of step kk+PF in front of the products of step kk
-        cA = mf(r[c][0], r[c][1], cA);
-        cB = mf(r[c][2], r[c][3], cB);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int NK, int PF, int SA, int SB>
-__device__ __forceinline__ void mfma_chain3(const double *aA, const double *bA, const double *aB, const double *bB, const double *aC, const double *bC,
-                                            d4 &cA, d4 &cB, d4 &cC)
-{
-    double r[PF + 1][6];
-#pragma unroll
-    for (int j = 0; j < PF; ++j) { r[j][0] = aA[SA * j]; r[j][1] = bA[SB * j]; r[j][2] = aB[SA * j]; r[j][3] = bB[SB * j]; r[j][4] = aC[SA * j]; r[j][5] = bC[SB * j]; }
-#pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-        if (kk + PF < NK) {
-            const int j = (kk + PF) % (PF + 1);
-            r[j][0] = aA[SA * (kk + PF)]; r[j][1] = bA[SB * (kk + PF)]; r[j][2] = aB[SA * (kk + PF)]; r[j][3] = bB[SB * (kk + PF)];
-            r[j][4] = aC[SA * (kk + PF)]; r[j][5] = bC[SB * (kk + PF)];
-        }
-        const int c = kk % (PF + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        cA = mf(r[c][0], r[c][1], cA);
-        cB = mf(r[c][2], r[c][3], cB);
-        cC = mf(r[c][4], r[c][5], cC);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 // NTL MFMA chains that share one operand (A if SHA, else B): 1 + NTL LDS reads per k-step instead of 2·NTL — with all four
 // waves in a product phase the LDS, not the matrix pipe, is what saturates at two reads per MFMA.
@@ -446,7 +394,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             for (int rb = 0; rb < 4; ++rb) acc[rb] = d4{0.0, 0.0, 0.0, 0.0};
             const double *ap = Vs + l15 + LDV * l4;                   // A[i][k] = Vxx[16rb+i, k]
             const double *bp = Fs + l4 + LDK * (16 * wv + l15);       // B[k][j] = F[k, 16c+j]
-            constexpr int PF = DDP_PF2;                               // operands fetched PF k-steps ahead
+            constexpr int PF = 2;                                     // operands fetched PF k-steps ahead (deeper did not help)
             double bq[PF + 1], aq_[PF + 1][4];
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
