@@ -223,6 +223,88 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     }
 }
 
+
+// ---- pendcart, ONE LANE per (trajectory, α) rollout.  In the row kernel above the 16 lanes of a row all evaluate the same
+// sincos (and only 5 of them carry state): with the 6-11 step sizes of a line search there are enough rollouts to give every
+// lane its own — 16x fewer wave-instructions per rollout.  Same arithmetic (system_pendcart.jl:83-89, forward_pass.jl:17-24;
+// K·dx summed in index order).  Operands are prefetched DL steps ahead (a lane's loads are its own 32-byte pieces).
+template <bool POLICY, bool LIMS>
+__global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs a)
+{
+    constexpr int n = 4, DL = 4;
+    const int N = a.N, B = a.B;
+    const long total = (long)B * a.nalpha;
+    long rho = (long)blockIdx.x * DDP_WAVE + threadIdx.x;
+    const bool valid = rho < total;
+    if (!valid) rho = total - 1;
+    const int b = (int)(rho % B), ai = (int)(rho / B);
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    const double alpha = a.alpha[ai];
+    const double *ug = a.u + (size_t)N * b;
+    const double *xg = POLICY ? a.x + (size_t)n * N * b : nullptr;
+    const double *Kg = POLICY ? a.K + (size_t)n * N * b : nullptr;
+    const double *kg = POLICY ? a.k + (size_t)N * b : nullptr;
+    double *xo = a.xnew + (size_t)n * N * rho, *uo = a.unew + (size_t)N * rho;
+    const double lo = LIMS ? a.lims[0] : 0.0, hi = LIMS ? a.lims[1] : 0.0;
+    const double gl = a.g / a.l, h = a.h;
+    struct Ops { double u, k; d2 K0, K1, x0, x1; };
+    auto fetch = [&](int i, Ops &o) {
+        o.u = ug[i];
+        if (POLICY) {
+            o.k = kg[i];
+            o.K0 = *(const d2 *)(Kg + (size_t)n * i); o.K1 = *(const d2 *)(Kg + (size_t)n * i + 2);
+            o.x0 = *(const d2 *)(xg + (size_t)n * i); o.x1 = *(const d2 *)(xg + (size_t)n * i + 2);
+        }
+    };
+    double x0v = a.x0[(size_t)n * b], x1v = a.x0[(size_t)n * b + 1], x2v = a.x0[(size_t)n * b + 2], x3v = a.x0[(size_t)n * b + 3];
+    auto step = [&](int i, const Ops &o, bool advance) {
+        double uu = o.u;
+        if (POLICY) {
+            uu += o.k * alpha;                                           // unew .+= k*α
+            double s = o.K0.x * (x0v - o.x0.x);
+            s += o.K0.y * (x1v - o.x0.y);
+            s += o.K1.x * (x2v - o.x1.x);
+            s += o.K1.y * (x3v - o.x1.y);
+            uu += s;                                                     // unew .+= K*dx
+        }
+        if (LIMS) uu = clampd(uu, lo, hi);
+        if (uu != uu) uu = 0.0;
+        if (act) {
+            *(d2 *)(xo + (size_t)n * i) = d2{x0v, x1v};
+            *(d2 *)(xo + (size_t)n * i + 2) = d2{x2v, x3v};
+            uo[i] = uu;
+        }
+        if (advance) {                                                   // system_pendcart.jl:83-89
+            double sn, cs;
+            sincos(x0v, &sn, &cs);
+            const double f1 = x1v + h * (-gl * sn + uu / a.l * cs - a.d * x1v);
+            const double n0 = x0v + h * x1v, n2 = x2v + h * x3v, n3 = x3v + h * uu;
+            x0v = n0; x1v = f1; x2v = n2; x3v = n3;
+        }
+    };
+    Ops ring[DL];
+#pragma unroll
+    for (int d = 0; d < DL; ++d) fetch(d < N ? d : N - 1, ring[d]);
+    int i0 = 0;
+    for (; i0 + 2 * DL <= N; i0 += DL) {
+#pragma unroll
+        for (int d = 0; d < DL; ++d) {
+            step(i0 + d, ring[d], true);
+            fetch(i0 + d + DL, ring[d]);
+        }
+    }
+    for (; i0 < N; i0 += DL) {
+#pragma unroll
+        for (int d = 0; d < DL; ++d) {
+            const int i = i0 + d;
+            if (i < N) {
+                step(i, ring[d], i < N - 1);
+                fetch(i + DL < N ? i + DL : N - 1, ring[d]);
+            }
+        }
+    }
+}
+
 // ---- per-step cost + its sum: one wave per rollout, lanes over time (costfun of the registered families)
 //   LQ        c_i = .5 x_i'Q x_i + .5 u_i'R u_i                      (src/demo_linear.jl:49, split per step)
 //   pendcart  c_i = .5 ((x_i-goal)'Q(x_i-goal) + R u_i^2), c_{N+1} = .5 (x_N-goal)'Q(x_N-goal)
@@ -321,7 +403,24 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
     a.xnew = xnew; a.unew = unew;
-    int rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1>(h, a);
+    int rc;
+    const char *lane_env = getenv("DDP_FORWARD_LANE");          // 1 / 0 forces the lane-per-rollout pendcart kernel on / off
+    const long total = (long)p->B * nalpha;
+    const bool lane = !lq && (lane_env ? lane_env[0] == '1' : total >= 3L * 4096);       // at least ~3 rollouts per lane of a row kernel wave
+    if (lane) {
+        const dim3 grid((unsigned)((total + DDP_WAVE - 1) / DDP_WAVE)), block(DDP_WAVE);
+        const int key = (a.has_policy ? 2 : 0) | (a.has_lims ? 1 : 0);
+        switch (key) {
+        case 0: hipLaunchKernelGGL((forward_lane_pendcart_kernel<false, false>), grid, block, 0, h->stream, a); break;
+        case 1: hipLaunchKernelGGL((forward_lane_pendcart_kernel<false, true>), grid, block, 0, h->stream, a); break;
+        case 2: hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, false>), grid, block, 0, h->stream, a); break;
+        case 3: hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, true>), grid, block, 0, h->stream, a); break;
+        }
+        DDP_HIP(hipGetLastError());
+        rc = 0;
+    } else {
+        rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1>(h, a);
+    }
     if (rc) return rc;
     CostArgs c;
     c.kind = p->kind; c.n = p->n; c.m = p->m; c.N = p->N; c.B = p->B; c.nalpha = nalpha; c.Q = p->Q; c.R = p->R;

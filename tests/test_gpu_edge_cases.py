@@ -304,3 +304,29 @@ def test_long_unstable_horizon_error_does_not_grow(ddp, monkeypatch, impl, n, m)
             d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], cxx, cxu, cuu, fx, fu, lam[b], regType, None, None, np.zeros((m, N)))
             assert div[b] == d == 0
             assert relerr(pol.K[..., b], K) < 1e-10 and relerr(Vxx[..., b], vxx) < 1e-10 and relerr(Vx[..., b], vx) < 1e-10
+
+
+@pytest.mark.parametrize("lane", ["0", "1"])                       # 16-lane row per rollout | one lane per rollout (line searches)
+@pytest.mark.parametrize("lims", [False, True])
+def test_pendcart_rollout_kernels(ddp, monkeypatch, lane, lims):
+    from oracle import oracle_ctypes as oc
+    monkeypatch.setenv("DDP_FORWARD_LANE", lane)
+    rng = np.random.default_rng(77)
+    N, B = 67, 70                                                   # partial last wave in both kernels
+    prob = ddp.PendcartProblem()
+    L = np.array([[-2.0, 2.5]]) if lims else None
+    x0 = np.array([np.pi - 0.6, 0, 0, 0])[:, None] + 0.2 * rng.standard_normal((4, B))
+    u = 1.5 * rng.standard_normal((1, N, B))
+    xnom = np.array([np.pi, 0, 0, 0])[:, None, None] + 0.3 * rng.standard_normal((4, N, B))
+    K = 0.3 * rng.standard_normal((1, 4, N, B)); k = 0.2 * rng.standard_normal((1, N, B))
+    alphas = np.array([1.0, 0.5, 0.1])
+    pend = dict(g=prob.g, l=prob.l, h=prob.h, d=prob.d, goal=prob.goal)
+    p = oc.make_problem("pendcart", 4, 1, N, Q=prob.Q, R=prob.R, pend=pend)
+    xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(N, 4, 1, K, k), x0, u, xnom, alphas, prob, L)
+    x1, u1, c1 = ddp.forward_pass(None, x0, u, None, 1.0, prob, L)                 # open loop (initial rollout)
+    for b in range(0, B, 7):
+        for j, a in enumerate(alphas):
+            xr, ur, cr = oc.forward_pass(p, (K[..., b], k[..., b]), x0[:, b], u[..., b], xnom[..., b], float(a), L)
+            assert relerr(xn[..., b, j], xr) < RTOL and relerr(un[..., b, j], ur) < RTOL and relerr(cn[..., b, j], cr) < RTOL
+        xr, ur, cr = oc.forward_pass(p, None, x0[:, b], u[..., b], None, 1.0, L)
+        assert relerr(x1.reshape(4, N, B)[..., b], xr) < RTOL and relerr(c1.reshape(-1, B)[:, b], cr) < RTOL
