@@ -207,41 +207,55 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
         iters[idx] = it
         # back_pass until the KL-regularised Quu is positive definite everywhere (:95-122); each trajectory owns its η
         pend = idx.copy()
-        res = {}
         guard = 0
+        allB = idx.size == B                                   # nothing to gather or scatter while every trajectory is live
+        acc = None                                             # results of this iteration, indexed like `idx`
+        pos = np.full(B, -1); pos[idx] = np.arange(idx.size)
         while pend.size:
-            sub = lambda a: a[..., pend]                                                                        # noqa: E731
+            whole = pend.size == B
+            sub = (lambda a: a) if whole else (lambda a: a[..., pend])                                          # noqa: E731
             div, pol, Vx, Vxx, dV = back_pass_gps(sub(cx), sub(cu), cxx if cxx.ndim == 3 else sub(cxx), cxu if cxu.ndim == 3 else sub(cxu),
                                                   cuu if cuu.ndim == 3 else sub(cuu), fx if fx.ndim == 3 else sub(fx),
                                                   fu if fu.ndim == 3 else sub(fu), lims, sub(x), sub(u),
                                                   (tuple(sub(a) for a in kl), etab[:, pend]), handle=h)
             nback[pend] += 1
-            for j, b in enumerate(pend):
-                if div[j] == 0:
-                    res[b] = (pol.K[..., j], pol.k[..., j], pol.Σ[..., j], pol.Σi[..., j], Vx[..., j], Vxx[..., j], dV[:, j])
-            bad = pend[div > 0]
+            good = div == 0
+            got = (pol.K, pol.k, pol.Σ, pol.Σi, Vx, Vxx, dV)
+            if acc is None and good.all() and pend.size == idx.size:
+                acc = list(got)                                # the common case: one back pass, no copies
+            else:
+                if acc is None:
+                    acc = [np.zeros(a_.shape[:-1] + (idx.size,), order="F") for a_ in got]
+                tgt = pos[pend[good]]
+                for dst, src in zip(acc, got):
+                    dst[..., tgt] = src[..., good]
+            bad = pend[~good]
             etab[1, bad] += del0[bad]                                                                            # :103-105
             del0[bad] *= 2
             pend = bad
             guard += 1
             if guard > 200:
                 raise RuntimeError("back_pass_gps keeps diverging (the reference would loop forever)")
-        st = lambda q: np.stack([res[b][q] for b in idx], axis=-1)                                              # noqa: E731
-        new = GaussianPolicy(N, n, m, st(0), st(1), st(2), st(3))
-        sel = lambda a: a[..., idx]                                                                             # noqa: E731
-        pb = _SubProblem(problem, idx, B)
-        xnew, unew, cnew = forward_pass(new, sel(x)[:, 0, :], sel(u), sel(x), 1.0, pb, lims, handle=h)          # :132
-        mdl = Model(model.fx if np.ndim(model.fx) == 3 else model.fx[..., idx], model.fu, model.R1)
-        sig = forward_covariance(mdl, sel(x), sel(u), new, handle=h)                                            # :133
-        pv = GaussianPolicy(N, n, m, sel(prev0.K), sel(prev0.k), sel(prev0.Σ), sel(prev0.Σi))
-        _, mean = _kl_div(xnew, sel(x), sig, new, pv, h)
+        new = GaussianPolicy(N, n, m, acc[0], acc[1], acc[2], acc[3])
+        sel = (lambda a: a) if allB else (lambda a: a[..., idx])                                                # noqa: E731
+        pb = problem if allB else _SubProblem(problem, idx, B)
+        xs = sel(x)
+        xnew, unew, cnew = forward_pass(new, xs[:, 0, :], sel(u), xs, 1.0, pb, lims, handle=h)                  # :132
+        mdl = Model(model.fx if (np.ndim(model.fx) == 3 or allB) else model.fx[..., idx], model.fu, model.R1)
+        sig = forward_covariance(mdl, xs, sel(u), new, handle=h)                                                # :133
+        pv = prev0 if allB else GaussianPolicy(N, n, m, sel(prev0.K), sel(prev0.k), sel(prev0.Σ), sel(prev0.Σi))
+        _, mean = _kl_div(xnew, xs, sig, new, pv, h)
         if out is None:
             out = dict(x=np.zeros((n, N, B)), u=np.zeros((m, N, B)), K=np.zeros((m, n, N, B)), S=np.zeros((m, m, N, B)),
                        Si=np.zeros((m, m, N, B)), Vx=np.zeros((n, N, B)), Vxx=np.zeros((n, n, N, B)), cost=np.zeros((cnew.shape[0], B)),
                        dV=np.zeros((2, B)))
-        out["x"][..., idx], out["u"][..., idx], out["cost"][..., idx] = xnew, unew, cnew
-        out["K"][..., idx], out["S"][..., idx], out["Si"][..., idx] = new.K, new.Σ, new.Σi
-        out["Vx"][..., idx], out["Vxx"][..., idx], out["dV"][..., idx] = st(4), st(5), st(6)
+        if allB:
+            out.update(x=xnew.reshape(n, N, B), u=unew.reshape(m, N, B), cost=cnew.reshape(-1, B), K=new.K, S=new.Σ, Si=new.Σi,
+                       Vx=acc[4], Vxx=acc[5], dV=acc[6])
+        else:
+            out["x"][..., idx], out["u"][..., idx], out["cost"][..., idx] = xnew.reshape(n, N, -1), unew.reshape(m, N, -1), cnew.reshape(-1, idx.size)
+            out["K"][..., idx], out["S"][..., idx], out["Si"][..., idx] = new.K, new.Σ, new.Σi
+            out["Vx"][..., idx], out["Vxx"][..., idx], out["dV"][..., idx] = acc[4], acc[5], acc[6]
         for j, b in enumerate(idx):                                                                             # :141, :169-177
             eb, sat, dv = calc_η(None, None, None, etab[:, b], None, None, kl_step, _mean=mean[j])
             etab[:, b] = eb
