@@ -200,6 +200,11 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
     divergence = np.zeros(B); satisfied = np.zeros(B, dtype=bool)
     live = np.ones(B, dtype=bool)
     out = None
+    import os as _os
+    if _os.environ.get("DDP_KL_HOSTLOOP") != "1":
+        out = _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u, (cx, cu, cxx, cxu, cuu, fx, fu), kl, dynb,
+                                  etab, del0, status, iters, nback, divergence, satisfied, live)
+        max_iter = 0                                           # the host-array loop below is the reference for tests (DDP_KL_HOSTLOOP=1)
     for it in range(1, max_iter + 1):                                                                           # :91
         idx = np.flatnonzero(live)
         if idx.size == 0:
@@ -273,6 +278,100 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
         return out["x"][..., 0], out["u"][..., 0], traj_new, out["Vx"][..., 0], out["Vxx"][..., 0], out["cost"][..., 0], trace
     return out["x"], out["u"], traj_new, out["Vx"], out["Vxx"], out["cost"], trace
 
+
+
+def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u, derivs, kl, dynb, etab, del0, status, iters, nback,
+                        divergence, satisfied, live):
+    """The iteration of iLQGkl (iLQGkl.jl:91-178) with every array resident on the device: per iteration only η[B] goes up and
+    diverge[B], mean KL[B] come down.  Each pass recomputes ALL trajectories with their current η — a trajectory that has
+    already met its constraint keeps its η, so it is recomputed to the same result and the final arrays are right for everyone
+    (the host-array loop, DDP_KL_HOSTLOOP=1, gathers the live ones instead and moved ~1.5 GB over PCIe per pass at B = 4096)."""
+    L_ = _lib.lib()
+    n, N, B = x.shape
+    m = u.shape[0]
+    cx, cu, cxx, cxu, cuu, fx, fu = derivs
+    bufs = []
+
+    def up(a):
+        p_ = h.to_device(_lib.f64(a)); bufs.append(p_); return p_
+
+    def dev(shape, dtype=np.float64):
+        p_ = h.malloc(int(np.prod(shape)) * np.dtype(dtype).itemsize); bufs.append(p_); return p_
+    try:
+        d_cx, d_cu, d_cxx, d_cxu, d_cuu, d_fx, d_fu = map(up, (cx, cu, cxx, cxu, cuu, fx, fu))
+        d_kl = [up(a) for a in kl]
+        d_x, d_u, d_x0 = up(x), up(u), up(x[:, 0, :])
+        d_pK, d_pk, d_pS, d_pSi = up(prev0.K), up(prev0.k), up(prev0.Σ), up(prev0.Σi)
+        mfx = _lib.f64(model.fx)
+        d_mfx, d_R1 = (d_fx if mfx is fx else up(mfx)), up(model.R1)
+        Lh = _lims(lims)
+        d_L = up(Lh) if Lh is not None else None
+        d_eta = dev((B,))
+        d_K, d_k, d_Quu, d_Quui = dev((m, n, N, B)), dev((m, N, B)), dev((m, m, N, B)), dev((m, m, N, B))
+        d_Vx, d_Vxx, d_dV, d_div = dev((n, N, B)), dev((n, n, N, B)), dev((2, B)), dev((B,), np.int32)
+        # registered problem with device-resident parameters
+        P = _lib.Problem()
+        P.kind, P.n, P.m, P.N, P.B = problem.kind, n, m, N, B
+        P.Q, P.R = up(problem.Q), up(np.atleast_2d(problem.R))
+        if problem.kind == 0:
+            P.A, P.Bm = up(problem.A), up(problem.B)
+            P.dyn_tv, P.dyn_batched = int(problem.dyn_tv), int(problem.dyn_batched)
+        else:
+            P.g, P.l, P.h, P.d = problem.g, problem.l, problem.h, problem.d
+            for i in range(4):
+                P.goal[i] = float(problem.goal[i])
+        CL = N + 1 if problem.kind == 1 else N
+        d_xn, d_un, d_cn, d_cs = dev((n, N, B)), dev((m, N, B)), dev((CL, B)), dev((B,))
+        d_sig, d_kld, d_klm = dev((n + m, n + m, N, B)), dev((N, B)), dev((B,))
+        desc = _lib.BPDesc(n, m, N, B, 1, int(fx.ndim == 4), 1, int(cxx.ndim == 4), 1, int(Lh is not None))
+        terms = _lib.KLCostTerms(*d_kl, d_eta, 0)
+        one = np.array([1.0])
+        eta_h = np.zeros(B)
+        for it in range(1, max_iter + 1):                                                                       # :91
+            idx = np.flatnonzero(live)
+            if idx.size == 0:
+                break
+            iters[idx] = it
+            pend = live.copy()
+            guard = 0
+            while True:                                        # back passes until the regularised Quu is positive definite (:95-122)
+                eta_h[:] = etab[1]
+                _lib.check(L_.ddp_memcpy_h2d(h.raw, d_eta, _lib.ptr(eta_h), _C.c_size_t(eta_h.nbytes)))
+                _lib.check(L_.ddp_back_pass_gps_f64_dev(h.raw, _C.byref(desc), d_cx, d_cu, d_cxx, d_cxu, d_cuu, d_fx, d_fu, _C.byref(terms),
+                                                        d_L, d_u, None, d_K, d_k, d_Quu, d_Quui, d_Vx, d_Vxx, d_dV, d_div))
+                div = h.to_host(d_div, (B,), np.int32)
+                nback[pend] += 1
+                bad = pend & (div > 0)
+                if not bad.any():
+                    break
+                etab[1, bad] += del0[bad]                                                                        # :103-105
+                del0[bad] *= 2
+                pend = bad
+                guard += 1
+                if guard > 200:
+                    raise RuntimeError("back_pass_gps keeps diverging (the reference would loop forever)")
+            _lib.check(L_.ddp_forward_pass_f64_dev(h.raw, _C.byref(P), d_K, d_k, d_x0, d_u, d_x, _lib.ptr(one), 1, d_L, None,
+                                                   d_xn, d_un, d_cn, d_cs))                                     # :132
+            _lib.check(L_.ddp_forward_covariance_f64_dev(h.raw, n, m, N, B, d_mfx, int(mfx.ndim == 4), d_R1, d_K, d_Quui, d_sig))   # :133
+            _lib.check(L_.ddp_kl_div_f64_dev(h.raw, n, m, N, B, d_xn, d_x, d_sig, d_K, d_k, d_Quui, d_pK, d_pk, d_pS, d_pSi, d_kld, d_klm))
+            mean = h.to_host(d_klm, (B,))
+            for b in idx:                                                                                       # :141, :169-177
+                eb, sat, dv = calc_η(None, None, None, etab[:, b], None, None, kl_step, _mean=mean[b])
+                etab[:, b] = eb
+                divergence[b], satisfied[b] = dv, sat
+                if sat:
+                    status[b], live[b] = 1, False
+                elif etab[1, b] > 0.999 * etab[2, b]:
+                    status[b], live[b] = 2, False
+        return dict(x=h.to_host(d_xn, (n, N, B)), u=h.to_host(d_un, (m, N, B)), cost=h.to_host(d_cn, (CL, B)), K=h.to_host(d_K, (m, n, N, B)),
+                    S=h.to_host(d_Quui, (m, m, N, B)), Si=h.to_host(d_Quu, (m, m, N, B)), Vx=h.to_host(d_Vx, (n, N, B)),
+                    Vxx=h.to_host(d_Vxx, (n, n, N, B)), dV=h.to_host(d_dV, (2, B)))
+    finally:
+        for p_ in bufs:
+            try:
+                h.free(p_)
+            except Exception:
+                pass
 
 def _tv(a, N, batched=False):
     """give a [r,c] (or, batched, [r,c,B]) array the time axis back_pass_gps wants: [r,c,N] / [r,c,N,B]"""

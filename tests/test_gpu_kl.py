@@ -99,7 +99,13 @@ def test_ilqgkl_golden(ddp, tag):
     assert np.array_equal(prev.k, g["u"])                                 # traj_prev.k restored (iLQGkl.jl:247)
 
 
-def test_ilqgkl_batch_independent_eta(ddp):
+@pytest.mark.parametrize("hostloop", ["0", "1"])     # device-resident loop | the host-array loop it replaced (kept as cross-check)
+def test_ilqgkl_batch_independent_eta(ddp, monkeypatch, hostloop):
+    monkeypatch.setenv("DDP_KL_HOSTLOOP", hostloop)
+    _ilqgkl_batch_independent_eta(ddp)
+
+
+def _ilqgkl_batch_independent_eta(ddp):
     """a batch of KL-constrained solves: every trajectory runs its own η bracket and matches its own oracle solve"""
     from oracle import oracle_ctypes as oc
     import scipy.linalg as sla
