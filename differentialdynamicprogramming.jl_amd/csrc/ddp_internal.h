@@ -57,6 +57,12 @@ int ddp_launch_back_pass_gps(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const double *fu, const ddp_kl_cost_terms *kl, const double *lims, const double *u,
                              const int32_t *active, double *K, double *k, double *Quu, double *Quui, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge);
+// one lane per trajectory (n = 4, m <= 2); returns 1 when the shape is not handled
+int ddp_launch_back_pass_gps_lane(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const ddp_kl_cost_terms *kl, const double *lims, const double *u,
+                             const int32_t *active, double *K, double *k, double *Quu, double *Quui, double *Vx,
+                             double *Vxx, double *dV, int32_t *diverge);
 // LDS-lean kernel for the unconstrained m=2 shapes; returns 1 when the shape has no fast kernel
 int ddp_launch_back_pass_fast(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                               const double *cxx, const double *cxu, const double *cuu, const double *fx,

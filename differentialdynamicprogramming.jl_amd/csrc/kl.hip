@@ -5,6 +5,7 @@
 // plus the C-ABI entry points of the four KL calls (the back_pass_gps kernel itself is the GPS variant of back_pass.hip).
 // None of this is on the benchmarked path; the kernels are written for clarity and coalescing, not tuned.
 #include "arena.h"
+#include <stdlib.h>
 #include "ddp_internal.h"
 
 namespace {
@@ -229,6 +230,11 @@ int ddp_back_pass_gps_f64_dev(ddp_handle h, const ddp_bp_desc *d,
     DDP_CHECK(h && d && cx && cu && cxx && cxu && cuu && fx && fu && kl && K && k && Quu && Quui && Vx && Vxx && dV && diverge,
               "back_pass_gps: null argument");
     DDP_HIP(hipMemsetAsync(Quui, 0, sizeof(double) * (size_t)d->m * d->m * d->N * d->B, h->stream));
+    const char *env = getenv("DDP_GPS_LANE");                     // 0: always the run-time-sized kernel (cross-check in the tests)
+    if (!(env && env[0] == '0') && kl && kl->cx && kl->cu && kl->cxx && kl->cxu && kl->cuu && kl->eta && (!d->has_lims || (lims && u))) {
+        const int rc = ddp_launch_back_pass_gps_lane(h, d, cx, cu, cxx, cxu, cuu, fx, fu, kl, lims, u, active, K, k, Quu, Quui, Vx, Vxx, dV, diverge);
+        if (rc <= 0) return rc;
+    }
     return ddp_launch_back_pass_gps(h, d, cx, cu, cxx, cxu, cuu, fx, fu, kl, lims, u, active, K, k, Quu, Quui, Vx, Vxx, dV, diverge);
 }
 

@@ -23,8 +23,10 @@ def _lims(g):
     return None if g["lims"].size == 0 else g["lims"]
 
 
+@pytest.mark.parametrize("lane", ["1", "0"])         # n=4: one lane per trajectory | the run-time-sized kernel for every shape
 @pytest.mark.parametrize("name", GPS)
-def test_gps_chain_golden(ddp, name):
+def test_gps_chain_golden(ddp, monkeypatch, name, lane):
+    monkeypatch.setenv("DDP_GPS_LANE", lane)
     kl = ddp.kl
     g = load_golden(name)
     N = g["u"].shape[1]
