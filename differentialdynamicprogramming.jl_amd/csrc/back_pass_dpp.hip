@@ -71,6 +71,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
     if (!valid) tb = a.B - 1;                                   // all lanes stay alive (DPP reads every lane)
     const int b = (int)tb;
     const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;                                    // nothing to do for this wave (trajectories of a batch finish at different iterations)
     const bool inx = j < n, inu = j >= n && j < p, ink = j == p;   // column roles: x-columns, u-columns, spare lane (stores k)
     const int jx = inx ? j : 0, jc = j < p ? j : 0, ja = inu ? j - n : 0;
 

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     if (!valid) rho = total - 1;                                // keep all lanes alive (DPP reads every lane)
     const int b = (int)(rho % B), ai = (int)(rho / B);
     const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;                                    // every rollout of this wave belongs to a finished trajectory
     const double alpha = a.alpha[ai];
     const bool inx = j < n, inu = j < m;
     const int jx = inx ? j : 0, ju = inu ? j : 0;
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
     if (!valid) rho = total - 1;
     const int b = (int)(rho % B), ai = (int)(rho / B);
     const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;                                    // every rollout of this wave belongs to a finished trajectory
     const double alpha = a.alpha[ai];
     const double *ug = a.u + (size_t)N * b;
     const double *xg = POLICY ? a.x + (size_t)n * N * b : nullptr;
