@@ -237,10 +237,12 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
-    worst = 0.0
+    worst, at = 0.0, -1
     for c in range(cases):
-        worst = max(worst, one_case(ddp, oc, np.random.default_rng([seed, c]), c))          # every case reproducible on its own
-    print("fuzz: %d cases passed, worst relative error %.3g" % (cases, worst))
+        e = one_case(ddp, oc, np.random.default_rng([seed, c]), c)          # every case reproducible on its own
+        if e > worst:
+            worst, at = e, c
+    print("fuzz: %d cases passed, worst relative error %.3g (case %d: `--cond %d %d` shows its conditioning)" % (cases, worst, at, seed, at))
     worst = 0.0
     for c in range(cases // 10):
         worst = max(worst, ilqg_case(ddp, oc, rng, c))
