@@ -1,0 +1,50 @@
+#!/bin/bash
+# Evidence for one non-headline config (C3 / C4) in ONE gpurun call: un-profiled HIP-event pass time, rocprofv3 kernel statistics,
+# HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc passes) and SQ counters of the backward kernel.
+#   bash profiles/pmc_config.sh <tag> <c3|c4> <kernel-substring> [ENV=VAL ...]
+# Output: gpurun_out/<tag>/summary.txt (copy into profiles/ to have it judged)
+set -u
+TAG=$1; CFG=$2; KSUB=$3; shift 3
+for kv in "$@"; do export "$kv"; done
+export DDP_C4_SOLVE=0
+REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
+python profiles/bench_configs.py $CFG > $OUT/events.json 2> $OUT/events.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $REPO/profiles/bench_configs.py $CFG > $OUT/stats.log 2>&1
+P0="FETCH_SIZE"
+P1="WRITE_SIZE"
+P2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"
+P3="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_THREAD_CYCLES_VALU"
+P4="SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM GRBM_GUI_ACTIVE"
+i=0
+for P in "$P0" "$P1" "$P2" "$P3" "$P4"; do
+  timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- python $REPO/profiles/bench_configs.py $CFG > $OUT/p$i.log 2>&1
+  i=$((i+1))
+done
+cd $REPO
+python - "$OUT" "$KSUB" "$CFG" > $OUT/summary.txt <<'PY'
+import csv, glob, json, os, sys, collections
+root, ksub, cfg = sys.argv[1:4]
+print("# config %s, kernel substring %r" % (cfg, ksub))
+print("## un-profiled HIP-event pass times (profiles/bench_configs.py)")
+print(open(os.path.join(root, "events.json")).read().strip())
+print("## rocprofv3 --kernel-trace --stats (top kernels)")
+for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for i, row in enumerate(csv.DictReader(open(f))):
+        if i < 8 or ksub in row["Name"]:
+            print("  %-110s calls %4s avg %12.1f ns" % (row["Name"][:110], row["Calls"], float(row["AverageNs"])))
+acc = collections.defaultdict(list)
+for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if ksub in row["Kernel_Name"]:
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+print("## PMC, mean per launch of kernels matching %r" % ksub)
+for c, v in sorted(acc.items()):
+    print("  %-26s %18.1f (n=%d)" % (c, sum(v) / len(v), len(v)))
+if "FETCH_SIZE" in acc and "WRITE_SIZE" in acc:
+    fs = sum(acc["FETCH_SIZE"]) / len(acc["FETCH_SIZE"]); ws = sum(acc["WRITE_SIZE"]) / len(acc["WRITE_SIZE"])
+    print("## HBM traffic per launch: FETCH_SIZE KiB x1024 x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB x1024 = %.1f MB"
+          % ((2 * fs + ws) * 1024 / 1e6))
+PY
+cat $OUT/summary.txt
+find $OUT -name "*kernel_trace.csv" -size +4M -delete
