@@ -639,11 +639,15 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     //           batch gives every SIMD a few wavefronts; also the kernel for control limits;
     //   fast    64 lanes per trajectory, LDS-lean vector kernel (back_pass_fast.hip; n=10, m=2, no limits);
     //   general 64 lanes per trajectory, any n <= 32 / m <= 8 / limits (this file).
-    // DDP_BACKPASS=x|general|fast|dpp|big forces one (A/B timing, tests of every code path).
+    // DDP_BACKPASS=x|q|general|fast|dpp|big forces one (A/B timing, tests of every code path).
     const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
     if (force == 'x' || (force == 0 && d->B < 5120)) {
         const int rc = ddp_launch_back_pass_mx(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) return rc;
+    }
+    if (force == 'q' || force == 0) {                             // n = 4, m = 1: one trajectory per 4x4x4 MFMA block
+        const int rc = ddp_launch_back_pass_q4(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;
     }
     if (force != 'g' && force != 'b') {

@@ -1,0 +1,442 @@
+// back_pass_q4.hip — backward pass for n = 4, m = 1 (the pendulum on a cart of BASELINE configs 3 and 5) on the fp64
+// matrix cores: ONE TRAJECTORY PER BLOCK of v_mfma_f64_4x4x4_4b, four trajectories per wavefront, every 4x4 matrix of a
+// Riccati step held as ONE element per lane.  Same arithmetic as src/backward_pass.jl:162-252 + :28-79 (all three rank
+// dispatches: time-invariant operands are read with stride 0).
+//
+// Layout L: element [r][c] of a trajectory's matrix lives in lane 16 r + 4 b + c of a register (b = block = trajectory of the
+// wave).  This is the D layout of the instruction; a register used as the B operand is read as it is, as the A operand it is
+// read TRANSPOSED (profiles/microbench/mfma_4x4x4_layout_probe.hip, mfma_4x4x4_chain_probe.hip):
+//        mm(X, Y, C) = X'·Y + C        per block, result in layout L again.
+// Vectors are kept REPLICATED: "column form" v_c (lane [i][.] holds v[i]) and "row form" v_r (lane [.][j] holds v[j]); a
+// replicated vector is a matrix with equal columns (rows), so matrix-vector products are the same instruction and deliver
+// their result in every lane that needs it — no broadcast, no select, no data movement between lanes in the whole step:
+//        W    = mm(V', fx)              = Vxx·fx                        W2 = mm(V, fu_c) = Vxx'·fu  (column form)
+//        Qxx  = mm(fx, W, cxx)          = cxx + fx'Vxx fx               Qxx' = mm(W, fx, cxx') (bitwise the transpose)
+//        Quu  = mm(fu_c, W2, cuu)       (every lane)                    Qu   = mm(fu_c, Vx_c, cu)      (every lane)
+//        Qux_c = mm(fx, W2, cxu_c)      Qux_r = mm(W2, fx, cxu_r)       Qx_c = mm(fx, Vx_c, cx_c)
+//        regType 2: fx'fu (both forms) and fu'fu by three products that do not depend on Vxx (off the chain)
+//        gains: scalar (m = 1), every lane computes them; boxQP is a straight-line restatement of the first two
+//               projected-Newton iterations of boxQP.jl:58-169 (where the m = 1 problem ends unless the Armijo search has to
+//               back off or rounding leaves a gradient above minGrad) with the generic loop (boxqp_dev1) as the fall-back
+//        value: P = Qxx + K_c∘T_r + T_c∘K_r  elementwise (T = Qux + ½Quu·K: K T' + T K' = K'QuuK + K'Qux + Qux'K, :70),
+//               P' likewise from Qxx', Vxx_i = ½(P + P') exactly symmetric (:71-72).
+// 9 (regType 2: 12) matrix instructions and ~90 vector instructions per step of FOUR trajectories; the 16-lane DPP-row
+// kernel this replaces for the shape (back_pass_dpp.hip) issued ~280 vector + ~130 scalar instructions, most of them the
+// divergent generic boxQP loop (profiles/r02_c3_baseline_pmc.txt).
+//
+// Memory: at one wave per SIMD the kernel is bound by the NUMBER of vector-memory instructions (the address unit of a CU takes
+// ~16 cycles per wave instruction and is shared by its four SIMDs; measured: the first version with 9 loads + 2 stores per
+// step ran 0.82 ms, 0.39 ms with the memory instructions removed).  back_pass_q4p_kernel therefore works on PAIRS of time
+// steps: rows 0, 2 of a block load the 16-byte pair {M[r], M[r+1]} of step 2j+1 while rows 1, 3 load {M[r-1], M[r]} of step
+// 2j, and one v_permlane16_swap per dword turns the two halves into the two matrices; results go back the same way
+// (Vxx_i pairs; K_i, Vx_i, k_i, Quu_i merged into ONE 16-byte store): 3.5 memory instructions per step.  It needs an even
+// horizon N (16-byte alignment of the [1,N] arrays) and time-invariant cost; back_pass_q4_kernel (one step at a time, any
+// N, time-varying cost) covers the rest.
+#include <stdlib.h>
+#include "ddp_internal.h"
+#include "boxqp_dev.h"
+
+namespace {
+
+struct Q4Args {
+    int N, B;
+    int regType;
+    // element strides (doubles): per time step (0 when time-invariant) and per trajectory (0 when shared)
+    int fx_t, fu_t, cxx_t, cxu_t, cuu_t;
+    long fx_b, fu_b, cxx_b, cxu_b, cuu_b;
+    const double *cx, *cu, *cxx, *cxu, *cuu, *fx, *fu, *lambda, *lims, *u;
+    const int32_t *active;
+    double *K, *k, *Quu, *Vx, *Vxx, *dV;
+    int32_t *diverge;
+};
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double mm(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+// (a, b) -> (x, y): x = rows [a0, b0, a2, b2], y = rows [a1, b1, a3, b3] of the 16-lane rows (v_permlane16_swap per dword)
+__device__ __forceinline__ void row_swap(double a, double b, double &x, double &y)
+{
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    x = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
+    y = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+}
+
+// First two iterations of boxQP(H,g,lower,upper,x0) for m = 1 (boxQP.jl:58-169) as straight-line code, arithmetic of
+// boxqp_dev1 (boxqp_dev.h).  Decided here: result 6 in the first iteration (x0 clamped, gradient pointing outwards) and, after
+// one accepted full Newton step, results 4, 6, 5 of the second iteration.  Everything else — a non-positive H, a gradient below
+// minGrad at the start, no descent, an Armijo back-off, a third iteration — is `slow` and goes to the generic loop.
+__device__ __forceinline__ void boxqp1_two_iterations(double H, double g, double lower, double upper, double x0, const QPOptsDev &o,
+                                                       double &x, double &rH, bool &clamped, bool &slow)
+{
+    auto val = [&](double xx) { return xx * g + ((0.5 * xx) * H) * xx; };                      // :63
+    const double x1 = ddp_clamp(x0, lower, upper);                                              // :58
+    const double v1 = val(x1);
+    const double grad1 = g + H * x1;                                                            // :85
+    const bool c1 = ((x1 == lower) && (grad1 > 0)) || ((x1 == upper) && (grad1 < 0));          // :92-95 -> result 6 (:98-101)
+    rH = ddp_rcp_nr(H);
+    const double search = -(g * rH) - x1;                                                       // :127-129
+    const double sdotg = search * grad1;                                                        // :132
+    const double xc = ddp_clamp(x1 + search, lower, upper);                                     // step = 1 (:138-141)
+    const double vc = val(xc);
+    // iteration 1 runs to its end with step 1: H > 0 (:111), |grad| >= minGrad (:120), sdotg < 0 (:133), Armijo holds (:142)
+    const bool plain = (H > 0.0) && !(fabs(grad1) < o.minGrad) && (sdotg < 0) && !((vc - v1) > o.Armijo * sdotg);
+    // second iteration
+    const bool relimp = (v1 - vc) < o.minRelImprove * fabs(v1);                                 // result 4 (:78-81), free set of iteration 1
+    const double grad2 = g + H * xc;
+    const bool c2 = ((xc == lower) && (grad2 > 0)) || ((xc == upper) && (grad2 < 0));          // result 6
+    const bool small2 = fabs(grad2) < o.minGrad;                                                // result 5
+    slow = !c1 && !(plain && (relimp || c2 || small2));
+    x = c1 ? x1 : xc;
+    clamped = c1 || (!relimp && c2);
+}
+
+struct Q4In { double fx, fu, cx, cu, u, cxx, cxxT, cxuc, cxur, cuu; };    // operands of one step (layout L / column / row forms)
+struct Q4State { double V, VT, vxc, kprev, dV0, dV1; int diverge; };        // Vxx_{i+1} (and transposed), Vx_{i+1} column form
+struct Q4Out { double Vn, Kc, vx, kk, Quu; };
+struct Q4Par { double lam, limlo, limhi; bool nolims; };
+
+template <bool LIMS, bool REG2, int EXP>
+__device__ __forceinline__ void q4_step(int i, const Q4In &o, Q4State &s, Q4Out &out, const Q4Par &p)
+{
+    const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};                                   // boxQP.jl:30-35
+    // ---- products that do not depend on Vxx (regType 2: Vxx_reg = Vxx + λI adds λ·fu'fx, λ·fu'fu; :245-247)
+    double Fc = 0.0, Fr = 0.0, ff = 0.0;
+    if (REG2) {
+        Fc = mm(o.fx, o.fu, 0.0);                               // (fx'fu)[i], column form
+        Fr = mm(o.fu, o.fx, 0.0);                               // (fu'fx)[j], row form
+        ff = mm(o.fu, o.fu, 0.0);                               // fu'fu
+    }
+    // ---- Q-function expansion (:165-169 / :203-210 / :240-244)
+    const double Qu = mm(o.fu, s.vxc, o.cu);
+    const double Qxc = mm(o.fx, s.vxc, o.cx);
+    const double W2 = mm(s.V, o.fu, 0.0);                       // Vxx'·fu: (fu'Vxx)' in column form
+    const double W = mm(s.VT, o.fx, 0.0);                       // Vxx·fx
+    const double Quu = mm(o.fu, W2, o.cuu);
+    const double Quxc = mm(o.fx, W2, o.cxuc);
+    const double Quxr = mm(W2, o.fx, o.cxur);
+    const double Qxx = mm(o.fx, W, o.cxx);
+    const double QxxT = mm(W, o.fx, o.cxxT);
+    const double QuuF = Quu + (REG2 ? p.lam * ff : p.lam);    // :247
+    const double Qrc = Quxc + (REG2 ? p.lam * Fc : 0.0);      // Qux_reg, both forms (:246)
+    const double Qrr = Quxr + (REG2 ? p.lam * Fr : 0.0);
+    // ---- gains (:31-61), scalar system
+    double kk, rH;
+    bool clamped = false, fail;
+    if (!LIMS || p.nolims || (EXP & 4)) {
+        fail = !(QuuF > 0.0);                                   // cholesky(Hermitian(QuuF)) (:35)
+        rH = ddp_rcp_nr(QuuF);
+        kk = -(Qu * rH);                                        // k_i = -(R\Qu) (:41)
+    } else {
+        const double lo = p.limlo - o.u, up = p.limhi - o.u;    // :45-46
+        bool slow;
+        boxqp1_two_iterations(QuuF, Qu, lo, up, s.kprev, qpo, kk, rH, clamped, slow);     // :49 (warm start k[:, min(i+1,N-1)])
+        fail = false;
+        if (__builtin_expect(slow && s.diverge == 0, 0)) {                           // rare: the generic loop decides
+            unsigned cl; int iters;
+            const int result = boxqp_dev1(QuuF, Qu, lo, up, s.kprev, qpo, kk, rH, cl, iters);
+            clamped = (cl & 1u) != 0u;
+            fail = result < 1;                                  // :53
+        }
+    }
+    const bool alive = s.diverge == 0 && !fail;
+    if (s.diverge == 0 && fail) s.diverge = i + 1;              // :37-38, :54-55
+    const double nrH = clamped ? 0.0 : -rH;
+    const double Kc = Qrc * nrH, Kr = Qrr * nrH;                // K_i = -(R\Qux_reg), clamped rows zero (:42, :57-61)
+    // ---- value update (:64-72)
+    const double Quuk = Quu * kk;
+    s.dV0 += alive ? kk * Qu : 0.0;                             // :68
+    s.dV1 += alive ? (0.5 * kk) * Quuk : 0.0;
+    const double vx = Qxc + Kc * (Quuk + Qu) + Quxc * kk;       // :69
+    const double hQ = 0.5 * Quu;
+    const double Tc = Quxc + hQ * Kc, Tr = Quxr + hQ * Kr;      // K T' + T K' = K'QuuK + K'Qux + Qux'K
+    const double P = Kc * Tr + (Tc * Kr + Qxx);                 // :70
+    const double Pt = Kr * Tc + (Tr * Kc + QxxT);               // the same sums for the transposed element
+    const double Vn = 0.5 * (P + Pt);                           // :71-72
+    out.Vn = Vn; out.Kc = Kc; out.vx = vx; out.kk = kk; out.Quu = Quu;
+    s.V = Vn; s.VT = Vn; s.vxc = vx; s.kprev = kk;
+}
+
+// outputs earlier in time than a failing step are zero (backward_pass.jl:37-38 with :226-229); Quu of the failing step itself
+// stays (assigned before the failure), earlier Quu is `undef` upstream, zero here.  The 16 lanes of a block share the work.
+__device__ __forceinline__ void q4_zero_fill(const Q4Args &a, int b, int q16, int diverge)
+{
+    const int N = a.N;
+    const size_t ie = (size_t)diverge;                          // = failing 0-based step + 1
+    double *Kg = a.K + (size_t)4 * N * b, *kg = a.k + (size_t)N * b, *Vxg = a.Vx + (size_t)4 * N * b,
+           *Vxx0 = a.Vxx + (size_t)16 * N * b, *Quug = a.Quu + (size_t)N * b;
+    for (size_t t = q16; t < 4 * ie; t += 16) { Kg[t] = 0.0; Vxg[t] = 0.0; }
+    for (size_t t = q16; t < ie; t += 16) kg[t] = 0.0;
+    for (size_t t = q16; t < 16 * ie; t += 16) Vxx0[t] = 0.0;
+    for (size_t t = q16; t + 1 < ie; t += 16) Quug[t] = 0.0;
+}
+
+// ---- one time step at a time: any N, time-varying cost (CTV) or not
+template <bool LIMS, bool CTV, bool REG2, int EXP = 0>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_q4_kernel(Q4Args a)
+{
+    constexpr int n = 4, D = 8;
+    const int N = a.N;
+    const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3, q16 = 4 * r + c;
+    long tb = (long)blockIdx.x * 4 + blk;
+    const bool valid = tb < a.B;
+    if (!valid) tb = a.B - 1;                                   // idle blocks repeat the last trajectory (no stores)
+    const int b = (int)tb;
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;
+    const int e = r + 4 * c, et = c + 4 * r;                    // column-major offsets of [r][c] and [c][r]
+
+    const double *cx = a.cx + (size_t)n * N * b + r, *cu = a.cu + (size_t)N * b;
+    const double *ug = LIMS ? a.u + (size_t)N * b : cu;
+    const double *fx = a.fx + a.fx_b * b + e, *fu = a.fu + a.fu_b * b + r;
+    const double *cxx = a.cxx + a.cxx_b * b, *cuu = a.cuu + a.cuu_b * b, *cxu = a.cxu + a.cxu_b * b;
+    double *Vxxg = a.Vxx + (size_t)16 * N * b + e;
+    // merged store of K_i[0, r] (lanes [r][0]), Vx_i[r] (lanes [r][1]), k_i (lane [0][2]), Quu_i (lane [1][2])
+    const bool st_K = c == 0, st_Vx = c == 1, st_k = (c == 2 && r == 0), st_Q = (c == 2 && r == 1);
+    const bool st_on = act && (st_K || st_Vx || st_k || st_Q);
+    double *st_base = st_K ? a.K + (size_t)n * N * b + r : st_Vx ? a.Vx + (size_t)n * N * b + r : st_k ? a.k + (size_t)N * b : a.Quu + (size_t)N * b;
+    const unsigned st_stride = (st_K || st_Vx) ? n * 8u : 8u;
+
+    Q4Par par;
+    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;
+    if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }     // backward_pass.jl:31
+
+    // ---- terminal step (backward_pass.jl:21-23 / :197-199 / :234-236).  Vxx_i is exactly symmetric for i < N-1; the terminal cxx
+    // is used as given (a non-symmetric one enters fx'Vxx fx and fu'Vxx fx like upstream), hence the transposed copy VT.
+    const int tl = N - 1;
+    Q4State s;
+    s.V = cxx[(size_t)a.cxx_t * tl + e]; s.VT = cxx[(size_t)a.cxx_t * tl + et];
+    s.vxc = cx[(size_t)n * tl];
+    s.kprev = 0.0; s.dV0 = 0.0; s.dV1 = 0.0; s.diverge = 0;
+    if (act) {
+        Vxxg[(size_t)16 * tl] = s.V;
+        if (st_on) {
+            const double v0 = st_K ? 0.0 : st_Vx ? s.vxc : st_k ? 0.0 : cuu[(size_t)a.cuu_t * tl];
+            *(double *)((char *)st_base + (size_t)tl * st_stride) = v0;
+        }
+    }
+    Q4In cst;                                                   // time-invariant cost: read once
+    cst.cxx = cxx[e]; cst.cxxT = cxx[et]; cst.cxuc = cxu[r]; cst.cxur = cxu[c]; cst.cuu = cuu[0];
+
+    auto fetch = [&](int i, Q4In &o) {
+        o.fx = fx[(size_t)(unsigned)(a.fx_t * i)]; o.fu = fu[(size_t)(unsigned)(a.fu_t * i)];
+        o.cx = cx[(size_t)(unsigned)(n * i)]; o.cu = cu[i]; o.u = ug[i];
+        if (CTV) {
+            o.cxx = cxx[(size_t)(unsigned)(a.cxx_t * i) + e]; o.cxxT = cxx[(size_t)(unsigned)(a.cxx_t * i) + et];
+            o.cxuc = cxu[(size_t)(unsigned)(a.cxu_t * i) + r]; o.cxur = cxu[(size_t)(unsigned)(a.cxu_t * i) + c];
+            o.cuu = cuu[(size_t)(unsigned)(a.cuu_t * i)];
+        }
+    };
+    auto step = [&](int i, Q4In &o) __attribute__((always_inline)) {
+        if (!CTV) { o.cxx = cst.cxx; o.cxxT = cst.cxxT; o.cxuc = cst.cxuc; o.cxur = cst.cxur; o.cuu = cst.cuu; }
+        Q4Out out;
+        q4_step<LIMS, REG2, EXP>(i, o, s, out, par);
+        // ---- stores (a diverged trajectory keeps writing; its range is zero-filled after the loop)
+        if (act && !(EXP & 1)) Vxxg[(size_t)(unsigned)(16 * i)] = out.Vn;
+        const double v0 = st_K ? out.Kc : st_Vx ? out.vx : st_k ? out.kk : out.Quu;       // :75-76
+        if (st_on && !(EXP & 1)) *(double *)((char *)st_base + (size_t)((unsigned)i * st_stride)) = v0;
+    };
+
+    if (N >= 2) {
+        Q4In ring[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const int i = N - 2 - d; fetch(i >= 0 ? i : 0, ring[d]); }
+        int i0 = N - 2;
+        for (; i0 - (2 * D - 1) >= 0; i0 -= D) {                // branch-free groups of D steps
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                step(i0 - d, ring[d]);
+                if (!(EXP & 2)) fetch(i0 - d - D, ring[d]);
+            }
+        }
+        for (; i0 >= 0; i0 -= D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int i = i0 - d;
+                if (i >= 0) {
+                    step(i, ring[d]);
+                    if (!(EXP & 2)) fetch(i - D >= 0 ? i - D : 0, ring[d]);
+                }
+            }
+        }
+        if (s.diverge && act) q4_zero_fill(a, b, q16, s.diverge);
+    }
+    if (act && q16 == 0) { a.dV[2 * b] = s.dV0; a.dV[2 * b + 1] = s.dV1; a.diverge[b] = s.diverge; }
+}
+
+// ---- two time steps per memory instruction (even N, time-invariant cost)
+template <bool LIMS, bool REG2, int EXP = 0>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
+{
+    constexpr int n = 4, DP = 4;                                // ring of DP pairs = 8 steps
+    const int N = a.N, NP = N / 2;
+    const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3, q16 = 4 * r + c;
+    long tb = (long)blockIdx.x * 4 + blk;
+    const bool valid = tb < a.B;
+    if (!valid) tb = a.B - 1;
+    const int b = (int)tb;
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;
+    const int e = r + 4 * c, et = c + 4 * r;
+    const int odd = r & 1, re = r & ~1;                         // odd rows serve the even step 2j of a pair, even rows step 2j+1
+
+    // pair p = steps (2p+1, 2p); per-lane bases already point at this lane's step of pair 0
+    const double *fxp = a.fx + a.fx_b * b + (re + 4 * c) + (odd ? 0 : a.fx_t);
+    const double *fup = a.fu + a.fu_b * b + re + (odd ? 0 : a.fu_t);
+    const double *cxp = a.cx + (size_t)n * N * b + re + (odd ? 0 : n);
+    const double *cup = a.cu + (size_t)N * b;
+    const double *up = LIMS ? a.u + (size_t)N * b : cup;
+    const double *cxx = a.cxx + a.cxx_b * b, *cuu = a.cuu + a.cuu_b * b, *cxu = a.cxu + a.cxu_b * b;
+    double *Vxxp = a.Vxx + (size_t)16 * N * b + (re + 4 * c) + (odd ? 0 : 16);
+    // merged 16-byte store per pair: lanes [.][0]: K pairs, [.][1]: Vx pairs (row parity selects the step like the loads),
+    // lane [0][2]: {k[2p], k[2p+1]}, lane [0][3]: {Quu[2p], Quu[2p+1]}
+    const bool st_K = c == 0, st_Vx = c == 1, st_s = (r == 0 && c >= 2);
+    const bool st_on = act && (st_K || st_Vx || st_s);
+    double *st_base = st_K ? a.K + (size_t)n * N * b + re + (odd ? 0 : n) : st_Vx ? a.Vx + (size_t)n * N * b + re + (odd ? 0 : n)
+                      : (c == 2) ? a.k + (size_t)N * b : a.Quu + (size_t)N * b;
+    const unsigned st_stride = (st_K || st_Vx) ? 2u * n * 8u : 16u;      // bytes per pair
+
+    Q4Par par;
+    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;
+    if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }
+
+    Q4In cst;
+    cst.cxx = cxx[e]; cst.cxxT = cxx[et]; cst.cxuc = cxu[r]; cst.cxur = cxu[c]; cst.cuu = cuu[0];
+
+    struct Pair { d2 fx, fu, cx, cu, u; };
+    auto fetch = [&](int p, Pair &o) {
+        o.fx = *(const d2 *)(fxp + (size_t)(unsigned)(2 * a.fx_t * p));
+        o.fu = *(const d2 *)(fup + (size_t)(unsigned)(2 * a.fu_t * p));
+        o.cx = *(const d2 *)(cxp + (size_t)(unsigned)(2 * n * p));
+        o.cu = *(const d2 *)(cup + (size_t)(unsigned)(2 * p));
+        o.u = *(const d2 *)(up + (size_t)(unsigned)(2 * p));
+    };
+    auto unpack = [&](const Pair &o, Q4In &A, Q4In &Bs) {
+        row_swap(o.fx.x, o.fx.y, A.fx, Bs.fx);
+        row_swap(o.fu.x, o.fu.y, A.fu, Bs.fu);
+        row_swap(o.cx.x, o.cx.y, A.cx, Bs.cx);
+        A.cu = o.cu.y; Bs.cu = o.cu.x; A.u = o.u.y; Bs.u = o.u.x;
+        A.cxx = Bs.cxx = cst.cxx; A.cxxT = Bs.cxxT = cst.cxxT; A.cxuc = Bs.cxuc = cst.cxuc; A.cxur = Bs.cxur = cst.cxur;
+        A.cuu = Bs.cuu = cst.cuu;
+    };
+    auto store_pair = [&](int p, const Q4Out &oa, const Q4Out &ob) {
+        if (EXP & 1) return;
+        double x, y;
+        row_swap(oa.Vn, ob.Vn, x, y);
+        if (act) *(d2 *)(Vxxp + (size_t)(unsigned)(32 * p)) = d2{x, y};
+        // lanes [0][2], [0][3] store {value of step 2p, value of step 2p+1}: after the swap row 0 holds x = a(row 0), y = a(row 1)
+        const double sa = (c == 2) ? (r == 0 ? ob.kk : oa.kk) : (r == 0 ? ob.Quu : oa.Quu);
+        const double va = st_K ? oa.Kc : st_Vx ? oa.vx : sa;
+        const double vb = st_K ? ob.Kc : ob.vx;
+        row_swap(va, vb, x, y);
+        if (st_on) *(d2 *)((char *)st_base + (size_t)((unsigned)p * st_stride)) = d2{x, y};
+    };
+
+    Q4State s;
+    s.kprev = 0.0; s.dV0 = 0.0; s.dV1 = 0.0; s.diverge = 0;
+    Pair ring[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) { const int p = NP - 1 - d; fetch(p >= 0 ? p : 0, ring[d]); }
+    // ---- first pair: its upper member is the terminal step (backward_pass.jl:21-23 / :234-236), see back_pass_q4_kernel
+    {
+        Q4In A, Bs;
+        unpack(ring[0], A, Bs);
+        Q4Out oa, ob;
+        s.V = cst.cxx; s.VT = cst.cxxT; s.vxc = A.cx;
+        oa.Vn = s.V; oa.Kc = 0.0; oa.vx = A.cx; oa.kk = 0.0; oa.Quu = cst.cuu;
+        q4_step<LIMS, REG2, EXP>(N - 2, Bs, s, ob, par);
+        store_pair(NP - 1, oa, ob);
+        fetch(NP - 1 - DP >= 0 ? NP - 1 - DP : 0, ring[0]);
+    }
+    auto pair_step = [&](int p, Pair &slot, int pnext) __attribute__((always_inline)) {
+        Q4In A, Bs;
+        unpack(slot, A, Bs);
+        Q4Out oa, ob;
+        q4_step<LIMS, REG2, EXP>(2 * p + 1, A, s, oa, par);
+        q4_step<LIMS, REG2, EXP>(2 * p, Bs, s, ob, par);
+        store_pair(p, oa, ob);
+        if (!(EXP & 2)) fetch(pnext, slot);
+    };
+    // slot of pair p is (NP-1-p) % DP; the first pair used slot 0
+    int p0 = NP - 2;
+    // leading group so that the main loop starts at slot 0 again: slots 1 .. DP-1.  Unconditional (the launcher guarantees NP >= DP):
+    // a conditionally issued load does not count for the compiler's s_waitcnt vmcnt(n) bookkeeping, and a small n at the top of
+    // the main loop would drain the whole prefetch ring in every iteration (measured: a third of the kernel time).
+#pragma unroll
+    for (int d = 1; d < DP; ++d) {
+        const int p = NP - 1 - d;
+        pair_step(p, ring[d], p - DP >= 0 ? p - DP : 0);
+    }
+    p0 = NP - 1 - DP;
+    for (; p0 - (2 * DP - 1) >= 0; p0 -= DP) {                  // branch-free groups of DP pairs
+#pragma unroll
+        for (int d = 0; d < DP; ++d) pair_step(p0 - d, ring[d], p0 - d - DP);
+    }
+    for (; p0 >= 0; p0 -= DP) {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+            const int p = p0 - d;
+            if (p >= 0) pair_step(p, ring[d], p - DP >= 0 ? p - DP : 0);
+        }
+    }
+    if (s.diverge && act) q4_zero_fill(a, b, q16, s.diverge);
+    if (act && q16 == 0) { a.dV[2 * b] = s.dV0; a.dV[2 * b + 1] = s.dV1; a.diverge[b] = s.diverge; }
+}
+
+}   // namespace
+
+// returns 1 if this shape has no such kernel (caller falls back), 0 launched, <0 error
+int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                            const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                            const double *fu, const double *lambda, const double *lims, const double *u,
+                            const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                            double *Vxx, double *dV, int32_t *diverge)
+{
+    if (!(d->n == 4 && d->m == 1)) return 1;
+    Q4Args a;
+    const long N = d->N;
+    a.N = d->N; a.B = d->B; a.regType = d->regType;
+    a.fx_t = d->fx_tv ? 16 : 0; a.fx_b = d->fx_batched ? 16 * (d->fx_tv ? N : 1) : 0;
+    a.fu_t = d->fx_tv ? 4 : 0; a.fu_b = d->fx_batched ? 4 * (d->fx_tv ? N : 1) : 0;
+    a.cxx_t = d->cost_tv ? 16 : 0; a.cxx_b = d->cost_batched ? 16 * (d->cost_tv ? N : 1) : 0;
+    a.cxu_t = d->cost_tv ? 4 : 0; a.cxu_b = d->cost_batched ? 4 * (d->cost_tv ? N : 1) : 0;
+    a.cuu_t = d->cost_tv ? 1 : 0; a.cuu_b = d->cost_batched ? (d->cost_tv ? N : 1) : 0;
+    a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.lims = lims;
+    a.u = u; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
+    const char *ex = getenv("DDP_Q4_EXP");
+    const int exp = ex ? atoi(ex) : 0;
+    const char *sg = getenv("DDP_Q4_SINGLE");                  // 1: force the one-step-at-a-time kernel (tests)
+    const bool aligned16 = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu |
+                              (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)(d->has_lims ? u : cu)) & 15) == 0);
+    const bool paired = !d->cost_tv && (d->N % 2 == 0) && d->N >= 8 && aligned16 && !(sg && sg[0] == '1');
+#define Q4P(L_, R_, E_) hipLaunchKernelGGL((back_pass_q4p_kernel<L_, R_, E_>), grid, block, 0, h->stream, a)
+#define Q4S(L_, C_, R_) hipLaunchKernelGGL((back_pass_q4_kernel<L_, C_, R_>), grid, block, 0, h->stream, a)
+    const bool reg2 = d->regType == 2;
+    if (paired) {
+        if (d->has_lims && reg2) {
+            switch (exp) {
+            case 1: Q4P(true, true, 1); break; case 2: Q4P(true, true, 2); break; case 3: Q4P(true, true, 3); break;
+            case 4: Q4P(true, true, 4); break; case 7: Q4P(true, true, 7); break; default: Q4P(true, true, 0);
+            }
+        } else if (d->has_lims) Q4P(true, false, 0);
+        else if (reg2) Q4P(false, true, 0);
+        else Q4P(false, false, 0);
+    } else {
+        const int key = (d->has_lims ? 4 : 0) | (d->cost_tv ? 2 : 0) | (reg2 ? 1 : 0);
+        switch (key) {
+        case 0: Q4S(false, false, false); break; case 1: Q4S(false, false, true); break;
+        case 2: Q4S(false, true, false); break;  case 3: Q4S(false, true, true); break;
+        case 4: Q4S(true, false, false); break;  case 5: Q4S(true, false, true); break;
+        case 6: Q4S(true, true, false); break;   case 7: Q4S(true, true, true); break;
+        }
+    }
+#undef Q4S
+#undef Q4P
+    DDP_HIP(hipGetLastError());
+    return 0;
+}

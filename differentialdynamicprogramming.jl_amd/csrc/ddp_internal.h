@@ -81,6 +81,12 @@ int ddp_launch_back_pass_dpp(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const double *fu, const double *lambda, const double *lims, const double *u,
                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge);
+// n = 4, m = 1 on v_mfma_f64_4x4x4_4b, one trajectory per MFMA block (back_pass_q4.hip); returns 1 for any other shape
+int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                            const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                            const double *fu, const double *lambda, const double *lims, const double *u,
+                            const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                            double *Vxx, double *dV, int32_t *diverge);
 // large states (even n <= 64, even m <= 8): 256-thread work-group per trajectory; returns 1 when not applicable
 int ddp_launch_back_pass_big(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
