@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddp_amd.so")
+LIB_PATH = os.environ.get("DDP_AMD_LIB", os.path.join(_HERE, "libddp_amd.so"))      # the override is for A/B timing of kernel variants
 
 dp = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)

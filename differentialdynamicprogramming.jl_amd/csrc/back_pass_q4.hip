@@ -36,6 +36,9 @@
 #include "ddp_internal.h"
 #include "boxqp_dev.h"
 
+#ifndef Q4_DP
+#define Q4_DP 4
+#endif
 namespace {
 
 struct Q4Args {
@@ -73,14 +76,17 @@ __device__ __forceinline__ void boxqp1_two_iterations(double H, double g, double
                                                        double &x, double &rH, bool &clamped, bool &slow)
 {
     auto val = [&](double xx) { return xx * g + ((0.5 * xx) * H) * xx; };                      // :63
-    const double x1 = ddp_clamp(x0, lower, upper);                                              // :58
+    // clamp by v_max/v_min: like Base.clamp for ordered operands; a NaN iterate (only possible after an earlier step of the
+    // trajectory has already failed) comes out as a bound instead of NaN, and the generic loop still decides such a case
+    auto clampf = [](double v, double lo_, double hi_) { return fmin(fmax(v, lo_), hi_); };
+    const double x1 = clampf(x0, lower, upper);                                                 // :58
     const double v1 = val(x1);
     const double grad1 = g + H * x1;                                                            // :85
     const bool c1 = ((x1 == lower) && (grad1 > 0)) || ((x1 == upper) && (grad1 < 0));          // :92-95 -> result 6 (:98-101)
     rH = ddp_rcp_nr(H);
     const double search = -(g * rH) - x1;                                                       // :127-129
     const double sdotg = search * grad1;                                                        // :132
-    const double xc = ddp_clamp(x1 + search, lower, upper);                                     // step = 1 (:138-141)
+    const double xc = clampf(x1 + search, lower, upper);                                        // step = 1 (:138-141)
     const double vc = val(xc);
     // iteration 1 runs to its end with step 1: H > 0 (:111), |grad| >= minGrad (:120), sdotg < 0 (:133), Armijo holds (:142)
     const bool plain = (H > 0.0) && !(fabs(grad1) < o.minGrad) && (sdotg < 0) && !((vc - v1) > o.Armijo * sdotg);
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4_kernel(Q4Args a)
 template <bool LIMS, bool REG2, int EXP = 0>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
 {
-    constexpr int n = 4, DP = 4;                                // ring of DP pairs = 8 steps
+    constexpr int n = 4, DP = Q4_DP;                            // ring of DP pairs
     const int N = a.N, NP = N / 2;
     const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3, q16 = 4 * r + c;
     long tb = (long)blockIdx.x * 4 + blk;
@@ -413,7 +419,7 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
     const char *sg = getenv("DDP_Q4_SINGLE");                  // 1: force the one-step-at-a-time kernel (tests)
     const bool aligned16 = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu |
                               (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)(d->has_lims ? u : cu)) & 15) == 0);
-    const bool paired = !d->cost_tv && (d->N % 2 == 0) && d->N >= 8 && aligned16 && !(sg && sg[0] == '1');
+    const bool paired = !d->cost_tv && (d->N % 2 == 0) && d->N >= 4 * Q4_DP && aligned16 && !(sg && sg[0] == '1');
 #define Q4P(L_, R_, E_) hipLaunchKernelGGL((back_pass_q4p_kernel<L_, R_, E_>), grid, block, 0, h->stream, a)
 #define Q4S(L_, C_, R_) hipLaunchKernelGGL((back_pass_q4_kernel<L_, C_, R_>), grid, block, 0, h->stream, a)
     const bool reg2 = d->regType == 2;

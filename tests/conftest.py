@@ -20,10 +20,27 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-def relerr(a, b):
+STEP_FLOOR = 1e-4      # a time step whose reference is smaller than this fraction of the array's largest entry is scaled by the floor
+
+
+def relerr(a, b, taxis=-1):
+    """Distance used by every parity assert: the LARGER of
+       (i)  max|a-b| / max|b|  over the whole array, and
+       (ii) max_t  max|a_t - b_t| / max(max|b_t|, STEP_FLOOR * max|b|)  over the slices along `taxis` (the time axis of
+            K[m,n,N], k[m,N], Vx[n,N], Vxx[n,n,N], x[n,N] ...; for a batched array the trailing axis is the trajectory).
+    (i) alone lets a wrong small time step hide behind the largest entry of the array (K, Vx, Vxx span decades along the horizon);
+    the floor keeps (ii) from demanding digits that cancellation has removed from a step that is tiny against the rest."""
     a = np.asarray(a, float); b = np.asarray(b, float)
-    den = max(np.max(np.abs(b)) if b.size else 0.0, 1e-300)
-    return float(np.max(np.abs(a - b)) / den) if b.size else 0.0
+    if not b.size:
+        return 0.0
+    g = max(float(np.max(np.abs(b))), 1e-300)
+    err = np.abs(a - b)
+    worst = float(np.max(err)) / g
+    if b.ndim >= 1 and b.shape[taxis] > 1:
+        e_t = np.moveaxis(err, taxis, 0).reshape(b.shape[taxis], -1).max(axis=1) if b.ndim > 1 else err
+        s_t = np.moveaxis(np.abs(b), taxis, 0).reshape(b.shape[taxis], -1).max(axis=1) if b.ndim > 1 else np.abs(b)
+        worst = max(worst, float(np.max(e_t / np.maximum(s_t, STEP_FLOOR * g))))
+    return worst
 
 
 @pytest.fixture(scope="session")
