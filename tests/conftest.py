@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """GPU runs: torch ships its own HIP runtime, and whichever runtime touches the device first wins — once libddp_amd.so has
+    initialised, torch reports "No HIP GPUs are available".  The one test that builds its operands with torch (C4 at full size,
+    8.6 GB) therefore needs torch to initialise before any other GPU test has created a handle."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch
+            torch.cuda.init()
+        except Exception:
+            pass
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
         return {k: z[k] for k in z.files}

@@ -1,0 +1,286 @@
+"""Full-size GPU tests (-m gpu) of the BASELINE configurations that test_gpu_parity.py covers only at toy sizes, with the DEFAULT
+kernel dispatch (no DDP_BACKPASS / DDP_FORWARD_LANE overrides: the size-triggered kernels run as shipped):
+
+    test/test_readme.jl:59-70   10 random LQ problems, n=10 m=2 T=1000, thresholds max<25 mean<10 min<5 — ONE batched call
+    C3  pendcart n=4 m=1 N=600 with control limits, B=4096        (back_pass_q4p, lane-per-rollout line search, whole solves)
+    C4  n=64 m=8 N=256 per-trajectory LTV, B=1024                 (fp64-MFMA back pass, streaming rollout)
+    C5  C3 + KL constraint, B=4096                                (back_pass_gps lane kernel, device-resident iLQGkl loop)
+
+Each: size-independent properties over the WHOLE batch + oracle comparisons (1e-8 per time step) on >= 3 trajectories."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+SPOTS3 = lambda B: (0, B // 2 - 1, B - 1)      # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def ddp():
+    try:                               # torch ships its own HIP runtime: it has to initialise BEFORE libddp_amd.so's (the C4 test builds its
+        import torch                   # 8.6 GB of operands with torch on the device); the other way round torch finds "no HIP GPUs"
+        torch.cuda.init()
+    except Exception:
+        pass
+    import ddp_amd
+    import ddp_amd.kl  # noqa: F401
+    ddp_amd.default_handle()
+    return ddp_amd
+
+
+@pytest.fixture(autouse=True)
+def _default_dispatch(monkeypatch):
+    for v in ("DDP_BACKPASS", "DDP_FORWARD_LANE", "DDP_Q4_SINGLE", "DDP_KL_HOSTLOOP"):
+        monkeypatch.delenv(v, raising=False)
+
+
+# ------------------------------------------------------------------------------------------------ test_readme.jl
+def test_readme_thresholds_one_batched_call(ddp):
+    """the reference's only assertions (test/test_readme.jl:59-70) through ddp_ilqg_f64: the 10 Monte-Carlo problems are the
+    10 trajectories of ONE batch (own A, B per trajectory), default iLQG options; every solve also equals its oracle solve"""
+    from oracle import np_restatement as npr
+    from oracle import oracle_ctypes as oc
+    n, m, T, B = 10, 2, 1000, 10
+    Ps = [npr.make_lq_problem(np.random.default_rng(seed)) for seed in range(B)]
+    A = np.stack([P["A"] for P in Ps], -1); Bm = np.stack([P["B"] for P in Ps], -1)
+    x0 = np.stack([P["x0"] for P in Ps], -1); u0 = np.stack([P["u0"] for P in Ps], -1)
+    assert all(np.array_equal(P["Q"], Ps[0]["Q"]) and np.array_equal(P["R"], Ps[0]["R"]) for P in Ps)      # Q = h·I, R = 0.1h·I
+    prob = ddp.LQProblem(A, Bm, Ps[0]["Q"], Ps[0]["R"], dyn_batched=True)
+    x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(prob, x0, u0)
+    costs = cost.sum(axis=0)
+    assert costs.shape == (B,)
+    assert costs.max() < 25 and costs.mean() < 10 and costs.min() < 5            # test_readme.jl:68-70
+    assert set(tr["status"]) <= {1, 2}
+    for b in range(B):
+        p = oc.make_problem("lq", n, m, T, A=Ps[b]["A"], B=Ps[b]["B"], Q=Ps[b]["Q"], R=Ps[b]["R"])
+        xr, ur, (Kr, kr, Quur), vxr, vxxr, cr, info = oc.ilqg(p, Ps[b]["x0"], Ps[b]["u0"])
+        st = tr["stats"][:, b]
+        assert (int(st[0]), int(st[1])) == (info["status"], info["iter"]), b
+        assert abs(costs[b] - cr.sum()) < 1e-9 * cr.sum()
+        assert relerr(x[..., b], xr) < RTOL and relerr(u[..., b], ur) < RTOL and relerr(Vxx[..., b], vxxr) < RTOL
+        assert relerr(Vx[..., b], vxr) < RTOL and relerr(pol.K[..., b], Kr) < RTOL
+
+
+# ------------------------------------------------------------------------------------------------ C3
+def _c3_inputs(B, N=600, seed=0):
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(np.array([np.pi - 0.6, 0, 0, 0])[:, None], (1, B)); x0[0] += rng.uniform(-0.1, 0.1, B)
+    u0 = 2.0 * np.sin(np.arange(N) / 37.0)[None, :, None] * np.ones((1, 1, B)) + 0.05 * rng.standard_normal((1, N, B))
+    return x0, u0
+
+
+def _pend_oracle(oc, prob, N):
+    return oc.make_problem("pendcart", 4, 1, N, Q=prob.Q, R=prob.R, pend=dict(g=prob.g, l=prob.l, h=prob.h, d=prob.d, goal=prob.goal))
+
+
+def test_full_size_c3_pass(ddp):
+    """C3: one back_pass (limits, boxQP, regType 2) + the 6-α line-search rollouts of demo_pendcart over B = 4096 trajectories"""
+    from oracle import oracle_ctypes as oc
+    B, N = 4096, 600
+    prob = ddp.PendcartProblem()
+    lims = 5.0 * np.array([[-1.0, 1.0]])
+    al = 10.0 ** np.linspace(0.2, -3, 6)
+    x0, u0 = _c3_inputs(B, N)
+    x, u, c = ddp.forward_pass(None, x0, u0, None, 1.0, prob, lims)
+    fx, fu, _, _, _, cx, cu, cxx, cxu, cuu = ddp.df(prob, x, u)
+    lam = 10.0 ** np.random.default_rng(1).uniform(-2, 1, B)
+    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 2, lims, x, u)
+    # ---- properties over the whole batch
+    assert not div.any()
+    assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2, 3)))                                  # exactly symmetric (:71-72)
+    assert np.isfinite(Vxx).all() and np.isfinite(pol.K).all()
+    un = u + pol.k
+    assert un[:, :-1].max() <= 5.0 + 1e-12 and un[:, :-1].min() >= -5.0 - 1e-12                  # boxQP keeps u + k inside the limits
+    clamped = (np.abs(np.abs(un) - 5.0) < 1e-12)[:, :-1]
+    # K_i = 0 on clamped steps (:57-61); a step that reaches the bound with boxQP result 4 keeps its free-set gain (quirk Q12), so "almost all"
+    Kc = pol.K[:, :, :-1][np.broadcast_to(clamped[:, None], pol.K[:, :, :-1].shape)].reshape(4, -1)
+    assert clamped.sum() > 1000 and np.mean(~Kc.any(axis=0)) > 0.99
+    assert (dV[0] <= 1e-12).all()                                                                 # k'Qu <= 0 at a QP minimiser started from 0
+    xn, un_, cn = ddp.forward_pass(pol, x0, u, x, al, prob, lims)                                 # 24 576 rollouts: lane kernel
+    assert np.abs(un_).max() <= 5.0 and np.isfinite(xn).all()
+    assert np.array_equal(xn[:, 0], np.broadcast_to(x0[:, :, None], xn[:, 0].shape))
+    # ---- oracle on spot trajectories
+    p = _pend_oracle(oc, prob, N)
+    for b in SPOTS3(B) + (1234,):
+        xr, ur, cr = oc.forward_pass(p, None, x0[:, b], u0[..., b], None, 1.0, lims)
+        assert relerr(x[..., b], xr) < RTOL and relerr(c[:, b], cr) < RTOL
+        dr = oc.df(p, xr, ur)
+        assert relerr(fx[..., b], dr[0]) < RTOL and relerr(fu[..., b], dr[1]) < RTOL
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(dr[2], dr[3], prob.Q, np.zeros((4, 1)), prob.R, dr[0], dr[1], lam[b], 2, lims, None, ur)
+        assert d == 0
+        for got, ref, name in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (Vx[..., b], vx, "Vx"), (Vxx[..., b], vxx, "Vxx"),
+                               (dV[:, b], dv, "dV"), (pol.Σi[..., b], Quu, "Quu")):
+            assert relerr(got, ref) < RTOL, (name, b, relerr(got, ref))
+        for j, a in enumerate(al):
+            xr2, ur2, cr2 = oc.forward_pass(p, (K, k), x0[:, b], ur, xr, float(a), lims)
+            assert relerr(xn[..., b, j], xr2) < RTOL and relerr(un_[..., b, j], ur2) < RTOL and relerr(cn[:, b, j], cr2) < RTOL
+
+
+def test_full_size_c3_solves(ddp):
+    """C3: 4096 whole demo_pendcart solves (device-resident driver); the exit decisions sit at the rounding floor of sum(cost)
+    (DESIGN.md §4), so the SOLUTION is compared: cost to 1e-9, trajectory to 1e-5 like the golden test"""
+    from oracle import oracle_ctypes as oc
+    B, T = 4096, 600
+    x0, _ = _c3_inputs(B, T)
+    prob = ddp.PendcartProblem()
+    lims = 5.0 * np.array([[-1.0, 1.0]])
+    kw = dict(regType=2, α=10.0 ** np.linspace(0.2, -3, 6), λmax=1e15, tol_fun=1e-8, tol_grad=1e-8, max_iter=1000)
+    x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(prob, x0, np.zeros((1, T, B)), lims=lims, **kw)
+    st = tr["stats"]
+    assert set(st[0].astype(int)) <= {1, 2, 3}                               # every trajectory finished
+    assert np.abs(u).max() <= 5.0 and np.isfinite(x).all()
+    assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2, 3)))
+    c0 = ddp.forward_pass(None, x0, np.zeros((1, T, B)), None, 1.0, prob, lims)[2].sum(axis=0)
+    assert (cost.sum(axis=0) < c0).all()                                     # every solve improved on the initial rollout
+    p = _pend_oracle(oc, prob, T)
+    for b in SPOTS3(B):
+        xr, ur, polr, vxr, vxxr, cr, info = oc.ilqg(p, x0[:, b], np.zeros((1, T)), lims=lims, regType=2, alpha=kw["α"], lam_max=1e15,
+                                                    tol_fun=1e-8, tol_grad=1e-8, max_iter=1000)
+        assert abs(cost[:, b].sum() - cr.sum()) < 1e-9 * cr.sum(), b
+        assert relerr(x[..., b], xr) < 1e-5 and relerr(u[..., b], ur) < 1e-5 and relerr(Vxx[..., b], vxxr) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ C4
+def test_full_size_c4_pass_and_solves(ddp):
+    """C4: n=64, m=8, N=256, per-trajectory time-varying dynamics (a3 layout), B=1024 — operands built on the device (8.6 GB);
+    back_pass + 4-α rollouts + whole solves; oracle on three trajectories copied back"""
+    import scipy.linalg as sla
+    import torch
+    from ddp_amd import _lib
+    from oracle import oracle_ctypes as oc
+    n, m, N, B = 64, 8, 256, 1024
+    dev = torch.device("cuda", 0)
+    L = _lib.lib()
+    h = ddp.default_handle()
+    p_ = lambda t: C.c_void_p(t.data_ptr())                                  # noqa: E731
+    f64 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))).to(dev)   # noqa: E731
+    empty = lambda cnt, dt=torch.float64: torch.empty(int(cnt), dtype=dt, device=dev)     # noqa: E731
+    rng = np.random.default_rng(1)
+    hh = 0.01
+    a0 = rng.standard_normal((n, n))
+    A = sla.expm(hh * (a0 - a0.T)); Bm = hh * rng.standard_normal((n, m))
+    torch.manual_seed(0)
+    dA = (f64(A).reshape(1, -1) * (1.0 + 0.01 * torch.rand(N * B, 1, dtype=torch.float64, device=dev))).reshape(-1).contiguous()
+    dB = (f64(Bm).reshape(1, -1) * (1.0 + 0.01 * torch.rand(N * B, 1, dtype=torch.float64, device=dev))).reshape(-1).contiguous()
+    Q, R = hh * np.eye(n), 0.1 * hh * np.eye(m)
+    dQ, dR = f64(Q), f64(R)
+    prob = _lib.Problem()
+    prob.kind, prob.n, prob.m, prob.N, prob.B = 0, n, m, N, B
+    prob.A, prob.Bm, prob.Q, prob.R = dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr()
+    prob.dyn_tv, prob.dyn_batched = 1, 1
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B)); u0 = 0.1 * rng.standard_normal((m, N, B))
+    dx0, du0 = f64(x0), f64(u0)
+    one = np.array([1.0]); al = np.array([1.0, 0.5, 0.1, 0.01])
+    dx, du, dc, dcs = empty(n * N * B), empty(m * N * B), empty(N * B), empty(B)
+    _lib.check(L.ddp_forward_pass_f64_dev(h.raw, C.byref(prob), None, None, p_(dx0), p_(du0), None, _lib.ptr(one), 1, None, None, p_(dx), p_(du),
+                                          p_(dc), p_(dcs)))
+    dcx, dcu = empty(n * N * B), empty(m * N * B)
+    _lib.check(L.ddp_df_f64_dev(h.raw, C.byref(prob), p_(dx), p_(du), None, p_(dcx), p_(dcu), None, None))
+    dK, dk, dQuu, dVx, dVxx, ddV = empty(m * n * N * B), empty(m * N * B), empty(m * m * N * B), empty(n * N * B), empty(n * n * N * B), empty(2 * B)
+    ddiv = torch.zeros(B, dtype=torch.int32, device=dev)
+    dlam = f64(10.0 ** rng.uniform(-3, 0, B)); dcxu = torch.zeros(n * m, dtype=torch.float64, device=dev)
+    desc = _lib.BPDesc(n, m, N, B, 1, 1, 0, 0, 1, 0)
+    _lib.check(L.ddp_back_pass_f64_dev(h.raw, C.byref(desc), p_(dcx), p_(dcu), p_(dQ), p_(dcxu), p_(dR), p_(dA), p_(dB), p_(dlam), None, None, None,
+                                       p_(dK), p_(dk), p_(dQuu), p_(dVx), p_(dVxx), p_(ddV), p_(ddiv)))
+    na = len(al)
+    dxn, dun, dcn, dcsn = empty(n * N * B * na), empty(m * N * B * na), empty(N * B * na), empty(B * na)
+    _lib.check(L.ddp_forward_pass_f64_dev(h.raw, C.byref(prob), p_(dK), p_(dk), p_(dx0), p_(du), p_(dx), _lib.ptr(al), na, None, None, p_(dxn), p_(dun),
+                                          p_(dcn), p_(dcsn)))
+    torch.cuda.synchronize()
+    # ---- properties over the whole batch
+    assert int(ddiv.sum().item()) == 0
+    Vxx = dVxx.reshape(B, N, n, n)                                           # [b][t][c][r]
+    assert torch.equal(Vxx, Vxx.transpose(2, 3))                             # exactly symmetric
+    dVh = ddV.cpu().numpy().reshape(2, B, order="F")
+    csum0 = dcs.cpu().numpy(); csn = dcsn.cpu().numpy().reshape(B, na, order="F")
+    assert (dVh[0] < 0).all() and np.isfinite(csn).all()
+    # LQ problem, unconstrained: the actual reduction along the line search equals the model -α(dV1 + α dV2) up to the λ term;
+    # with λ > 0 the full step still descends
+    assert (csn[:, 0] < csum0).all()
+    assert torch.allclose(dcsn.reshape(na, B), dcn.reshape(na, B, N).sum(dim=2), rtol=1e-12, atol=0)       # csum = sum(cnew)
+    # ---- oracle on three trajectories
+    lam = dlam.cpu().numpy()
+    for b in SPOTS3(B):
+        sl = lambda t, per: t[per * b: per * (b + 1)].cpu().numpy()          # noqa: E731
+        Ab = sl(dA, n * n * N).reshape(n, n, N, order="F"); Bb = sl(dB, n * m * N).reshape(n, m, N, order="F")
+        p = oc.make_problem("lq", n, m, N, A=Ab, B=Bb, Q=Q, R=R)
+        xr, ur, cr = oc.forward_pass(p, None, x0[:, b], u0[..., b], None, 1.0, None)
+        assert relerr(sl(dx, n * N).reshape(n, N, order="F"), xr) < RTOL
+        cxr, cur = Q @ xr, R @ ur
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cxr, cur, Q, np.zeros((n, m)), R, Ab, Bb, lam[b], 1, None, None, ur)
+        assert d == 0
+        for got, ref, name in ((sl(dK, m * n * N).reshape(m, n, N, order="F"), K, "K"), (sl(dk, m * N).reshape(m, N, order="F"), k, "k"),
+                               (sl(dVx, n * N).reshape(n, N, order="F"), vx, "Vx"), (sl(dVxx, n * n * N).reshape(n, n, N, order="F"), vxx, "Vxx"),
+                               (sl(dQuu, m * m * N).reshape(m, m, N, order="F"), Quu, "Quu"), (dVh[:, b], dv, "dV")):
+            assert relerr(got, ref) < RTOL, (name, b, relerr(got, ref))
+        for j, a in enumerate(al):
+            xr2, ur2, cr2 = oc.forward_pass(p, (K, k), x0[:, b], ur, xr, float(a), None)
+            off = (b + B * j)
+            assert relerr(dxn[n * N * off: n * N * (off + 1)].cpu().numpy().reshape(n, N, order="F"), xr2) < RTOL
+            assert relerr(dun[m * N * off: m * N * (off + 1)].cpu().numpy().reshape(m, N, order="F"), ur2) < RTOL
+            assert abs(csn[b, j] - cr2.sum()) < 1e-10 * abs(cr2.sum())
+    # ---- whole solves, device resident (4 step sizes)
+    o = _lib.ILQGOpts()
+    L.ddp_ilqg_default_opts(C.byref(o))
+    o.max_iter, o.n_alpha = 50, 4
+    for i, a in enumerate(10.0 ** np.linspace(0, -3, 4)):
+        o.alpha[i] = a
+    sx, su = empty(n * N * B), empty(m * N * B)
+    scost, stats = empty(N * B), empty(8 * B)
+    git = C.c_int(0)
+    _lib.check(L.ddp_ilqg_f64_dev(h.raw, C.byref(prob), C.byref(o), p_(dx0), p_(du0), None, p_(sx), p_(su), p_(dK), p_(dk), p_(dQuu), p_(dVx), p_(dVxx),
+                                  p_(scost), p_(stats), 0, None, C.byref(git)))
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy().reshape(8, B, order="F")
+    assert set(st[0].astype(int)) <= {1, 2}
+    for b in SPOTS3(B):
+        sl = lambda t, per: t[per * b: per * (b + 1)].cpu().numpy()          # noqa: E731
+        Ab = sl(dA, n * n * N).reshape(n, n, N, order="F"); Bb = sl(dB, n * m * N).reshape(n, m, N, order="F")
+        p = oc.make_problem("lq", n, m, N, A=Ab, B=Bb, Q=Q, R=R)
+        xr, ur, polr, vxr, vxxr, cr, info = oc.ilqg(p, x0[:, b], u0[..., b], max_iter=50, alpha=10.0 ** np.linspace(0, -3, 4))
+        assert (int(st[0, b]), int(st[1, b])) == (info["status"], info["iter"]), b
+        assert abs(st[7, b] - cr.sum()) < 1e-9 * cr.sum()
+        assert relerr(sl(sx, n * N).reshape(n, N, order="F"), xr) < RTOL and relerr(sl(su, m * N).reshape(m, N, order="F"), ur) < RTOL
+        assert relerr(sl(dVxx, n * n * N).reshape(n, n, N, order="F"), vxxr) < RTOL
+
+
+# ------------------------------------------------------------------------------------------------ C5
+def test_full_size_c5_kl_solves(ddp):
+    """C5 = C3 + KL constraint at B = 4096: the KL-constrained iteration on device-resident arrays (lane-per-trajectory
+    back_pass_gps); per-trajectory η brackets; oracle solves on three trajectories"""
+    from oracle import oracle_ctypes as oc
+    kl = ddp.kl
+    B, N = 4096, 600
+    prob = ddp.PendcartProblem()
+    lims = 5.0 * np.array([[-1.0, 1.0]])
+    x0, u = _c3_inputs(B, N)
+    x, _, c0 = ddp.forward_pass(None, x0, u, None, 1.0, prob, lims)
+    cost0 = c0.sum(axis=0)
+    fx, fu = ddp.df(prob, x, u)[:2]
+    R1 = 1e-3 * np.eye(4)
+    eye = np.ones((1, 1, N, B))
+    prev = ddp.GaussianPolicy(N, 4, 1, np.zeros((1, 4, N, B)), u, eye, eye.copy())
+    xo, uo, pol, Vx, Vxx, cost, tr = kl.iLQGkl(prob, x, prev, kl.Model(fx, fu, R1), kl_step=0.05, lims=lims, max_iter=30, cost=cost0)
+    # ---- properties over the whole batch
+    assert set(np.asarray(tr["status"]).astype(int)) <= {1, 2}               # satisfied, or the bracket closed (iLQGkl.jl:173-181)
+    assert np.abs(uo).max() <= 5.0 and np.isfinite(xo).all() and np.isfinite(pol.K).all()
+    assert np.array_equal(pol.k, uo)                                         # traj_new.k = copy(u) (iLQGkl.jl:239)
+    assert (pol.Σ[0, 0] > 0).all()                                           # Σ = inv(Quu) of a positive definite Quu
+    sat = np.asarray(tr["status"]).astype(int) == 1
+    assert sat.any()
+    dvg = np.asarray(tr["divergence"], float)
+    assert np.all(np.abs(dvg[sat] - 0.05) < 0.1 * 0.05 + 1e-12)              # satisfied = within 10 % of kl_step (klutils.jl:121)
+    # ---- oracle on three trajectories
+    p = _pend_oracle(oc, prob, N)
+    for b in SPOTS3(B):
+        pb = dict(K=np.zeros((1, 4, N)), k=u[..., b], S=eye[..., b], Si=eye[..., b])
+        xr, ur, polr, vx, vxx, cr, info = oc.ilqgkl(p, x[..., b], float(cost0[b]), pb, dict(fx=fx[..., b], R1=R1), kl_step=0.05, lims=lims,
+                                                    max_iter=30)
+        assert (tr["status"][b], tr["iter"][b], tr["n_backpass"][b]) == (info["status"], info["iter"], info["n_backpass"]), b
+        assert relerr(np.asarray(tr["η"])[:, b], info["eta"]) < 1e-7
+        assert relerr(xo[..., b], xr) < 1e-7 and relerr(uo[..., b], ur) < 1e-7 and relerr(pol.K[..., b], polr["K"]) < 1e-7
