@@ -151,7 +151,15 @@ def back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u, *, fx_batc
     assert cxu.shape[:2] == (n, m), "size(cxu) should be (n, m)"
     assert cuu.reshape((m, m) + cuu.shape[2:] if cuu.ndim >= 2 else (m, m)).shape[:2] == (m, m), "size(cuu)"
     cuu = cuu.reshape((m, m) + (cuu.shape[2:] if cuu.ndim >= 2 else ()))
+    # full extents (the reference asserts size(cxx) == (n,n,N) etc.; the C side would read out of bounds otherwise)
+    tail_f = ((N,) if fx_tv else ()) + ((B,) if fx_batched else ())
+    tail_c = ((N,) if cost_tv else ()) + ((B,) if cost_batched else ())
+    assert cu.shape == (m, N) + ((B,) if batched else ()), "size(cu) should be (m, N[, B])"
+    assert u.shape == cu.shape, "size(u) should be (m, N[, B])"
+    assert fx.shape == (n, n) + tail_f and fu.shape == (n, m) + tail_f, "size(fx), size(fu): time / batch extents"
+    assert cxx.shape == (n, n) + tail_c and cxu.shape == (n, m) + tail_c and cuu.shape == (m, m) + tail_c, "size(cxx), size(cxu), size(cuu): time / batch extents"
     L = _lims(lims)
+    assert L is None or L.shape == (m, 2), "lims should be (m, 2)"
     d = _lib.BPDesc(n, m, N, B, int(fx_tv), int(fx_batched), int(cost_tv), int(cost_batched), int(regType),
                     int(L is not None))
     lam = np.ascontiguousarray(np.broadcast_to(np.asarray(λ, dtype=np.float64), (B,)))
@@ -248,6 +256,20 @@ def mpc_shift(a, shift=1, *, zero_tail=False, batched=None, handle=None):
     return out
 
 
+def _check_problem(problem, n, m, N, B):
+    """extents of a registered family's arrays against the call's sizes (the C side trusts them)"""
+    if problem.kind == 1:
+        if (n, m) != (4, 1):
+            raise ValueError("PendcartProblem has n = 4, m = 1")
+        return
+    tail = ((N,) if problem.dyn_tv else ()) + ((B,) if problem.dyn_batched else ())
+    A, Bm = np.asarray(problem.A), np.asarray(problem.B)
+    if A.shape != (n, n) + tail or Bm.shape != (n, m) + tail:
+        raise ValueError("LQProblem: A should be (n,n%s), B (n,m%s)" % ((",".join([""] + ["N"] * problem.dyn_tv + ["B"] * problem.dyn_batched),) * 2))
+    if np.shape(problem.Q) != (n, n) or np.shape(np.atleast_2d(problem.R)) != (m, m):
+        raise ValueError("LQProblem: Q should be (n,n), R (m,m)")
+
+
 # ------------------------------------------------------------------------------- forward_pass
 def forward_pass(traj_new, x0, u, x, α, problem, lims, *, handle=None):
     """Drop-in for ``forward_pass(traj_new,x0,u,x,α,f,costfun,lims,diff)`` (forward_pass.jl:9) with a
@@ -262,12 +284,19 @@ def forward_pass(traj_new, x0, u, x, α, problem, lims, *, handle=None):
     n = x0.shape[0]
     B = u.shape[2] if batched else 1
     dp = _DevProblem(problem, N, B)
+    if x0.shape != ((n, B) if batched else (n,)) and not (not batched and x0.shape == (n, 1)):
+        raise ValueError("x0 should be (n,) — (n, B) with a batched u")
+    _check_problem(problem, n, m, N, B)
     alphas = np.atleast_1d(np.asarray(α, dtype=np.float64))
     na = len(alphas)
     empty = traj_new is None or traj_new.isempty()
     K = None if empty else _lib.f64(traj_new.K)
     k = None if empty else _lib.f64(traj_new.k)
     xx = None if empty else _lib.f64(x)
+    if not empty:
+        tb = (B,) if batched else ()
+        if K.shape != (m, n, N) + tb or k.shape != (m, N) + tb or xx.shape != (n, N) + tb:
+            raise ValueError("traj_new.K, traj_new.k, x should be (m,n,N), (m,N), (n,N) [+ batch axis]")
     L = _lims(lims)
     CL = dp.cost_len
     xnew = np.zeros((n, N, B, na), order="F"); unew = np.zeros((m, N, B, na), order="F")
@@ -350,6 +379,9 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
             x0 = _lib.f64(x0[:, 0])
         else:
             raise ValueError("pre-rolled initial trajectory must be of correct length (size(x0,2) == N)")     # iLQG.jl:199
+    if x0.shape != (((n, N) if prerolled else (n,)) + ((B,) if batched else ())):
+        raise ValueError("x0 should be (n,) / pre-rolled (n, N) — with a batched u0: (n, B) / (n, N, B)")
+    _check_problem(problem, n, m, N, B)
     dp = _DevProblem(problem, N, B)
     o = _lib.ILQGOpts()
     _lib.lib().ddp_ilqg_default_opts(_C.byref(o))

@@ -594,6 +594,7 @@ int ddp_launch_back_pass_gps(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const int32_t *active, double *K, double *k, double *Quu, double *Quui, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge)
 {
+    DDP_DEVICE(h);
 #ifndef DDP_FAST_BUILD
     DDP_CHECK(d->n >= 1 && d->m >= 1 && d->N >= 1 && d->B >= 1, "back_pass_gps: bad sizes n=%d m=%d N=%d B=%d", d->n, d->m, d->N, d->B);
     DDP_CHECK(d->fx_tv && d->cost_tv, "back_pass_gps: needs time-varying (3-D) fx/fu and cxx/cxu/cuu like backward_pass.jl:259");
@@ -627,6 +628,7 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
                          const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                          double *Vxx, double *dV, int32_t *diverge)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(d->n >= 1 && d->m >= 1 && d->N >= 1 && d->B >= 1, "back_pass: bad sizes n=%d m=%d N=%d B=%d", d->n, d->m, d->N, d->B);
     DDP_CHECK(d->regType == 1 || d->regType == 2, "back_pass: regType must be 1 or 2 (got %d)", d->regType);
     DDP_CHECK(!d->has_lims || (lims && u), "back_pass: has_lims needs lims and u");

@@ -74,6 +74,7 @@ int ddp_destroy(ddp_handle h)
 
 int ddp_sync(ddp_handle h)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h, "ddp_sync: null handle");
     DDP_HIP(hipStreamSynchronize(h->stream));
     return 0;
@@ -90,12 +91,14 @@ int ddp_malloc(ddp_handle h, size_t bytes, void **dptr)
 }
 int ddp_free(ddp_handle h, void *dptr)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h, "ddp_free: null handle");
     if (dptr) { DDP_HIP(hipStreamSynchronize(h->stream)); DDP_HIP(hipFree(dptr)); }
     return 0;
 }
 int ddp_memcpy_h2d(ddp_handle h, void *dst, const void *src, size_t bytes)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h, "ddp_memcpy_h2d: null handle");
     DDP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     DDP_HIP(hipStreamSynchronize(h->stream));
@@ -103,6 +106,7 @@ int ddp_memcpy_h2d(ddp_handle h, void *dst, const void *src, size_t bytes)
 }
 int ddp_memcpy_d2h(ddp_handle h, void *dst, const void *src, size_t bytes)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h, "ddp_memcpy_d2h: null handle");
     DDP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     DDP_HIP(hipStreamSynchronize(h->stream));
@@ -110,6 +114,7 @@ int ddp_memcpy_d2h(ddp_handle h, void *dst, const void *src, size_t bytes)
 }
 int ddp_memset(ddp_handle h, void *dst, int value, size_t bytes)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h, "ddp_memset: null handle");
     DDP_HIP(hipMemsetAsync(dst, value, bytes, h->stream));
     return 0;
@@ -130,6 +135,7 @@ int ddp_event_destroy(ddp_handle h, void *ev)
 }
 int ddp_event_record(ddp_handle h, void *ev)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && ev, "ddp_event_record: null argument");
     DDP_HIP(hipEventRecord((hipEvent_t)ev, h->stream));
     return 0;
@@ -146,6 +152,7 @@ int ddp_event_elapsed_ms(ddp_handle h, void *start, void *stop, float *ms)
 
 int ddp_scratch(ddp_handle h, size_t bytes, void **out)
 {
+    DDP_DEVICE(h);
     if (bytes > h->scratch_bytes) {
         DDP_HIP(hipStreamSynchronize(h->stream));
         if (h->scratch) DDP_HIP(hipFree(h->scratch));
@@ -296,6 +303,7 @@ int ddp_boxqp_f64_dev(ddp_handle h, int m, int count, const double *H, const dou
                       const double *upper, const double *x0, const ddp_qp_opts *opts, double *x,
                       int32_t *result, double *Hfree, uint8_t *free_out)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h, "boxqp: null handle");
     DDP_CHECK(m >= 1 && m <= DDP_MAX_M, "boxqp: m=%d out of [1,%d]", m, DDP_MAX_M);
     DDP_CHECK(count >= 1, "boxqp: count=%d", count);

@@ -43,6 +43,14 @@ void ddp_set_error(const char *fmt, ...);
         }                                                                                     \
     } while (0)
 
+// every public entry point makes the handle's device current first: a process may hold handles on several devices, and scratch
+// allocations / kernel launches go to the CURRENT device of the calling thread.  A handle is single-threaded (ddp_amd.h).
+#define DDP_DEVICE(h)                                                                         \
+    do {                                                                                      \
+        if (!(h)) { ddp_set_error("null handle"); return -1; }                                \
+        DDP_HIP(hipSetDevice((h)->device));                                                   \
+    } while (0)
+
 // grows the handle's scratch to at least `bytes` (contents not preserved)
 int ddp_scratch(ddp_handle h, size_t bytes, void **out);
 

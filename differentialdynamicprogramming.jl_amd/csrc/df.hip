@@ -281,6 +281,7 @@ extern "C" {
 int ddp_df_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
                    double *cx, double *cu, double *fx, double *fu)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && p && x && u && cx && cu, "df: null argument");
     const long cols = (long)p->N * p->B;
     if (p->kind == DDP_PROBLEM_LQ) {

@@ -235,6 +235,7 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
                              int nalpha, const double *lims, const int32_t *active, double *xnew,
                              double *unew, double *cnew, double *csum)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && p, "forward_pass: null handle/problem");
     DDP_CHECK(nalpha >= 1 && nalpha <= 16, "forward_pass: nalpha=%d out of [1,16]", nalpha);
     DDP_CHECK((K == nullptr) == (k == nullptr), "forward_pass: K and k must both be given or both NULL");

@@ -268,6 +268,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
                      double *Vxx, double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters,
                      bool prerolled, const double *cost0, double *trace7 = nullptr)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && p && x0 && u0 && x && u && K && k && Quu && Vx && Vxx && cost && stats, "ilqg: null argument");
     ddp_ilqg_opts od;
     if (!oo) { ddp_ilqg_default_opts(&od); oo = &od; }
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(256) void batch_stats_kernel(int B, const double *c
 
 int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const double *dV, const int32_t *diverge, double *out4)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && out4 && B >= 1, "batch_stats: bad argument");
     hipLaunchKernelGGL(batch_stats_kernel, dim3(1), dim3(256), 0, h->stream, B, csum, dV, diverge, out4);
     DDP_HIP(hipGetLastError());
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(256) void mpc_shift_kernel(int d, int N, long total
 
 int ddp_mpc_shift_f64_dev(ddp_handle h, int d, int N, int B, int shift, int zero_tail, const double *src, double *dst)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && src && dst && src != dst, "mpc_shift: null or aliased argument (out of place only)");
     DDP_CHECK(d > 0 && N > 0 && B > 0 && shift >= 0, "mpc_shift: d=%d N=%d B=%d shift=%d", d, N, B, shift);
     const long total = (long)d * N * B;
@@ -484,6 +487,7 @@ int ddp_mpc_shift_f64_dev(ddp_handle h, int d, int N, int B, int shift, int zero
 int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const double *u, const int32_t *active,
                         double *cost, double *csum)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && p && x && u && cost, "costfun: null argument");
     hipLaunchKernelGGL(costfun_kernel, dim3((unsigned)p->B), dim3(64), 0, h->stream, p->kind, p->n, p->m, p->N, ddp_cost_len(p), p->Q, p->R,
                        p->goal[0], p->goal[1], p->goal[2], p->goal[3], x, u, active, cost, csum);
@@ -496,6 +500,7 @@ static int ilqg_host(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
                      const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
                      double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters, double *trace7 = nullptr)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && p && x0 && u0, "ilqg: null argument");
     const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p);
     const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? B : 1);

@@ -212,6 +212,7 @@ extern "C" {
 int ddp_kl_terms_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *K, const double *k, const double *Sigmai,
                          double *cx, double *cu, double *cxx, double *cxu, double *cuu)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && K && k && Sigmai && cx && cu && cxx && cxu && cuu, "kl_terms: null argument");
     DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "kl_terms: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
     const long NB = (long)N * B;
@@ -227,6 +228,7 @@ int ddp_back_pass_gps_f64_dev(ddp_handle h, const ddp_bp_desc *d,
                               double *K, double *k, double *Quu, double *Quui, double *Vx, double *Vxx, double *dV,
                               int32_t *diverge)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && d && cx && cu && cxx && cxu && cuu && fx && fu && kl && K && k && Quu && Quui && Vx && Vxx && dV && diverge,
               "back_pass_gps: null argument");
     DDP_HIP(hipMemsetAsync(Quui, 0, sizeof(double) * (size_t)d->m * d->m * d->N * d->B, h->stream));
@@ -241,6 +243,7 @@ int ddp_back_pass_gps_f64_dev(ddp_handle h, const ddp_bp_desc *d,
 int ddp_forward_covariance_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *fx, int fx_batched,
                                    const double *R1, const double *K, const double *Sigma, double *sigmanew)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && fx && R1 && K && Sigma && sigmanew, "forward_covariance: null argument");
     DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "forward_covariance: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
     hipLaunchKernelGGL(fcov_kernel, dim3(B), dim3(DDP_WAVE), fcov_lds(n, m), h->stream, n, m, N, fx, fx_batched, R1, K, Sigma, sigmanew);
@@ -253,6 +256,7 @@ int ddp_kl_div_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *x
                        const double *Kp, const double *kp, const double *Sp, const double *Sip,
                        double *kldiv, double *klmean)
 {
+    DDP_DEVICE(h);
     DDP_CHECK(h && xnew && xold && sigmanew && Kn && kn && Sn && Kp && kp && Sp && Sip && kldiv && klmean, "kl_div: null argument");
     DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "kl_div: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
     hipLaunchKernelGGL(kl_div_kernel, dim3(B), dim3(DDP_WAVE), 0, h->stream, n, m, N, xnew, xold, sigmanew, Kn, kn, Sn, Kp, kp, Sp, Sip,

@@ -1,12 +1,21 @@
-# DDPAmd.jl — thin `@ccall` binding of libddp_amd.so (include/ddp_amd.h) that keeps the reference's
-# call signatures for the hot path.  NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia
-# toolchain; every call below is mirrored one-to-one by the ctypes host in ../__init__.py, which is what
-# the tests drive.  See INTEGRATION.md for how a maintainer of DifferentialDynamicProgramming.jl wires it in.
+# DDPAmd.jl — `@ccall` binding of libddp_amd.so (include/ddp_amd.h) that keeps the reference's call signatures for the hot path
+# and adds what the GPU needs to pay off: a BATCH axis and DEVICE-RESIDENT operands.
 #
-#   DDPAmd.back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u)   ↔ src/backward_pass.jl:162-252
-#   DDPAmd.boxQP(H,g,lower,upper,x0)                               ↔ src/boxQP.jl:29-188
-#   DDPAmd.forward_pass(traj_new,x0,u,x,α,problem,lims)            ↔ src/forward_pass.jl:9-33
-#   DDPAmd.iLQG(problem,x0,u0; lims, kwargs...)                    ↔ src/iLQG.jl:143-341
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia toolchain.  Every `@ccall` below is checked against the
+# header by tests/test_julia_binding.py (name, arity, argument and return types, struct layouts) and mirrored one-to-one by
+# the ctypes host in ../__init__.py, which is what the GPU tests drive.  INTEGRATION.md shows how a maintainer of
+# DifferentialDynamicProgramming.jl wires it in.
+#
+#   drop-in entry points (one trajectory = the reference's arrays unchanged; a trailing batch axis solves B problems at once)
+#     DDPAmd.iLQG(f, costfun, df, x0, u0; lims, α, tol_fun, ...)          ↔ src/iLQG.jl:143-341
+#         f a registered problem (LQProblem / PendcartProblem are callable like `f`)  → device-resident driver
+#         f any other closure  → the reference's own loop with `back_pass` (STEP 2, iLQG.jl:235-251) on the GPU (`install!`)
+#     DDPAmd.back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u)        ↔ src/backward_pass.jl:162-252
+#     DDPAmd.boxQP(H,g,lower,upper,x0)                                    ↔ src/boxQP.jl:29-188
+#     DDPAmd.forward_pass(traj_new,x0,u,x,α,problem,lims)                 ↔ src/forward_pass.jl:9-33
+#     DDPAmd.∇kl / back_pass_gps / forward_covariance / kl_div_wiki       ↔ src/klutils.jl, backward_pass.jl:259-350, forward_pass.jl:37-56
+#   device-resident (`DevArray`, or any array type whose `pointer` is a device pointer, e.g. AMDGPU.ROCArray)
+#     back_pass_dev!, forward_pass_dev!, df_dev!, iLQG_dev!
 module DDPAmd
 
 using LinearAlgebra
@@ -15,27 +24,77 @@ const libddp = get(ENV, "DDP_AMD_LIB", joinpath(@__DIR__, "..", "libddp_amd.so")
 
 # ---- C structs (field order = include/ddp_amd.h) -------------------------------------------------
 struct BPDesc
-    n::Cint; m::Cint; N::Cint; B::Cint
-    fx_tv::Cint; fx_batched::Cint; cost_tv::Cint; cost_batched::Cint
-    regType::Cint; has_lims::Cint
+    n::Cint
+    m::Cint
+    N::Cint
+    B::Cint
+    fx_tv::Cint
+    fx_batched::Cint
+    cost_tv::Cint
+    cost_batched::Cint
+    regType::Cint
+    has_lims::Cint
+end
+
+struct QPOpts
+    maxIter::Cint
+    minGrad::Cdouble
+    minRelImprove::Cdouble
+    stepDec::Cdouble
+    minStep::Cdouble
+    Armijo::Cdouble
 end
 
 struct CProblem
-    kind::Cint; n::Cint; m::Cint; N::Cint; B::Cint
-    A::Ptr{Float64}; Bm::Ptr{Float64}; dyn_tv::Cint; dyn_batched::Cint
-    Q::Ptr{Float64}; R::Ptr{Float64}
-    g::Float64; l::Float64; h::Float64; d::Float64
-    goal::NTuple{4,Float64}
+    kind::Cint
+    n::Cint
+    m::Cint
+    N::Cint
+    B::Cint
+    A::Ptr{Float64}
+    Bm::Ptr{Float64}
+    dyn_tv::Cint
+    dyn_batched::Cint
+    Q::Ptr{Float64}
+    R::Ptr{Float64}
+    g::Cdouble
+    l::Cdouble
+    h::Cdouble
+    d::Cdouble
+    goal::NTuple{4,Cdouble}
 end
 
 struct ILQGOpts
-    lambda::Float64; dlambda::Float64; lambda_factor::Float64; lambda_max::Float64; lambda_min::Float64
-    tol_fun::Float64; tol_grad::Float64
-    max_iter::Cint; regType::Cint
-    reduce_ratio_min::Float64
+    lambda::Cdouble
+    dlambda::Cdouble
+    lambda_factor::Cdouble
+    lambda_max::Cdouble
+    lambda_min::Cdouble
+    tol_fun::Cdouble
+    tol_grad::Cdouble
+    max_iter::Cint
+    regType::Cint
+    reduce_ratio_min::Cdouble
     n_alpha::Cint
-    alpha::NTuple{16,Float64}
+    alpha::NTuple{16,Cdouble}
 end
+
+struct KLCostTerms
+    cx::Ptr{Float64}
+    cu::Ptr{Float64}
+    cxx::Ptr{Float64}
+    cxu::Ptr{Float64}
+    cuu::Ptr{Float64}
+    eta::Ptr{Float64}
+    eta_tv::Cint
+end
+
+const NULLF = Ptr{Float64}(C_NULL)
+const NULLI = Ptr{Int32}(C_NULL)
+
+# ---- handle ---------------------------------------------------------------------------------------
+last_error() = unsafe_string(@ccall libddp.ddp_last_error()::Cstring)
+check(rc) = rc == 0 ? nothing : error("libddp_amd: $(last_error()) (rc=$rc)")   # there is no CPU fallback
 
 mutable struct Handle
     ptr::Ptr{Cvoid}
@@ -43,145 +102,297 @@ mutable struct Handle
         r = Ref{Ptr{Cvoid}}(C_NULL)
         check(@ccall libddp.ddp_create(device::Cint, r::Ptr{Ptr{Cvoid}})::Cint)
         h = new(r[])
-        finalizer(h -> (@ccall libddp.ddp_destroy(h.ptr::Ptr{Cvoid})::Cint), h)
-        h
+        finalizer(hh -> (@ccall libddp.ddp_destroy(hh.ptr::Ptr{Cvoid})::Cint), h)
+        return h
     end
 end
 
-last_error() = unsafe_string(@ccall libddp.ddp_last_error()::Cstring)
-check(rc) = rc == 0 ? nothing : error("libddp_amd: $(last_error()) (rc=$rc)")   # there is no CPU fallback
-
 const _default = Ref{Union{Nothing,Handle}}(nothing)
-default_handle() = (_default[] === nothing && (_default[] = Handle(0)); _default[])
+default_handle() = (_default[] === nothing && (_default[] = Handle(0)); _default[]::Handle)
+sync(h::Handle=default_handle()) = check(@ccall libddp.ddp_sync(h.ptr::Ptr{Cvoid})::Cint)
+device_count() = Int(@ccall libddp.ddp_device_count()::Cint)
 
-# the reference's output container (src/iLQG.jl:39-53); redefine or reuse the package's own type
+# ---- output container (src/iLQG.jl:39-53); with a batch the arrays carry a trailing axis ------------
 mutable struct GaussianPolicy{P}
-    T::Int; n::Int; m::Int
-    K::Array{P,3}; k::Array{P,2}; Σ::Array{P,3}; Σi::Array{P,3}
+    T::Int
+    n::Int
+    m::Int
+    K::Array{P}
+    k::Array{P}
+    Σ::Array{P}
+    Σi::Array{P}
 end
+GaussianPolicy(P::Type) = GaussianPolicy{P}(0, 0, 0, zeros(P, 0, 0, 0), zeros(P, 0, 0), zeros(P, 0, 0, 0), zeros(P, 0, 0, 0))
+Base.isempty(p::GaussianPolicy) = p.T == p.n == p.m == 0
+Base.length(p::GaussianPolicy) = p.T
+_isempty_policy(p) = p === nothing || (p.T == 0 && p.n == 0 && p.m == 0)
 
-# ---- registered problem families (stand-ins for the closures f / costfun / df) --------------------
-struct LQProblem
-    A::Array{Float64}; B::Array{Float64}; Q::Matrix{Float64}; R::Matrix{Float64}
+# ---- registered problem families: callable like the closure `f(x,u,i)`, so `iLQG(problem, costfun, df, x0, u0)` dispatches ----
+abstract type RegisteredProblem end
+
+"x⁺ = A x + B u, cost ½Σx∘Qx + ½Σu∘Ru (src/demo_linear.jl:30-50); A,B: [n,n]/[n,m], [..,N] (LTV), [..,B] / [..,N,B] with `dyn_batched`"
+struct LQProblem <: RegisteredProblem
+    A::Array{Float64}
+    B::Array{Float64}
+    Q::Matrix{Float64}
+    R::Matrix{Float64}
+    dyn_batched::Bool
 end
-Base.@kwdef struct PendcartProblem
-    g::Float64 = 9.82; l::Float64 = 0.35; h::Float64 = 0.01; d::Float64 = 0.99
-    Q::Matrix{Float64} = Matrix(Diagonal([10.0, 1, 2, 1])); R::Matrix{Float64} = fill(1.0, 1, 1)
+LQProblem(A, B, Q, R; dyn_batched::Bool=false) = LQProblem(Array{Float64}(A), Array{Float64}(B), Matrix{Float64}(Q), Matrix{Float64}(R), dyn_batched)
+(p::LQProblem)(x, u, i) = (ndims(p.A) == 2 ? p.A : view(p.A, :, :, i)) * x + (ndims(p.B) == 2 ? p.B : view(p.B, :, :, i)) * u
+
+"pendulum on a cart (src/system_pendcart.jl:42-59,83-106): explicit Euler step, quadratic cost of length N+1"
+Base.@kwdef struct PendcartProblem <: RegisteredProblem
+    g::Float64 = 9.82
+    l::Float64 = 0.35
+    h::Float64 = 0.01
+    d::Float64 = 0.99
+    Q::Matrix{Float64} = Matrix(Diagonal([10.0, 1, 2, 1]))
+    R::Matrix{Float64} = fill(1.0, 1, 1)
     goal::Vector{Float64} = [π, 0, 0, 0]
 end
+(p::PendcartProblem)(x, u, i) = [x[1] + p.h * x[2], x[2] + p.h * (-p.g / p.l * sin(x[1]) + u[1] / p.l * cos(x[1]) - p.d * x[2]),
+                                 x[3] + p.h * x[4], x[4] + p.h * u[1]]
 
-cproblem(p::LQProblem, N, B) = CProblem(0, size(p.A, 1), size(p.B, 2), N, B, pointer(p.A), pointer(p.B),
-                                         ndims(p.A) == 3, 0, pointer(p.Q), pointer(p.R), 0, 0, 0, 0, (0.0, 0.0, 0.0, 0.0))
-cproblem(p::PendcartProblem, N, B) = CProblem(1, 4, 1, N, B, C_NULL, C_NULL, 0, 0, pointer(p.Q), pointer(p.R),
-                                               p.g, p.l, p.h, p.d, Tuple(p.goal))
+dims(p::LQProblem) = (size(p.A, 1), size(p.B, 2))
+dims(::PendcartProblem) = (4, 1)
+cost_len(::LQProblem, N) = N
+cost_len(::PendcartProblem, N) = N + 1
+dyn_tv(p::LQProblem) = (ndims(p.A) - (p.dyn_batched ? 1 : 0)) == 3
+
+# C view of a problem; `A`, `Bm`, `Q`, `R` are host or device pointers depending on the entry point it is passed to
+cproblem(p::LQProblem, N, B; A=pointer(p.A), Bm=pointer(p.B), Q=pointer(p.Q), R=pointer(p.R)) =
+    CProblem(0, size(p.A, 1), size(p.B, 2), N, B, A, Bm, dyn_tv(p), p.dyn_batched, Q, R, 0.0, 0.0, 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
+cproblem(p::PendcartProblem, N, B; A=NULLF, Bm=NULLF, Q=pointer(p.Q), R=pointer(p.R)) =
+    CProblem(1, 4, 1, N, B, A, Bm, 0, 0, Q, R, p.g, p.l, p.h, p.d, (p.goal[1], p.goal[2], p.goal[3], p.goal[4]))
 
 _f64(a) = Array{Float64}(a)      # dense column-major copy (handles Diagonal cxx, Vector cuu of the demos)
+_lims(lims) = (lims === nothing || isempty(lims)) ? Float64[] : _f64(lims)
+_ptr_or_null(a::Array{Float64}) = isempty(a) ? NULLF : pointer(a)
 
+# ======================================================================================= host-array API
 """
     back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u) -> diverge, GaussianPolicy, Vx, Vxx, dV
 
-Same signature, dispatch (array rank selects LTI / LTV / time-varying cost) and return values as the
-reference's linear-system `back_pass` methods.  One trajectory (B = 1) goes through the host-pointer
-entry point; arrays are passed as they are (Julia memory layout is the ABI's layout).
+Same signature, dispatch (array rank selects LTI / LTV / time-varying cost) and return values as the reference's linear-system
+`back_pass` methods (src/backward_pass.jl:162,179,217).  `cx[n,N,B]` solves a batch: `λ` may then be a vector, `fx`/`cxx` of
+one more rank are per trajectory, every output carries the batch axis and `diverge` is a vector.
 """
-function back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u; handle=default_handle())
-    n, N = size(cx); m = size(cu, 1)
+function back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u; handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
+    batched = ndims(cx) == 3
+    n, N = size(cx, 1), size(cx, 2)
+    m = size(cu, 1)
+    B = batched ? size(cx, 3) : 1
     cx, cu, cxx, cxu, fx, fu, u = map(_f64, (cx, cu, cxx, cxu, fx, fu, u))
-    cuu = reshape(_f64(cuu), m, m, :)
-    has_lims = !isempty(lims)
-    d = BPDesc(n, m, N, 1, ndims(fx) == 3, 0, ndims(cxx) == 3, 0, regType, has_lims)
-    K = zeros(m, n, N); k = zeros(m, N); Quu = zeros(m, m, N); Vx = zeros(n, N); Vxx = zeros(n, n, N); dV = zeros(2)
-    diverge = Ref{Int32}(0)
-    lam = [Float64(λ)]
-    limsp = has_lims ? _f64(lims) : Float64[]
-    GC.@preserve cx cu cxx cxu cuu fx fu u lam limsp K k Quu Vx Vxx dV begin
+    cuu = reshape(_f64(cuu), m, m, size(_f64(cuu))[3:end]...)
+    fx_batched = ndims(fx) == 4 || (batched && ndims(fx) == 3 && size(fx, 3) == B && B != N)
+    cost_batched = ndims(cxx) == 4
+    fx_tv = (ndims(fx) - (fx_batched ? 1 : 0)) == 3
+    cost_tv = (ndims(cxx) - (cost_batched ? 1 : 0)) == 3
+    @assert size(cu) == (m, N, (batched ? (B,) : ())...) "size(cu) should be (m, N)"
+    @assert size(fx)[1:2] == (n, n) && size(fu)[1:2] == (n, m) "size(fx), size(fu)"
+    @assert size(cxx)[1:2] == (n, n) "size(cxx) should be (n, n)"
+    @assert size(cxu)[1:2] == (n, m) "size(cxu) should be (n, m)"
+    limsp = _lims(lims)
+    has_lims = !isempty(limsp)
+    d = BPDesc(n, m, N, B, fx_tv, fx_batched, cost_tv, cost_batched, regType, has_lims)
+    bt = batched ? (B,) : ()
+    K = zeros(m, n, N, bt...); k = zeros(m, N, bt...); Quu = zeros(m, m, N, bt...)
+    Vx = zeros(n, N, bt...); Vxx = zeros(n, n, N, bt...); dV = zeros(2, bt...)
+    diverge = zeros(Int32, B)
+    lam = λ isa Number ? fill(Float64(λ), B) : _f64(λ)
+    GC.@preserve cx cu cxx cxu cuu fx fu u lam limsp K k Quu Vx Vxx dV diverge begin
         check(@ccall libddp.ddp_back_pass_f64(handle.ptr::Ptr{Cvoid}, Ref(d)::Ptr{BPDesc},
             cx::Ptr{Float64}, cu::Ptr{Float64}, cxx::Ptr{Float64}, cxu::Ptr{Float64}, cuu::Ptr{Float64},
             fx::Ptr{Float64}, fu::Ptr{Float64}, lam::Ptr{Float64},
-            (has_lims ? pointer(limsp) : Ptr{Float64}(C_NULL))::Ptr{Float64},
-            (has_lims ? pointer(u) : Ptr{Float64}(C_NULL))::Ptr{Float64},
+            _ptr_or_null(limsp)::Ptr{Float64}, (has_lims ? pointer(u) : NULLF)::Ptr{Float64},
             K::Ptr{Float64}, k::Ptr{Float64}, Quu::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64},
             dV::Ptr{Float64}, diverge::Ptr{Int32})::Cint)
     end
     # Σ (= Quui) is never written by the reference's back_pass (`undef`, backward_pass.jl:231); zeros here
-    return Int(diverge[]), GaussianPolicy(N, n, m, K, k, zeros(m, m, N), Quu), Vx, Vxx, dV
+    pol = policy(N, n, m, K, k, zeros(m, m, N, bt...), Quu)
+    return (batched ? Vector{Int}(diverge) : Int(diverge[1])), pol, Vx, Vxx, dV
 end
 
 """
-    boxQP(H,g,lower,upper,x0; maxIter=100, ...) -> x, result, Hfree, free
+    boxQP(H,g,lower,upper,x0; maxIter=100, ...) -> x, result, Hfree, free, trace        (src/boxQP.jl:29-36)
+
+`H[m,m,count]` with matrix-shaped `g, lower, upper, x0` solves `count` problems in one launch.
 """
-function boxQP(H, g, lower, upper, x0::AbstractVector; maxIter=100, minGrad=1e-8, minRelImprove=1e-8,
-               stepDec=0.6, minStep=1e-22, Armijo=0.1, handle=default_handle())
+function boxQP(H, g, lower, upper, x0::AbstractVecOrMat; maxIter=100, minGrad=1e-8, minRelImprove=1e-8,
+               stepDec=0.6, minStep=1e-22, Armijo=0.1, print=0, handle::Handle=default_handle())
+    batched = ndims(H) == 3
     m = size(H, 1)
+    cnt = batched ? size(H, 3) : 1
     H, g, lower, upper, x0 = map(_f64, (H, g, lower, upper, x0))
-    x = zeros(m); Hf = zeros(m, m); res = Ref{Int32}(0); fr = zeros(UInt8, m)
-    opts = (Cint(maxIter), minGrad, minRelImprove, stepDec, minStep, Armijo)
-    GC.@preserve H g lower upper x0 x Hf fr begin
-        check(@ccall libddp.ddp_boxqp_f64(handle.ptr::Ptr{Cvoid}, m::Cint, 1::Cint, H::Ptr{Float64}, g::Ptr{Float64},
-            lower::Ptr{Float64}, upper::Ptr{Float64}, x0::Ptr{Float64}, Ref(opts)::Ptr{Cvoid},
+    x = zeros(m, cnt); Hf = zeros(m, m, cnt); res = zeros(Int32, cnt); fr = zeros(UInt8, m, cnt)
+    opts = QPOpts(maxIter, minGrad, minRelImprove, stepDec, minStep, Armijo)
+    GC.@preserve H g lower upper x0 x Hf res fr begin
+        check(@ccall libddp.ddp_boxqp_f64(handle.ptr::Ptr{Cvoid}, m::Cint, cnt::Cint, H::Ptr{Float64}, g::Ptr{Float64},
+            lower::Ptr{Float64}, upper::Ptr{Float64}, x0::Ptr{Float64}, Ref(opts)::Ptr{QPOpts},
             x::Ptr{Float64}, res::Ptr{Int32}, Hf::Ptr{Float64}, fr::Ptr{UInt8})::Cint)
     end
-    free = BitVector(fr .!= 0); nf = count(free)
-    return x, Int(res[]), UpperTriangular(Hf[1:nf, 1:nf]), free, nothing
+    if !batched
+        free = BitVector(fr[:, 1] .!= 0); nf = count(free)
+        return x[:, 1], Int(res[1]), UpperTriangular(Hf[1:nf, 1:nf, 1]), free, nothing
+    end
+    return x, Vector{Int}(res), Hf, fr .!= 0, nothing
 end
 
 """
     forward_pass(traj_new, x0, u, x, α, problem, lims) -> xnew, unew, cnew
 
-`problem` (LQProblem / PendcartProblem) replaces the closures `f`, `costfun`; `diff` is `-`.
+`problem` (LQProblem / PendcartProblem) replaces the closures `f`, `costfun` of src/forward_pass.jl:9; `diff` is `-`.
+`u[m,N,B]` with `x0[n,B]` rolls a batch out; a vector `α` rolls all step sizes out concurrently (trailing α axis).
 """
-function forward_pass(traj_new, x0, u, x, α, problem, lims; handle=default_handle())
-    m, N = size(u); n = length(x0)
-    P = cproblem(problem, N, 1)
-    CL = problem isa PendcartProblem ? N + 1 : N
-    empty = traj_new === nothing || traj_new.T == 0
-    xnew = zeros(n, N); unew = zeros(m, N); cnew = zeros(CL); csum = zeros(1)
-    a = [Float64(α)]; x0 = _f64(x0); u = _f64(u)
-    Kp = empty ? Ptr{Float64}(C_NULL) : pointer(traj_new.K); kp = empty ? Ptr{Float64}(C_NULL) : pointer(traj_new.k)
-    xp = empty ? Ptr{Float64}(C_NULL) : pointer(x)
-    lp = isempty(lims) ? Ptr{Float64}(C_NULL) : pointer(_f64(lims))
-    GC.@preserve problem traj_new x0 u x a xnew unew cnew csum begin
-        check(@ccall libddp.ddp_forward_pass_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Kp::Ptr{Float64}, kp::Ptr{Float64},
-            x0::Ptr{Float64}, u::Ptr{Float64}, xp::Ptr{Float64}, a::Ptr{Float64}, 1::Cint, lp::Ptr{Float64},
+function forward_pass(traj_new, x0, u, x, α, problem::RegisteredProblem, lims; handle::Handle=default_handle())
+    batched = ndims(u) == 3
+    m, N = size(u, 1), size(u, 2)
+    n = size(x0, 1)
+    B = batched ? size(u, 3) : 1
+    P = cproblem(problem, N, B)
+    CL = cost_len(problem, N)
+    empty = _isempty_policy(traj_new)
+    al = α isa Number ? [Float64(α)] : _f64(α)
+    na = length(al)
+    xnew = zeros(n, N, B, na); unew = zeros(m, N, B, na); cnew = zeros(CL, B, na); csum = zeros(B, na)
+    x0 = _f64(x0); u = _f64(u)
+    Kh = empty ? Float64[] : _f64(traj_new.K); kh = empty ? Float64[] : _f64(traj_new.k); xh = empty ? Float64[] : _f64(x)
+    limsp = _lims(lims)
+    GC.@preserve problem Kh kh xh x0 u al limsp xnew unew cnew csum begin
+        check(@ccall libddp.ddp_forward_pass_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, _ptr_or_null(Kh)::Ptr{Float64},
+            _ptr_or_null(kh)::Ptr{Float64}, x0::Ptr{Float64}, u::Ptr{Float64}, _ptr_or_null(xh)::Ptr{Float64}, al::Ptr{Float64},
+            na::Cint, _ptr_or_null(limsp)::Ptr{Float64},
             xnew::Ptr{Float64}, unew::Ptr{Float64}, cnew::Ptr{Float64}, csum::Ptr{Float64})::Cint)
+    end
+    sel(a) = (batched ? a : dropdims(a, dims=ndims(a) - 1))
+    xnew, unew, cnew = sel(xnew), sel(unew), sel(cnew)
+    if α isa Number
+        xnew, unew, cnew = map(a -> dropdims(a, dims=ndims(a)), (xnew, unew, cnew))
     end
     return xnew, unew, cnew
 end
 
 """
+    df(problem, x, u) -> fx,fu,fxx,fxu,fuu,cx,cu,cxx,cxu,cuu         (the `df` closure of the registered families, iLQG.jl:225-229)
+"""
+function df(problem::RegisteredProblem, x, u; handle::Handle=default_handle())
+    batched = ndims(u) == 3
+    m, N = size(u, 1), size(u, 2)
+    n = size(x, 1)
+    B = batched ? size(u, 3) : 1
+    P = cproblem(problem, N, B)
+    x = _f64(x); u = _f64(u)
+    bt = batched ? (B,) : ()
+    cx = zeros(n, N, bt...); cu = zeros(m, N, bt...)
+    pend = problem isa PendcartProblem
+    fx = pend ? zeros(n, n, N, bt...) : Float64[]
+    fu = pend ? zeros(n, m, N, bt...) : Float64[]
+    GC.@preserve problem x u cx cu fx fu begin
+        check(@ccall libddp.ddp_df_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, x::Ptr{Float64}, u::Ptr{Float64},
+            cx::Ptr{Float64}, cu::Ptr{Float64}, _ptr_or_null(fx)::Ptr{Float64}, _ptr_or_null(fu)::Ptr{Float64})::Cint)
+    end
+    if !pend
+        fx, fu = problem.A, problem.B
+    end
+    return fx, fu, [], [], [], cx, cu, problem.Q, zeros(n, m), problem.R
+end
+
+const DEFAULT_ALPHA = exp10.(range(0, stop=-3, length=11))     # iLQG.jl:145
+
+function _opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
+    length(α) <= 16 || error("at most 16 line-search step sizes are supported")
+    al = ntuple(i -> i <= length(α) ? Float64(α[i]) : 0.0, 16)
+    return ILQGOpts(λ, dλ, λfactor, λmax, λmin, tol_fun, tol_grad, max_iter, regType, reduce_ratio_min, length(α), al)
+end
+
+"""
     iLQG(problem, x0, u0; lims=[], α=..., tol_fun=1e-7, ...) -> x, u, traj_new, Vx, Vxx, cost, trace
 
-Device-resident solve for a registered problem family (same keyword arguments and defaults as
-src/iLQG.jl:143-163).  Arbitrary closures `f/costfun/df` keep the reference's own `iLQG` loop and
-offload only `back_pass` (see INTEGRATION.md).
+Device-resident solve for a registered problem family; keyword arguments and defaults of src/iLQG.jl:143-163.
+`u0[m,N,B]` with `x0[n,B]` solves B independent problems (own λ schedule, line search and termination each); `x0[n,N(,B)]` is a
+PRE-ROLLED trajectory with `cost` (iLQG.jl:193-197).  Returns `nothing` when the initial controls diverge (one trajectory, :209).
+`trace` is a Dict with the reference's trace keys per iteration (and trajectory) plus the per-trajectory summary `:stats`.
 """
-function iLQG(problem, x0, u0; lims=[], α=exp10.(range(0, stop=-3, length=11)), tol_fun=1e-7, tol_grad=1e-4,
-              max_iter=500, λ=1.0, dλ=1.0, λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0,
-              handle=default_handle(), kwargs...)
-    m, N = size(u0); n = size(x0, 1)
-    P = cproblem(problem, N, 1)
-    CL = problem isa PendcartProblem ? N + 1 : N
-    al = ntuple(i -> i <= length(α) ? Float64(α[i]) : 0.0, 16)
-    o = ILQGOpts(λ, dλ, λfactor, λmax, λmin, tol_fun, tol_grad, max_iter, regType, reduce_ratio_min, length(α), al)
-    x = zeros(n, N); u = zeros(m, N); K = zeros(m, n, N); k = zeros(m, N); Quu = zeros(m, m, N)
-    Vx = zeros(n, N); Vxx = zeros(n, n, N); cost = zeros(CL); stats = zeros(8)
-    cap = 4max_iter + 64; tr = zeros(cap); git = Ref{Cint}(0)
-    x0 = _f64(vec(x0)); u0 = _f64(u0)
-    lp = isempty(lims) ? Ptr{Float64}(C_NULL) : pointer(_f64(lims))
-    tcap = 4max_iter + 1000; timing = fill(NaN, tcap, 3)     # C layout [3, tcap]: column r of the Julia array is row r
-    GC.@preserve problem x0 u0 timing begin
-        check(@ccall libddp.ddp_ilqg_set_timing(handle.ptr::Ptr{Cvoid}, timing::Ptr{Float64}, tcap::Cint)::Cint)
-        check(@ccall libddp.ddp_ilqg_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGOpts},
-            x0::Ptr{Float64}, u0::Ptr{Float64}, lp::Ptr{Float64}, x::Ptr{Float64}, u::Ptr{Float64}, K::Ptr{Float64},
-            k::Ptr{Float64}, Quu::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64}, cost::Ptr{Float64},
-            stats::Ptr{Float64}, cap::Cint, tr::Ptr{Float64}, git::Ptr{Cint})::Cint)
-        @ccall libddp.ddp_ilqg_set_timing(handle.ptr::Ptr{Cvoid}, C_NULL::Ptr{Float64}, 0::Cint)::Cint
+function iLQG(problem::RegisteredProblem, x0, u0; lims=[], α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0,
+              λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0, diff_fun=-, plot=1, verbosity=2, plot_fun=x -> 0,
+              cost=[], traj_prev=0, print_head=10, handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
+    batched = ndims(u0) == 3
+    m, N = size(u0, 1), size(u0, 2)
+    n = size(x0, 1)
+    B = batched ? size(u0, 3) : 1
+    prerolled = size(x0, 2) == N && ndims(x0) == (batched ? 3 : 2) && N != 1
+    if !prerolled && ndims(x0) == (batched ? 3 : 2) && !(ndims(x0) == 2 && batched)
+        size(x0, 2) == 1 || error("pre-rolled initial trajectory must be of correct length (size(x0,2) == N)")   # iLQG.jl:199
     end
-    stats[1] == -1 && return nothing                       # EXIT: Initial control sequence caused divergence
+    P = cproblem(problem, N, B)
+    CL = cost_len(problem, N)
+    o = _opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
+    bt = batched ? (B,) : ()
+    x = zeros(n, N, bt...); u = zeros(m, N, bt...); K = zeros(m, n, N, bt...); k = zeros(m, N, bt...); Quu = zeros(m, m, N, bt...)
+    Vx = zeros(n, N, bt...); Vxx = zeros(n, n, N, bt...); costo = zeros(CL, bt...); stats = zeros(8, B)
+    cap = min(4max_iter + 64, 4096); tr7 = zeros(7, cap, B); git = Ref{Cint}(0)
+    x0h = prerolled ? _f64(x0) : _f64(reshape(x0, n, B)); u0h = _f64(u0)
+    c0 = (prerolled && !isempty(cost)) ? _f64(cost) : Float64[]
+    limsp = _lims(lims)
+    tcap = 4max_iter + 1000; timing = fill(NaN, tcap, 3)     # C layout [3, tcap]: column r of the Julia array is row r
+    GC.@preserve problem x0h u0h c0 limsp timing x u K k Quu Vx Vxx costo stats tr7 begin
+        check(@ccall libddp.ddp_ilqg_set_timing(handle.ptr::Ptr{Cvoid}, timing::Ptr{Float64}, tcap::Cint)::Cint)
+        rc = @ccall libddp.ddp_ilqg_ex_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGOpts},
+            x0h::Ptr{Float64}, (prerolled ? 1 : 0)::Cint, u0h::Ptr{Float64}, _ptr_or_null(c0)::Ptr{Float64}, _ptr_or_null(limsp)::Ptr{Float64},
+            x::Ptr{Float64}, u::Ptr{Float64}, K::Ptr{Float64}, k::Ptr{Float64}, Quu::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64},
+            costo::Ptr{Float64}, stats::Ptr{Float64}, cap::Cint, tr7::Ptr{Float64}, git::Ptr{Cint})::Cint
+        @ccall libddp.ddp_ilqg_set_timing(handle.ptr::Ptr{Cvoid}, NULLF::Ptr{Float64}, 0::Cint)::Cint
+        check(rc)
+    end
+    (!batched && stats[1, 1] == -1) && return nothing      # EXIT: Initial control sequence caused divergence (iLQG.jl:205-210)
     g = Int(git[])
-    trace = Dict(:cost => tr[1:max(Int(stats[2]) - 1, 0)], :λ => stats[6], :grad_norm => stats[7], :status => Int(stats[1]),
-                 :time_derivs => timing[1:g, 1], :time_backward => timing[1:g, 2], :time_forward => timing[1:g, 3])   # iLQG.jl:227,241,281
-    return x, u, GaussianPolicy(N, n, m, K, k, zeros(m, m, N), Quu), Vx, Vxx, cost, trace
+    keys7 = (:λ, :dλ, :α, :improvement, :cost, :reduce_ratio, :grad_norm)                                   # iLQG.jl:257,325-330
+    trace = Dict{Symbol,Any}(:stats => stats, :status => Int.(stats[1, :]), :iter => Int.(stats[2, :]), :global_iters => g,
+                             :time_derivs => timing[1:g, 1], :time_backward => timing[1:g, 2], :time_forward => timing[1:g, 3])
+    for (r, key) in enumerate(keys7)
+        trace[key] = batched ? tr7[r, :, :] : tr7[r, 1:max(Int(stats[2, 1]) - 1, 0), 1]
+    end
+    return x, u, policy(N, n, m, K, k, zeros(m, m, N, bt...), Quu), Vx, Vxx, costo, trace
+end
+
+# ---- the drop-in entry point ------------------------------------------------------------------------------------------
+const _ref = Ref{Any}(nothing)         # the reference module once `install!` has rebound its back_pass
+
+"""
+    install!(ref::Module = Main.DifferentialDynamicProgramming)
+
+Rebinds the three linear-system `back_pass` methods of the loaded reference package (src/backward_pass.jl:162,179,217) to
+`DDPAmd.back_pass`, so that the reference's own `iLQG(f,costfun,df,x0,u0; ...)` — arbitrary Julia closures, its own line search,
+trace and printing — runs STEP 2 (iLQG.jl:235-251) on the GPU.  Returns policies of the reference's own `GaussianPolicy` type.
+"""
+function install!(ref::Module=getfield(Main, :DifferentialDynamicProgramming))
+    pol(N, n, m, K, k, Σ, Σi) = ref.GaussianPolicy(N, n, m, K, k, Σ, Σi)
+    bp(args...) = back_pass(args...; policy=pol)
+    @eval ref begin
+        back_pass(cx, cu, cxx::AbstractArray{T,2}, cxu, cuu, fx::AbstractArray{T,3}, fu, λ, regType, lims, x, u) where {T} = $bp(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+        back_pass(cx, cu, cxx::AbstractArray{T,3}, cxu, cuu, fx::AbstractArray{T,3}, fu, λ, regType, lims, x, u) where {T} = $bp(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+        back_pass(cx, cu, cxx::AbstractArray{T,2}, cxu, cuu, fx::AbstractMatrix{T}, fu, λ, regType, lims, x, u) where {T} = $bp(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+    end
+    _ref[] = ref
+    return ref
+end
+
+"""
+    iLQG(f, costfun, df, x0, u0; lims=[], α=..., tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1., dλ=1., λfactor=1.6, λmax=1e10,
+         λmin=1e-6, regType=1, reduce_ratio_min=0, diff_fun=-, plot=1, verbosity=2, plot_fun=x->0, cost=[], traj_prev=0, print_head=10)
+
+THE drop-in for src/iLQG.jl:143-163 (same positional and keyword arguments, same return tuple).
+* `f` a registered problem (`LQProblem`, `PendcartProblem` — they are callable like `f(x,u,i)`): the whole iteration runs on the
+  device (`costfun`, `df` are the family's own); `u0[m,N,B]` solves a batch.
+* any other `f`: the reference's own loop with its `back_pass` rebound to the GPU (`install!`); needs the reference package loaded.
+"""
+function iLQG(f, costfun, df_, x0, u0; kwargs...)
+    if f isa RegisteredProblem
+        return iLQG(f, x0, u0; kwargs...)
+    end
+    ref = _ref[] === nothing ? install!() : _ref[]
+    return Base.invokelatest(ref.iLQG, f, costfun, df_, x0, u0; kwargs...)
 end
 
 """
@@ -189,7 +400,7 @@ end
 
 Receding-horizon warm start between two solves: `out[:, i] = a[:, i+shift]` along the time axis (the last axis of `u[m,N]`,
 `x[n,N]`, `K[m,n,N]`), the vacated tail repeats the last column or is zero.  Host arrays; device-resident loops call
-`ddp_mpc_shift_f64_dev` on their buffers instead.
+`ddp_mpc_shift_f64_dev` on their buffers (`mpc_shift_dev!`).
 """
 function mpc_shift(a::AbstractArray, shift::Integer=1; zero_tail::Bool=false)
     N = size(a, ndims(a)); out = similar(a)
@@ -197,24 +408,112 @@ function mpc_shift(a::AbstractArray, shift::Integer=1; zero_tail::Bool=false)
         src = i + shift
         selectdim(out, ndims(a), i) .= src <= N ? selectdim(a, ndims(a), src) : (zero_tail ? zero(eltype(a)) : selectdim(a, ndims(a), N))
     end
-    out
+    return out
 end
 
-# ---- KL-constrained path (src/backward_pass.jl:259-350, src/klutils.jl, src/forward_pass.jl:37-56) -------------------
-struct KLCostTerms
-    cx::Ptr{Float64}; cu::Ptr{Float64}; cxx::Ptr{Float64}; cxu::Ptr{Float64}; cuu::Ptr{Float64}; eta::Ptr{Float64}; eta_tv::Cint
+# ======================================================================================= device-resident API
+"""
+    DevArray(dims...; handle) / DevArray(hostarray; handle)
+
+fp64 device buffer owned by the library's allocator (`ddp_malloc`); `Array(d)` copies back.  Any array type whose `pointer` is a
+device pointer (AMDGPU.ROCArray) can be passed to the `_dev!` functions instead.
+"""
+mutable struct DevArray{T}
+    ptr::Ptr{T}
+    dims::Dims
+    handle::Handle
+    function DevArray{T}(dims::Dims; handle::Handle=default_handle()) where {T}
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(@ccall libddp.ddp_malloc(handle.ptr::Ptr{Cvoid}, (sizeof(T) * max(prod(dims), 1))::Csize_t, r::Ptr{Ptr{Cvoid}})::Cint)
+        d = new{T}(Ptr{T}(r[]), dims, handle)
+        finalizer(dd -> (@ccall libddp.ddp_free(dd.handle.ptr::Ptr{Cvoid}, dd.ptr::Ptr{Cvoid})::Cint), d)
+        return d
+    end
+end
+DevArray(dims::Integer...; handle::Handle=default_handle()) = DevArray{Float64}(Dims(dims); handle=handle)
+function DevArray(a::AbstractArray; handle::Handle=default_handle())
+    T = eltype(a) <: Integer ? Int32 : Float64
+    h = Array{T}(a)
+    d = DevArray{T}(size(h); handle=handle)
+    GC.@preserve h check(@ccall libddp.ddp_memcpy_h2d(handle.ptr::Ptr{Cvoid}, d.ptr::Ptr{Cvoid}, h::Ptr{Cvoid}, sizeof(h)::Csize_t)::Cint)
+    return d
+end
+Base.size(d::DevArray) = d.dims
+Base.pointer(d::DevArray) = d.ptr
+function Base.Array(d::DevArray{T}) where {T}
+    h = Array{T}(undef, d.dims...)
+    GC.@preserve h check(@ccall libddp.ddp_memcpy_d2h(d.handle.ptr::Ptr{Cvoid}, h::Ptr{Cvoid}, d.ptr::Ptr{Cvoid}, sizeof(h)::Csize_t)::Cint)
+    return h
+end
+dptr(a) = a === nothing ? NULLF : Ptr{Float64}(UInt(pointer(a)))
+diptr(a) = a === nothing ? NULLI : Ptr{Int32}(UInt(pointer(a)))
+
+"""
+    back_pass_dev!(K,k,Quu,Vx,Vxx,dV,diverge, desc::BPDesc, cx,cu,cxx,cxu,cuu,fx,fu, λ, lims,u; active=nothing)
+
+All operands device-resident (layouts of include/ddp_amd.h: batch slowest); asynchronous on the handle's stream.
+"""
+function back_pass_dev!(K, k, Quu, Vx, Vxx, dV, diverge, desc::BPDesc, cx, cu, cxx, cxu, cuu, fx, fu, λ, lims, u; active=nothing,
+                        handle::Handle=default_handle())
+    check(@ccall libddp.ddp_back_pass_f64_dev(handle.ptr::Ptr{Cvoid}, Ref(desc)::Ptr{BPDesc}, dptr(cx)::Ptr{Float64}, dptr(cu)::Ptr{Float64},
+        dptr(cxx)::Ptr{Float64}, dptr(cxu)::Ptr{Float64}, dptr(cuu)::Ptr{Float64}, dptr(fx)::Ptr{Float64}, dptr(fu)::Ptr{Float64},
+        dptr(λ)::Ptr{Float64}, dptr(lims)::Ptr{Float64}, dptr(u)::Ptr{Float64}, diptr(active)::Ptr{Int32},
+        dptr(K)::Ptr{Float64}, dptr(k)::Ptr{Float64}, dptr(Quu)::Ptr{Float64}, dptr(Vx)::Ptr{Float64}, dptr(Vxx)::Ptr{Float64},
+        dptr(dV)::Ptr{Float64}, diptr(diverge)::Ptr{Int32})::Cint)
+end
+
+"`P::CProblem` with DEVICE pointers (`cproblem(problem, N, B; A=dptr(dA), ...)`); `alpha` is a host vector"
+function forward_pass_dev!(xnew, unew, cnew, csum, P::CProblem, K, k, x0, u, x, alpha::Vector{Float64}, lims; active=nothing,
+                           handle::Handle=default_handle())
+    GC.@preserve alpha check(@ccall libddp.ddp_forward_pass_f64_dev(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, dptr(K)::Ptr{Float64},
+        dptr(k)::Ptr{Float64}, dptr(x0)::Ptr{Float64}, dptr(u)::Ptr{Float64}, dptr(x)::Ptr{Float64}, alpha::Ptr{Float64},
+        length(alpha)::Cint, dptr(lims)::Ptr{Float64}, diptr(active)::Ptr{Int32},
+        dptr(xnew)::Ptr{Float64}, dptr(unew)::Ptr{Float64}, dptr(cnew)::Ptr{Float64}, dptr(csum)::Ptr{Float64})::Cint)
+end
+
+function df_dev!(cx, cu, fx, fu, P::CProblem, x, u; active=nothing, handle::Handle=default_handle())
+    check(@ccall libddp.ddp_df_f64_dev(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, dptr(x)::Ptr{Float64}, dptr(u)::Ptr{Float64},
+        diptr(active)::Ptr{Int32}, dptr(cx)::Ptr{Float64}, dptr(cu)::Ptr{Float64}, dptr(fx)::Ptr{Float64}, dptr(fu)::Ptr{Float64})::Cint)
 end
 
 """
-    ∇kl(traj_prev) -> cx, cu, cxx, cxu, cuu          (klutils.jl:8-23; cxu is m×n×T like the reference)
+    iLQG_dev!(x,u,K,k,Quu,Vx,Vxx,cost,stats, P::CProblem, x0, u0, lims; prerolled=false, cost0=nothing, opts...) -> global_iters
+
+Whole batched solves on device buffers (what an MPC loop keeps calling with its shifted solution: `prerolled=true`); x0/u0 must
+not alias x/u.  `stats[8,B]` = status, iter, accepted_iter, n_backpass, n_forward, λ, g_norm, sum(cost) per trajectory.
 """
-function ∇kl(traj_prev::GaussianPolicy; handle=default_handle())
-    isempty(traj_prev) && return (0, 0, 0, 0, 0)
+function iLQG_dev!(x, u, K, k, Quu, Vx, Vxx, cost, stats, P::CProblem, x0, u0, lims; prerolled::Bool=false, cost0=nothing, trace7=nothing,
+                   trace_cap::Integer=0, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0, λfactor=1.6, λmax=1e10,
+                   λmin=1e-6, regType=1, reduce_ratio_min=0, handle::Handle=default_handle())
+    o = _opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
+    git = Ref{Cint}(0)
+    check(@ccall libddp.ddp_ilqg_ex_f64_dev(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGOpts}, dptr(x0)::Ptr{Float64},
+        (prerolled ? 1 : 0)::Cint, dptr(u0)::Ptr{Float64}, dptr(cost0)::Ptr{Float64}, dptr(lims)::Ptr{Float64},
+        dptr(x)::Ptr{Float64}, dptr(u)::Ptr{Float64}, dptr(K)::Ptr{Float64}, dptr(k)::Ptr{Float64}, dptr(Quu)::Ptr{Float64},
+        dptr(Vx)::Ptr{Float64}, dptr(Vxx)::Ptr{Float64}, dptr(cost)::Ptr{Float64}, dptr(stats)::Ptr{Float64}, trace_cap::Cint,
+        dptr(trace7)::Ptr{Float64}, git::Ptr{Cint})::Cint)
+    return Int(git[])
+end
+
+"`dst[:, i, b] = src[:, i+shift, b]` on device buffers `a[d, N, B]` (out of place)"
+function mpc_shift_dev!(dst, src, d::Integer, N::Integer, B::Integer, shift::Integer=1; zero_tail::Bool=false, handle::Handle=default_handle())
+    check(@ccall libddp.ddp_mpc_shift_f64_dev(handle.ptr::Ptr{Cvoid}, d::Cint, N::Cint, B::Cint, shift::Cint, (zero_tail ? 1 : 0)::Cint,
+        dptr(src)::Ptr{Float64}, dptr(dst)::Ptr{Float64})::Cint)
+end
+
+# ======================================================================================= KL-constrained path
+"""
+    ∇kl(traj_prev) -> cx, cu, cxx, cxu, cuu          (klutils.jl:8-23; cxu is m×n×T like the reference; batch axis allowed)
+"""
+function ∇kl(traj_prev; handle::Handle=default_handle())
+    _isempty_policy(traj_prev) && return (0, 0, 0, 0, 0)
     m, n, T = traj_prev.m, traj_prev.n, traj_prev.T
-    cx, cu, cxx, cxu, cuu = zeros(n, T), zeros(m, T), zeros(n, n, T), zeros(m, n, T), zeros(m, m, T)
-    K, k, Σi = traj_prev.K, traj_prev.k, traj_prev.Σi
+    K, k, Σi = _f64(traj_prev.K), _f64(traj_prev.k), _f64(traj_prev.Σi)
+    B = ndims(k) == 3 ? size(k, 3) : 1
+    bt = ndims(k) == 3 ? (B,) : ()
+    cx, cu, cxx, cxu, cuu = zeros(n, T, bt...), zeros(m, T, bt...), zeros(n, n, T, bt...), zeros(m, n, T, bt...), zeros(m, m, T, bt...)
     GC.@preserve K k Σi cx cu cxx cxu cuu begin
-        check(@ccall libddp.ddp_kl_terms_f64(handle.ptr::Ptr{Cvoid}, n::Cint, m::Cint, T::Cint, 1::Cint, K::Ptr{Float64},
+        check(@ccall libddp.ddp_kl_terms_f64(handle.ptr::Ptr{Cvoid}, n::Cint, m::Cint, T::Cint, B::Cint, K::Ptr{Float64},
             k::Ptr{Float64}, Σi::Ptr{Float64}, cx::Ptr{Float64}, cu::Ptr{Float64}, cxx::Ptr{Float64}, cxu::Ptr{Float64},
             cuu::Ptr{Float64})::Cint)
     end
@@ -224,37 +523,37 @@ end
 """
     back_pass_gps(cx,cu,cxx,cxu,cuu,fx,fu,lims,x,u,kl_cost_terms) -> diverge, GaussianPolicy(N,n,m,K,k,Quui,Quu), Vx, Vxx, dV
 
-Same signature and return values as backward_pass.jl:259; `kl_cost_terms = (∇kl(traj_prev), ηbracket)` with `ηbracket`
-a 3-vector or a 3×N matrix.
+Same signature and return values as backward_pass.jl:259; `kl_cost_terms = (∇kl(traj_prev), ηbracket)` with `ηbracket` a 3-vector
+or a 3×N matrix.  One trajectory (the batched form is driven through the C ABI by the host mirror's iLQGkl).
 """
-function back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, kl_cost_terms; handle=default_handle())
+function back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, kl_cost_terms; handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
     n, N = size(cx); m = size(cu, 1)
     cx, cu, cxx, cxu, cuu, fx, fu, u = map(_f64, (cx, cu, cxx, cxu, cuu, fx, fu, u))
     cxkl, cukl, cxxkl, cxukl, cuukl = map(_f64, kl_cost_terms[1])
     ηb = kl_cost_terms[2]
     η = isa(ηb, AbstractMatrix) ? _f64(ηb[2, :]) : [Float64(ηb[2])]
-    has_lims = !isempty(lims)
-    limsp = has_lims ? _f64(lims) : Float64[]
+    limsp = _lims(lims)
+    has_lims = !isempty(limsp)
     d = BPDesc(n, m, N, 1, 1, 0, 1, 0, 1, has_lims)
     K = zeros(m, n, N); k = zeros(m, N); Quu = zeros(m, m, N); Quui = zeros(m, m, N); Vx = zeros(n, N); Vxx = zeros(n, n, N)
-    dV = zeros(2); diverge = Ref{Int32}(0)
-    GC.@preserve cx cu cxx cxu cuu fx fu u cxkl cukl cxxkl cxukl cuukl η limsp K k Quu Quui Vx Vxx dV begin
+    dV = zeros(2); diverge = zeros(Int32, 1)
+    GC.@preserve cx cu cxx cxu cuu fx fu u cxkl cukl cxxkl cxukl cuukl η limsp K k Quu Quui Vx Vxx dV diverge begin
         t = KLCostTerms(pointer(cxkl), pointer(cukl), pointer(cxxkl), pointer(cxukl), pointer(cuukl), pointer(η), isa(ηb, AbstractMatrix))
         check(@ccall libddp.ddp_back_pass_gps_f64(handle.ptr::Ptr{Cvoid}, Ref(d)::Ptr{BPDesc}, cx::Ptr{Float64}, cu::Ptr{Float64},
             cxx::Ptr{Float64}, cxu::Ptr{Float64}, cuu::Ptr{Float64}, fx::Ptr{Float64}, fu::Ptr{Float64}, Ref(t)::Ptr{KLCostTerms},
-            (has_lims ? pointer(limsp) : Ptr{Float64}(C_NULL))::Ptr{Float64}, (has_lims ? pointer(u) : Ptr{Float64}(C_NULL))::Ptr{Float64},
+            _ptr_or_null(limsp)::Ptr{Float64}, (has_lims ? pointer(u) : NULLF)::Ptr{Float64},
             K::Ptr{Float64}, k::Ptr{Float64}, Quu::Ptr{Float64}, Quui::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64},
             dV::Ptr{Float64}, diverge::Ptr{Int32})::Cint)
     end
-    return Int(diverge[]), GaussianPolicy(N, n, m, K, k, Quui, Quu), Vx, Vxx, dV
+    return Int(diverge[1]), policy(N, n, m, K, k, Quui, Quu), Vx, Vxx, dV
 end
 
 """
     forward_covariance(fx, R1, traj) -> sigmanew       (forward_pass.jl:37-56 with `df(model,·)[1]`, `covariance(model,·)` passed in)
 """
-function forward_covariance(fx::Array{Float64,3}, R1::Matrix{Float64}, traj::GaussianPolicy; handle=default_handle())
+function forward_covariance(fx::Array{Float64,3}, R1::Matrix{Float64}, traj; handle::Handle=default_handle())
     n, m, N = traj.n, traj.m, traj.T
-    S = zeros(n + m, n + m, N); K, Σ = traj.K, traj.Σ
+    S = zeros(n + m, n + m, N); K, Σ = _f64(traj.K), _f64(traj.Σ)
     GC.@preserve fx R1 K Σ S begin
         check(@ccall libddp.ddp_forward_covariance_f64(handle.ptr::Ptr{Cvoid}, n::Cint, m::Cint, N::Cint, 1::Cint, fx::Ptr{Float64},
             0::Cint, R1::Ptr{Float64}, K::Ptr{Float64}, Σ::Ptr{Float64}, S::Ptr{Float64})::Cint)
@@ -265,11 +564,11 @@ end
 """
     kl_div_wiki(xnew, xold, Σ_new, traj_new, traj_prev) -> kldiv (or Inf)      (klutils.jl:70-103)
 """
-function kl_div_wiki(xnew, xold, Σ_new, traj_new::GaussianPolicy, traj_prev::GaussianPolicy; handle=default_handle())
+function kl_div_wiki(xnew, xold, Σ_new, traj_new, traj_prev; handle::Handle=default_handle())
     n, m, T = traj_new.n, traj_new.m, traj_new.T
     kld = zeros(T); mean_ = zeros(1)
     xnew, xold, Σ_new = map(_f64, (xnew, xold, Σ_new))
-    Kn, kn, Σn, Kp, kp, Σp, Σip = traj_new.K, traj_new.k, traj_new.Σ, traj_prev.K, traj_prev.k, traj_prev.Σ, traj_prev.Σi
+    Kn, kn, Σn, Kp, kp, Σp, Σip = map(_f64, (traj_new.K, traj_new.k, traj_new.Σ, traj_prev.K, traj_prev.k, traj_prev.Σ, traj_prev.Σi))
     GC.@preserve xnew xold Σ_new Kn kn Σn Kp kp Σp Σip kld mean_ begin
         check(@ccall libddp.ddp_kl_div_f64(handle.ptr::Ptr{Cvoid}, n::Cint, m::Cint, T::Cint, 1::Cint, xnew::Ptr{Float64},
             xold::Ptr{Float64}, Σ_new::Ptr{Float64}, Kn::Ptr{Float64}, kn::Ptr{Float64}, Σn::Ptr{Float64}, Kp::Ptr{Float64},

@@ -188,7 +188,8 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
     if x.shape[1] != u.shape[1]:
         raise ValueError("pre-rolled initial trajectory must be of correct length (size(x0,2) == N)")            # :72
     prev0 = GaussianPolicy(N, n, m, _b(traj_prev.K, 3), np.zeros_like(u), _b(traj_prev.Σ, 3), _b(traj_prev.Σi, 3))   # k *= 0 (:51)
-    etab = np.repeat(np.asarray(ηbracket, dtype=np.float64)[:, None], B, 1)                                      # copy (:52)
+    etab = np.asarray(ηbracket, dtype=np.float64)
+    etab = etab.copy() if etab.shape == (3, B) else np.repeat(etab.reshape(3)[:, None], B, 1)                    # copy (:52); [3,B]: one bracket per trajectory
     del0 = np.full(B, float(del0))
     # STEP 1 (:86): the KL demos hand 3-D arrays to back_pass_gps (demo_linear.jl:91-101)
     fx, fu, _, _, _, cx, cu, cxx, cxu, cuu = df(problem, x, u, handle=h)
@@ -326,7 +327,10 @@ def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u,
         desc = _lib.BPDesc(n, m, N, B, 1, int(fx.ndim == 4), 1, int(cxx.ndim == 4), 1, int(Lh is not None))
         terms = _lib.KLCostTerms(*d_kl, d_eta, 0)
         one = np.array([1.0])
-        eta_h = np.zeros(B)
+        # η each trajectory was last computed with.  calc_η moves ηbracket[2, b] BEFORE the `η > 0.999 ηmax` exit test (iLQGkl.jl:141,174):
+        # a trajectory that leaves that way must keep the results of the η it was computed with (the reference breaks right there), so
+        # only live trajectories take a new η; the finished ones are recomputed to the same result by every later pass.
+        eta_h = etab[1].copy()
         for it in range(1, max_iter + 1):                                                                       # :91
             idx = np.flatnonzero(live)
             if idx.size == 0:
@@ -335,7 +339,7 @@ def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u,
             pend = live.copy()
             guard = 0
             while True:                                        # back passes until the regularised Quu is positive definite (:95-122)
-                eta_h[:] = etab[1]
+                eta_h[pend] = etab[1, pend]
                 _lib.check(L_.ddp_memcpy_h2d(h.raw, d_eta, _lib.ptr(eta_h), _C.c_size_t(eta_h.nbytes)))
                 _lib.check(L_.ddp_back_pass_gps_f64_dev(h.raw, _C.byref(desc), d_cx, d_cu, d_cxx, d_cxu, d_cuu, d_fx, d_fu, _C.byref(terms),
                                                         d_L, d_u, None, d_K, d_k, d_Quu, d_Quui, d_Vx, d_Vxx, d_dV, d_div))

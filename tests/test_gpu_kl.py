@@ -136,6 +136,38 @@ def _ilqgkl_batch_independent_eta(ddp):
     assert len(set(tr["η"][1])) > 1                                       # the brackets really are per trajectory
 
 
+def test_ilqgkl_bracket_exit_freezes_trajectory(ddp, monkeypatch):
+    """a trajectory that leaves through `η > 0.999 ηmax` (iLQGkl.jl:174) while others stay live keeps the results of
+    the η it was computed with — calc_η has already moved its bracket when the exit test fires.  Device loop == host-array loop."""
+    import scipy.linalg as sla
+    kl = ddp.kl
+    rng = np.random.default_rng(5)
+    n, m, T, B, h = 6, 2, 40, 5, 0.01
+    A0 = rng.standard_normal((n, n)); A = sla.expm(h * (A0 - A0.T)); Bm = h * rng.standard_normal((n, m))
+    Q, R = h * np.eye(n), 0.1 * h * np.eye(m)
+    u = 0.1 * rng.standard_normal((m, T, B)) * np.array([1.0, 2.0, 0.5, 3.0, 1.5])
+    x = np.zeros((n, T, B)); x[:, 0, :] = 1.0 + 0.1 * rng.standard_normal((n, B))
+    for t in range(T - 1):
+        x[:, t + 1, :] = A @ x[:, t, :] + Bm @ u[:, t, :]
+    cost0 = 0.5 * np.einsum("itb,ij,jtb->b", x, Q, x) + 0.5 * np.einsum("itb,ij,jtb->b", u, R, u)
+    eye = np.repeat(np.repeat(np.eye(m)[:, :, None, None], T, 2), B, 3)
+    fx, fu, R1 = np.repeat(A[:, :, None], T, 2), np.repeat(Bm[:, :, None], T, 2), 1e-4 * np.eye(n)
+    etab = np.repeat(np.array([1e-8, 1.0, 1e16])[:, None], B, 1)
+    etab[:, 1] = [1e-8, 0.85, 0.9]; etab[:, 3] = [1e-8, 0.79, 0.8]         # upper ends below the η that meets the constraint (~0.97): these two
+                                                                            # climb to 0.999 ηmax and leave through the bracket test after a few passes
+    outs = {}
+    for hostloop in ("0", "1"):
+        monkeypatch.setenv("DDP_KL_HOSTLOOP", hostloop)
+        prev = ddp.GaussianPolicy(T, n, m, np.zeros((m, n, T, B)), u.copy(), eye.copy(), eye.copy())
+        outs[hostloop] = kl.iLQGkl(ddp.LQProblem(A, Bm, Q, R), x, prev, kl.Model(fx, fu, R1), kl_step=2e-4, max_iter=40, cost=cost0, ηbracket=etab)
+    (xo, uo, pol, Vx, Vxx, cost, tr), (xh, uh, polh, Vxh, Vxxh, costh, trh) = outs["0"], outs["1"]
+    assert set(tr["status"]) >= {1, 2} and np.array_equal(tr["status"], trh["status"]) and np.array_equal(tr["iter"], trh["iter"])
+    first_exit = tr["iter"][tr["status"] == 2].min()
+    assert (tr["iter"][tr["status"] == 1] > first_exit).any()              # others were still live after the first bracket exit
+    for got, ref in ((xo, xh), (uo, uh), (pol.K, polh.K), (pol.Σ, polh.Σ), (pol.Σi, polh.Σi), (Vx, Vxh), (Vxx, Vxxh), (cost, costh), (tr["η"], trh["η"])):
+        assert relerr(got, ref) < 1e-12
+
+
 def test_ilqgkl_pendcart_c5_shape(ddp):
     """BASELINE config 5 = config 3 (pendcart, n=4, m=1, control limits) + the KL constraint; reduced N and B"""
     from oracle import oracle_ctypes as oc
