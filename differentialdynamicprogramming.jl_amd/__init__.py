@@ -351,7 +351,8 @@ def print_timing(trace):
 
 
 STATUS = {1: "SUCCESS: gradient norm < tol_grad", 2: "SUCCESS: cost change < tol_fun", 3: "EXIT: λ > λmax",
-          4: "EXIT: Maximum iterations reached", -1: "EXIT: Initial control sequence caused divergence"}
+          4: "EXIT: Maximum iterations reached", -1: "EXIT: Initial control sequence caused divergence",
+          5: "EXIT: the driver's bound on batch iterations ran out (not a state of the reference)"}
 
 
 def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0,
@@ -399,7 +400,9 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     K = np.zeros((m, n, N, B), order="F"); k = np.zeros((m, N, B), order="F"); Quu = np.zeros((m, m, N, B), order="F")
     Vx = np.zeros((n, N, B), order="F"); Vxx = np.zeros((n, n, N, B), order="F")
     stats = np.zeros((8, B), order="F")
-    cap = trace_cap if trace_cap is not None else 4 * max_iter + 64
+    # rows of the per-iteration trace kept per trajectory; by default bounded so that trace7[7, cap, B] stays under 256 MB
+    # (a batch of 4096 pendcart solves with cap = 4 max_iter + 64 moved 0.93 GB of mostly zeros)
+    cap = trace_cap if trace_cap is not None else min(4 * max_iter + 64, 4096, max(64, int(256e6 / (56 * B))))
     cap = min(cap, 4096)
     git = _C.c_int(0)
     c0 = None if (not prerolled or cost is None or np.size(cost) == 0) else _lib.f64(np.reshape(cost, (CL, B), order="F"))

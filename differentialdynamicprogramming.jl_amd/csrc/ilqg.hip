@@ -12,6 +12,7 @@
 // The host only launches kernels and polls one counter (number of running trajectories) per global
 // iteration.  The λ-schedule quirks of the reference are kept: the increase uses the OLD dλ
 // (tuple assignment, :246,:313), the decrease the NEW one (:299-300), λ never drops below λmin.
+#include <stdlib.h>
 #include <vector>
 #include "ddp_internal.h"
 
@@ -180,9 +181,11 @@ __global__ __launch_bounds__(64) void post_bp_kernel(int m, int N, Opt o, const 
 __global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, int CL, Opt o, const double *dV,
                                                     const double *xnew, const double *unew, const double *cnew,
                                                     const double *csumnew, Traj s, double *x, double *u, double *cost,
-                                                    double *k, int trace_cap, double *trace_cost, double *trace7, int *counter)
+                                                    double *k, int trace_cap, double *trace_cost, double *trace7, const int32_t *map,
+                                                    int *counter)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
+    const int tb = map ? map[b] : b;                                   // row of the caller's trace arrays (slot -> trajectory)
     if (!s.run[b]) return;
     if (!s.dofwd[b]) {            // diverged back_pass, retrying: nothing to do this round
         if (lane == 0) atomicAdd(counter, 1);
@@ -228,9 +231,9 @@ __global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, 
     if (sel >= 0) { s.csum[b] = csumnew[(size_t)b + (size_t)B * sel]; s.flg[b] = 1; }
     if (status == DDP_EXIT_RUNNING) {
         const int it = s.iter[b];
-        if (trace_cost && it - 1 < trace_cap) trace_cost[(size_t)trace_cap * b + (it - 1)] = s.csum[b];   // :329
+        if (trace_cost && it - 1 < trace_cap) trace_cost[(size_t)trace_cap * tb + (it - 1)] = s.csum[b];   // :329
         if (trace7 && it - 1 < trace_cap) {                            // :257,325-330: λ, dλ, α, improvement, cost, reduce_ratio, grad_norm
-            double *t7 = trace7 + 7 * ((size_t)trace_cap * b + (it - 1));
+            double *t7 = trace7 + 7 * ((size_t)trace_cap * tb + (it - 1));
             t7[0] = lam; t7[1] = dlam; t7[2] = sel >= 0 ? o.alpha[sel] : NAN; t7[3] = dcost; t7[4] = s.csum[b]; t7[5] = zlast;
             t7[6] = s.gnorm[b];
         }
@@ -242,11 +245,85 @@ __global__ __launch_bounds__(64) void accept_kernel(int n, int m, int N, int B, 
     s.dofwd[b] = 0;
 }
 
-__global__ void stats_kernel(int B, Traj s, double *stats)
+// only_finished: the slots that stopped running (their working set is about to be dropped); cap: still running when the driver gave up
+// After the first g step sizes of a line search have been rolled out: does the serial search of the reference (iLQG.jl:267-281)
+// stop inside them?  more[b] = 1 for the trajectories that still need the later step sizes.
+__global__ void ls_more_kernel(int B, int g, Opt o, const double *dV, const double *csumnew, Traj s, const int32_t *prev_more, int32_t *more)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double *r = stats + (size_t)DDP_ILQG_NSTATS * b;
+    int need = 0;
+    if (s.run[b] && s.dofwd[b] && (!prev_more || prev_more[b])) {
+        const double c0 = s.csum[b], dV0 = dV[2 * b], dV1 = dV[2 * b + 1];
+        need = 1;
+        for (int ai = 0; ai < g; ++ai) {
+            const double a = o.alpha[ai], dcost = c0 - csumnew[(size_t)b + (size_t)B * ai], expected = -a * (dV0 + a * dV1);
+            const double z = expected > 0 ? dcost / expected : ((dcost > 0) ? 1.0 : ((dcost < 0) ? -1.0 : dcost));
+            if (z > o.rrmin) { need = 0; break; }
+        }
+    }
+    more[b] = need;
+}
+
+// ---- compaction of the live trajectories (the batch advances in lock step: finished trajectories would keep their waves busy)
+// idx[0..count) = the running slots in order (one wave, ballot + prefix count)
+__global__ __launch_bounds__(64) void live_index_kernel(int B, Traj s, int32_t *idx, int *count)
+{
+    const int lane = threadIdx.x;
+    int base = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        const bool live = b < B && s.run[b] != 0;
+        const unsigned long long mask = __ballot(live);
+        if (live) idx[base + __popcll(mask & ((1ull << lane) - 1ull))] = b;
+        base += __popcll(mask);
+    }
+    if (lane == 0) *count = base;
+}
+
+struct WorkSet {            // where the state of the running trajectories lives: the caller's arrays, or a compacted copy
+    double *x, *u, *cost, *K, *k, *Quu, *Vx, *Vxx, *x0;
+    Traj s;
+    int32_t *map;           // slot -> trajectory of the caller's batch (NULL: identity)
+};
+
+// slot i of `dst` <- slot idx[i] of `src` (state only: x, u, cost, x0 and the scalar state machine; gains and value function are
+// recomputed by the next back pass, derivatives by the next df: dodf is set)
+__global__ __launch_bounds__(64) void gather_kernel(int n, int m, int N, int CL, const int32_t *idx, WorkSet src, WorkSet dst)
+{
+    const int i = blockIdx.x, lane = threadIdx.x, j = idx[i];
+    for (size_t e = lane; e < (size_t)n * N; e += 64) dst.x[(size_t)n * N * i + e] = src.x[(size_t)n * N * j + e];
+    for (size_t e = lane; e < (size_t)m * N; e += 64) dst.u[(size_t)m * N * i + e] = src.u[(size_t)m * N * j + e];
+    for (int e = lane; e < CL; e += 64) dst.cost[(size_t)CL * i + e] = src.cost[(size_t)CL * j + e];
+    for (int e = lane; e < n; e += 64) dst.x0[(size_t)n * i + e] = src.x0[(size_t)n * j + e];
+    if (lane == 0) {
+        dst.s.lam[i] = src.s.lam[j]; dst.s.dlam[i] = src.s.dlam[j]; dst.s.gnorm[i] = src.s.gnorm[j]; dst.s.csum[i] = src.s.csum[j];
+        dst.s.status[i] = src.s.status[j]; dst.s.iter[i] = src.s.iter[j]; dst.s.acc[i] = src.s.acc[j]; dst.s.nbp[i] = src.s.nbp[j];
+        dst.s.nfp[i] = src.s.nfp[j]; dst.s.flg[i] = src.s.flg[j]; dst.s.run[i] = src.s.run[j]; dst.s.dodf[i] = 1; dst.s.dofwd[i] = 0;
+        dst.s.div0[i] = src.s.div0[j];
+        dst.map[i] = src.map ? src.map[j] : j;
+    }
+}
+
+// results of the slots of a compacted working set that have stopped (all == 0) / of every slot (all != 0) go to the caller's arrays
+__global__ __launch_bounds__(64) void scatter_kernel(int n, int m, int N, int CL, int all, WorkSet src, WorkSet dst)
+{
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (!all && src.s.run[j]) return;
+    const size_t t = (size_t)src.map[j];
+    auto cp = [&](double *d, const double *s_, size_t per) { for (size_t e = lane; e < per; e += 64) d[per * t + e] = s_[per * j + e]; };
+    cp(dst.x, src.x, (size_t)n * N); cp(dst.u, src.u, (size_t)m * N); cp(dst.cost, src.cost, (size_t)CL);
+    cp(dst.K, src.K, (size_t)m * n * N); cp(dst.k, src.k, (size_t)m * N); cp(dst.Quu, src.Quu, (size_t)m * m * N);
+    cp(dst.Vx, src.Vx, (size_t)n * N); cp(dst.Vxx, src.Vxx, (size_t)n * n * N);
+}
+
+__global__ void stats_kernel(int B, Traj s, const int32_t *map, int only_finished, double *stats)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (only_finished && s.run[b]) return;
+    if (!only_finished && s.run[b]) s.status[b] = DDP_EXIT_CAP;
+    double *r = stats + (size_t)DDP_ILQG_NSTATS * (map ? map[b] : b);
     r[0] = s.status[b]; r[1] = s.iter[b]; r[2] = s.acc[b]; r[3] = s.nbp[b]; r[4] = s.nfp[b];
     r[5] = s.lam[b]; r[6] = s.gnorm[b]; r[7] = s.csum[b];
 }
@@ -273,6 +350,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     ddp_ilqg_opts od;
     if (!oo) { ddp_ilqg_default_opts(&od); oo = &od; }
     DDP_CHECK(oo->n_alpha >= 1 && oo->n_alpha <= 16, "ilqg: n_alpha=%d out of [1,16]", oo->n_alpha);
+    DDP_CHECK(x0 != x && u0 != u, "ilqg: x0/u0 must not alias the outputs x/u (the outputs are cleared before the initial rollout)");
     const size_t n = p->n, m = p->m, N = p->N, B = p->B, na = oo->n_alpha, CL = ddp_cost_len(p);
     const bool pend = p->kind == DDP_PROBLEM_PENDCART;
 
@@ -283,7 +361,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
                  s_fu = pend ? al(n * m * N * B * 8) : 0, s_xn = al(n * N * B * na * 8), s_un = al(m * N * B * na * 8),
                  s_cn = al(CL * B * na * 8), s_cs = al(B * na * 8), s_dV = al(2 * B * 8), s_div = al(B * 4),
                  s_cxu = al(n * m * 8), s_us = al(m * N * B * 8), s_d = al(B * 8), s_i = al(B * 4), s_x0 = al(n * B * 8);
-    bytes = s_cx + s_cu + s_fx + s_fu + s_xn + s_un + s_cn + s_cs + s_dV + s_div + s_cxu + s_us + 4 * s_d + 10 * s_i + 256 + s_x0;
+    bytes = s_cx + s_cu + s_fx + s_fu + s_xn + s_un + s_cn + s_cs + s_dV + s_div + s_cxu + s_us + 4 * s_d + 10 * s_i + 256 + s_x0 + 2 * s_i;
     void *base;
     int rc = ddp_scratch(h, bytes, &base);
     if (rc) return rc;
@@ -362,6 +440,36 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     d.cost_tv = 0; d.cost_batched = 0; d.regType = oo->regType; d.has_lims = lims != nullptr;
     const double *fx = pend ? fxw : p->A, *fu = pend ? fuw : p->Bm;
 
+    // ---- the working set: the caller's arrays until the first compaction
+    WorkSet user = {x, u, cost, K, k, Quu, Vx, Vxx, const_cast<double *>(x0), s, nullptr};
+    WorkSet ws = user;
+    ddp_problem pw = *p;                                   // the problem as the kernels see it (B = slots of the working set)
+    size_t Bw = B;
+    std::vector<void *> owned;                             // compacted working sets (freed on every way out)
+    struct Free { std::vector<void *> &v; ~Free() { for (void *q : v) hipFree(q); } } free_owned{owned};
+    // Two schedulers for THROUGHPUT-bound batches; both leave every per-trajectory result unchanged (tests/test_gpu_edge_cases.py).
+    // Up to about two waves per SIMD a pass takes the same time however many trajectories are live (each wave walks its N steps at
+    // the latency of one step), so neither helps there — measured on C3 at B = 4096: compaction 0.117 -> 0.117 s of back passes, the
+    // grouped line search 0.083 -> 0.19 s because its groups run one after the other.  They are switched on by the size of the
+    // working set, or forced / forbidden through the environment (tests, A/B timing).
+    //  * compaction: the batch advances in lock step, so a finished trajectory keeps the wave it shares with live ones busy
+    //    (C3: mean 59 iterations per solve, 264 for the slowest).  Once half of the slots have stopped the live ones move to a
+    //    smaller working set.  Not for per-trajectory dynamics (their operands would have to move as well).
+    //    DDP_ILQG_COMPACT=0: never;  =k (k > 1): whenever a working set of >= k slots is half empty.
+    //  * line search in groups: the reference stops at the first accepted step size (iLQG.jl:267-281); groups [0,1) [1,3) [3,n_alpha)
+    //    roll the later step sizes out only for the trajectories whose search is still open.  DDP_ILQG_LSGROUPS=0 / 1: never / always.
+    const char *cenv = getenv("DDP_ILQG_COMPACT");
+    const bool may_compact = !(cenv && cenv[0] == '0') && !(p->kind == DDP_PROBLEM_LQ && p->dyn_batched);
+    // trajectories per wave of the backward kernel the dispatcher picks (back_pass.hip) -> slots that make two waves per SIMD
+    const double tpw = (n == 4 && m == 1) ? 4.0 : (n == 10 && m == 2) ? (B < 5120 ? 1.0 : 4.0) : (n > DDP_MAX_N_GENERIC ? 0.25 : 1.0);
+    const size_t min_slots = (cenv && atoi(cenv) > 1) ? (size_t)atoi(cenv) : (size_t)(2048.0 * tpw);
+    const char *genv = getenv("DDP_ILQG_LSGROUPS");
+    const double rpw = pend ? 64.0 : (n <= 16 ? 4.0 : 1.0);                       // rollouts per wave of the forward kernels
+    (void)rpw;
+    const bool groups = na > 1 && genv && genv[0] == '1';                                  // measured: no gain even at B = 32768 (0.93 vs 0.88 s of rollouts) -> off unless forced
+    int32_t *more = (int32_t *)take(0);                    // two masks of B int32 were reserved behind x0c (see `bytes`)
+    int32_t *more2 = more + B;
+
     int git = 0;
     const long hard_cap = 4L * oo->max_iter + 1000;      // every global iteration advances iter or λ of each running trajectory
     // ddp_ilqg_set_timing: the time_derivs / time_backward / time_forward keys of the reference's trace (iLQG.jl:227,241,281)
@@ -371,21 +479,68 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
         for (int e = 0; e < 4; ++e) DDP_HIP(hipEventCreate(&h->tev[e]));
         h->tev_ok = true;
     }
+    auto launch_stats = [&](int only_finished) {
+        hipLaunchKernelGGL(stats_kernel, dim3((unsigned)((Bw + 255) / 256)), dim3(256), 0, st, (int)Bw, ws.s, ws.map, only_finished, stats);
+    };
     while (running > 0 && git < hard_cap) {
+        if (may_compact && (size_t)running * 2 <= Bw && Bw >= min_slots) {
+            // ---- drop the finished slots: their summary and (from a compacted set) their results go to the caller's arrays first
+            launch_stats(1);
+            if (ws.map) hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, 0, ws, user);
+            const size_t R = (size_t)running;
+            const size_t w_d = al(n * N * R * 8) + al(m * N * R * 8) + al(CL * R * 8) + al(m * n * N * R * 8) + al(m * N * R * 8) +
+                               al(m * m * N * R * 8) + al(n * N * R * 8) + al(n * n * N * R * 8) + al(n * R * 8) + 4 * al(R * 8) + 12 * al(R * 4) +
+                               al(Bw * 4) + 256;
+            void *blk = nullptr;
+            DDP_HIP(hipMalloc(&blk, w_d));
+            owned.push_back(blk);
+            char *q = (char *)blk;
+            auto tk = [&](size_t b_) { void *r_ = q; q += al(b_); return r_; };
+            WorkSet nw;
+            nw.x = (double *)tk(n * N * R * 8); nw.u = (double *)tk(m * N * R * 8); nw.cost = (double *)tk(CL * R * 8);
+            nw.K = (double *)tk(m * n * N * R * 8); nw.k = (double *)tk(m * N * R * 8); nw.Quu = (double *)tk(m * m * N * R * 8);
+            nw.Vx = (double *)tk(n * N * R * 8); nw.Vxx = (double *)tk(n * n * N * R * 8); nw.x0 = (double *)tk(n * R * 8);
+            nw.s.lam = (double *)tk(R * 8); nw.s.dlam = (double *)tk(R * 8); nw.s.gnorm = (double *)tk(R * 8); nw.s.csum = (double *)tk(R * 8);
+            nw.s.status = (int32_t *)tk(R * 4); nw.s.iter = (int32_t *)tk(R * 4); nw.s.acc = (int32_t *)tk(R * 4); nw.s.nbp = (int32_t *)tk(R * 4);
+            nw.s.nfp = (int32_t *)tk(R * 4); nw.s.flg = (int32_t *)tk(R * 4); nw.s.run = (int32_t *)tk(R * 4); nw.s.dodf = (int32_t *)tk(R * 4);
+            nw.s.dofwd = (int32_t *)tk(R * 4); nw.s.div0 = (int32_t *)tk(R * 4);
+            nw.map = (int32_t *)tk(R * 4);
+            int32_t *idx = (int32_t *)tk(Bw * 4);
+            hipLaunchKernelGGL(live_index_kernel, dim3(1), dim3(64), 0, st, (int)Bw, ws.s, idx, counter);
+            hipLaunchKernelGGL(gather_kernel, dim3((unsigned)R), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, idx, ws, nw);
+            ws = nw;
+            Bw = R;
+            pw.B = (int)R; d.B = (int)R;
+        }
         if (timed) DDP_HIP(hipEventRecord(h->tev[0], st));
-        rc = ddp_df_f64_dev(h, p, x, u, s.dodf, cx, cu, fxw, fuw);                                  // STEP 1
+        rc = ddp_df_f64_dev(h, &pw, ws.x, ws.u, ws.s.dodf, cx, cu, fxw, fuw);                                  // STEP 1
         if (rc) return rc;
         if (timed) DDP_HIP(hipEventRecord(h->tev[1], st));
-        rc = ddp_launch_back_pass(h, &d, cx, cu, p->Q, cxu, p->R, fx, fu, s.lam, lims, u, s.run, K, k, Quu, Vx, Vxx, dV, div);   // STEP 2
+        rc = ddp_launch_back_pass(h, &d, cx, cu, p->Q, cxu, p->R, fx, fu, ws.s.lam, lims, ws.u, ws.s.run, ws.K, ws.k, ws.Quu, ws.Vx, ws.Vxx,
+                                  dV, div);                                                                  // STEP 2
         if (rc) return rc;
-        hipLaunchKernelGGL(post_bp_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)m, (int)N, o, div, k, u, s);
+        hipLaunchKernelGGL(post_bp_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)m, (int)N, o, div, ws.k, ws.u, ws.s);
         if (timed) DDP_HIP(hipEventRecord(h->tev[2], st));
-        rc = ddp_forward_pass_f64_dev(h, p, K, k, x0, u, x, o.alpha, (int)na, lims, s.dofwd, xn, un, cn, cs);   // STEP 3
-        if (rc) return rc;
+        // STEP 3: all step sizes at once, or in groups with the later ones masked by `more`
+        const size_t gb[4] = {0, groups ? 1 : na, groups ? (na < 3 ? na : 3) : na, na};
+        const int32_t *mask = ws.s.dofwd;
+        for (int gi = 0; gi < 3; ++gi) {
+            const size_t a0 = gb[gi], a1 = gb[gi + 1];
+            if (a1 <= a0) continue;
+            if (a0 > 0) {
+                int32_t *mk = (gi == 1) ? more : more2;
+                hipLaunchKernelGGL(ls_more_kernel, dim3((unsigned)((Bw + 255) / 256)), dim3(256), 0, st, (int)Bw, (int)a0, o, dV, cs, ws.s,
+                                   gi == 1 ? (const int32_t *)nullptr : (const int32_t *)more, mk);
+                mask = mk;
+            }
+            rc = ddp_forward_pass_f64_dev(h, &pw, ws.K, ws.k, ws.x0, ws.u, ws.x, o.alpha + a0, (int)(a1 - a0), lims, mask, xn + n * N * Bw * a0,
+                                          un + m * N * Bw * a0, cn + CL * Bw * a0, cs + Bw * a0);
+            if (rc) return rc;
+        }
         if (timed) DDP_HIP(hipEventRecord(h->tev[3], st));
         DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
-        hipLaunchKernelGGL(accept_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)B, (int)CL, o, dV, xn,
-                           un, cn, cs, s, x, u, cost, k, trace_cap, trace_cost, trace7, counter);    // STEP 4
+        hipLaunchKernelGGL(accept_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)Bw, (int)CL, o, dV, xn,
+                           un, cn, cs, ws.s, ws.x, ws.u, ws.cost, ws.k, trace_cap, trace_cost, trace7, ws.map, counter);    // STEP 4
         DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
         DDP_HIP(hipStreamSynchronize(st));
         running = h->h_pinned[0];
@@ -398,7 +553,8 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
         }
         ++git;
     }
-    hipLaunchKernelGGL(stats_kernel, dim3(gB), dim3(256), 0, st, (int)B, s, stats);
+    launch_stats(0);                                       // trajectories still running here: DDP_EXIT_CAP (the driver's own bound)
+    if (ws.map) hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, 1, ws, user);
     DDP_HIP(hipGetLastError());
     DDP_HIP(hipStreamSynchronize(st));
     if (global_iters) *global_iters = git;

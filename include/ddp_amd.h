@@ -180,6 +180,8 @@ enum {
     DDP_EXIT_COST          = 2,   /* SUCCESS: cost change < tol_fun      (iLQG.jl:306-309) */
     DDP_EXIT_LAMBDA        = 3,   /* EXIT: lambda > lambda_max           (iLQG.jl:319-322) */
     DDP_EXIT_MAXITER       = 4,   /* while condition exhausted           (iLQG.jl:222)     */
+    DDP_EXIT_CAP           = 5,   /* NOT a state of the reference: the driver's own bound on batch-level iterations
+                                     (4 max_iter + 1000) ran out while this trajectory was still running         */
     DDP_EXIT_INIT_DIVERGED = -1   /* initial control sequence diverged   (iLQG.jl:205-210) */
 };
 
@@ -190,7 +192,8 @@ enum {
  * outputs x[n,N,B] u[m,N,B] K[m,n,N,B] k[m,N,B] (quirk: after an accepted step L.k is the control
  * sequence, iLQG.jl:303) Quu[m,m,N,B] Vx[n,N,B] Vxx[n,n,N,B] cost[CL,B] stats[8,B];
  * trace_cost (may be NULL) [trace_cap,B]: sum(cost) after every iteration (trace(:cost,...)).
- * `global_iters` (may be NULL) receives the number of batch-level iterations executed.           */
+ * `global_iters` (may be NULL) receives the number of batch-level iterations executed.
+ * x0 / u0 must not alias x / u (the outputs are cleared before the initial rollout).                */
 int ddp_ilqg_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
                  const double *x0, const double *u0, const double *lims,
                  double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,

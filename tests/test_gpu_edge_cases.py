@@ -330,3 +330,39 @@ def test_pendcart_rollout_kernels(ddp, monkeypatch, lane, lims):
             assert relerr(xn[..., b, j], xr) < RTOL and relerr(un[..., b, j], ur) < RTOL and relerr(cn[..., b, j], cr) < RTOL
         xr, ur, cr = oc.forward_pass(p, None, x0[:, b], u[..., b], None, 1.0, L)
         assert relerr(x1.reshape(4, N, B)[..., b], xr) < RTOL and relerr(c1.reshape(-1, B)[:, b], cr) < RTOL
+
+
+@pytest.mark.parametrize("family", ["pendcart", "lq"])
+def test_ilqg_compaction_and_line_search_groups_change_nothing(ddp, monkeypatch, family):
+    """The driver drops finished trajectories from the working set (compaction) and rolls the line search out in groups of step
+    sizes; both are scheduling only: status, iteration counts, n_backpass / n_forward, trace and every array equal the plain
+    lock-step run (DDP_ILQG_COMPACT=0, DDP_ILQG_LSGROUPS=0).  DDP_ILQG_COMPACT=4 lets batches of 4+ slots compact."""
+    rng = np.random.default_rng(17)
+    if family == "pendcart":
+        B, T = 40, 90
+        prob = ddp.PendcartProblem()
+        x0 = np.tile(np.array([np.pi - 0.6, 0, 0, 0])[:, None], (1, B)); x0[0] += rng.uniform(-0.3, 0.3, B)
+        u0 = np.zeros((1, T, B))
+        kw = dict(lims=5.0 * np.array([[-1.0, 1.0]]), regType=2, α=10.0 ** np.linspace(0.2, -3, 6), λmax=1e15, tol_fun=1e-8, tol_grad=1e-8,
+                  max_iter=300)
+    else:
+        from oracle import np_restatement as npr
+        B, T = 30, 120
+        P = npr.make_lq_problem(rng, T=T)
+        prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+        x0 = np.ones((10, B)) + 0.1 * rng.standard_normal((10, B))
+        u0 = 0.1 * rng.standard_normal((2, T, B)) * (1 + 3 * np.arange(B))[None, None, :]
+        kw = dict(tol_fun=10.0 ** rng.uniform(-9, -3))                      # spread of iteration counts comes from u0
+    runs = {}
+    for tag, compact, groups in (("plain", "0", "0"), ("compact", "4", "0"), ("groups", "0", "1"), ("both", "4", "1")):     # forced on
+        monkeypatch.setenv("DDP_ILQG_COMPACT", compact); monkeypatch.setenv("DDP_ILQG_LSGROUPS", groups)
+        runs[tag] = ddp.iLQG(prob, x0, u0, **kw)
+    ref = runs["plain"]
+    its = ref[6]["stats"][1]
+    assert its.max() >= 2 * np.median(its) or family == "lq"               # stragglers: compaction really happens
+    for tag in ("compact", "groups", "both"):
+        r = runs[tag]
+        assert np.array_equal(r[6]["stats"][:5], ref[6]["stats"][:5]), tag  # status, iter, accepted_iter, n_backpass, n_forward
+        for a, b_ in zip(r[:2] + (r[2].K, r[2].k, r[2].Σi) + r[3:6], ref[:2] + (ref[2].K, ref[2].k, ref[2].Σi) + ref[3:6]):
+            assert np.array_equal(a, b_), tag
+        assert np.array_equal(np.nan_to_num(r[6]["history"]["cost"]), np.nan_to_num(ref[6]["history"]["cost"])), tag
