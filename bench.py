@@ -89,6 +89,7 @@ class PassBench:
         self.dxn, self.dun, self.dcn, self.dcsn = empty(n * N * B), du0, dc, dcs   # u0 / initial-cost buffers are reused
         self.desc = _lib.BPDesc(n, m, N, B, 0, 0, 0, 0, 1, 0)
         self.stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.comm = None                                      # set by main(): sharding.CApiComm when --collective capi
 
     def step(self, ev=None, dist=None):
         _lib, L, h, p = self._lib, self.L, self.h, self.p
@@ -106,7 +107,10 @@ class PassBench:
         if dist is not None:
             # the single collective of the path: batch-level line-search statistics (latency-bound, 32 B)
             _lib.check(L.ddp_batch_stats_f64_dev(h.raw, self.B, p(self.dcsn), p(self.ddV), p(self.ddiv), p(self.stats)))
-            dist.all_reduce(self.stats)
+            if self.comm is not None:
+                self.comm.allreduce(self.stats.data_ptr(), 4, 0)     # RCCL through the C ABI (ddp_allreduce_stats_f64_dev)
+            else:
+                dist.all_reduce(self.stats)
 
     def timed(self, steps, warmup, fence, dist=None):
         _lib, L, h = self._lib, self.L, self.h
@@ -162,6 +166,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU (BASELINE config 2: 1024)")
     ap.add_argument("--horizon", type=int, default=1000)
+    ap.add_argument("--collective", choices=["torch", "capi"], default="torch",
+                    help="who issues the per-step statistics all-reduce: torch.distributed (backend nccl = RCCL) or the C ABI's own RCCL "
+                         "communicator (ddp_allreduce_stats_f64_dev; torch.distributed then only ships the 128-byte id)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories for the CPU baseline (0 = auto ~10-20 s)")
     ap.add_argument("--fill-batch", type=int, default=32768, help="machine-filling batch reported next to the headline (0 = skip)")
@@ -198,6 +205,9 @@ def main():
 
     n, m, N, B = N_STATE, N_CTRL, args.horizon, args.batch
     pb = PassBench(torch, dev, h, L, rank, n, m, N, B)
+    if use_dist and args.collective == "capi":
+        from ddp_amd import sharding
+        pb.comm = sharding.CApiComm(h, rank, world)
     elapsed, bp_ms, fp_ms = pb.timed(args.steps, args.warmup, fence, dist if use_dist else None)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -238,7 +248,7 @@ def main():
                "config": {"workload": "BASELINE config 2: demo_linear LTI n=10 m=2 N=%d, batch=%d trajectories per GPU, no control "
                                       "limits, regType=1, lambda=1; one step = back_pass + forward_pass(alpha=1) over the batch" % (N, B),
                           "batch_per_gpu": B, "n": n, "m": m, "N": N, "sharding": "batch (independent trajectories), "
-                          "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1"},
+                          "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1 (issued by %s)" % ("the C ABI, ddp_allreduce_stats_f64_dev" if args.collective == "capi" else "torch.distributed")},
                "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill}
         print(json.dumps(out))
     if use_dist:

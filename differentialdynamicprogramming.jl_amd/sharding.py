@@ -48,11 +48,56 @@ def allreduce_stats(v, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return np.asarray(v, dtype=np.float64)
+    # ONE collective: gather the tiny vectors, reduce locally (SUM for the first N_SUM entries, MAX for the rest) — the same
+    # scheme as ddp_allreduce_stats_f64_dev of the C ABI (csrc/comm.hip)
     t = torch.as_tensor(np.asarray(v, dtype=np.float64), device=device)
-    s, mx = t[:N_SUM].clone(), t[N_SUM:].clone()
-    dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    return torch.cat([s, mx]).cpu().numpy()
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    g = torch.stack(parts)
+    return torch.cat([g[:, :N_SUM].sum(dim=0), g[:, N_SUM:].max(dim=0).values]).cpu().numpy()
+
+
+class CApiComm:
+    """The RCCL communicator owned by the C ABI (ddp_comm_create / ddp_allreduce_stats_f64_dev, include/ddp_amd.h) — what a Julia
+    or C host without torch uses for the one collective of the path.  `exchange(id_bytes_or_None) -> id_bytes` ships the
+    128-byte RCCL id from rank 0 to every rank; by default torch.distributed's object broadcast does it (rendezvous only)."""
+
+    def __init__(self, handle, rank, world, exchange=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self.handle, self.rank, self.world = _lib, handle, rank, world
+        idbuf = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(_lib.lib().ddp_comm_unique_id(idbuf))
+        if exchange is None:
+            def exchange(b):
+                import torch.distributed as dist
+                if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+                    return b
+                box = [b]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+        raw = exchange(bytes(idbuf.raw) if rank == 0 else None)
+        idbuf.raw = raw
+        self._c = C.c_void_p()
+        _lib.check(_lib.lib().ddp_comm_create(handle.raw, int(world), int(rank), idbuf, C.byref(self._c)))
+
+    def allreduce(self, dptr, nsum, nmax=0):
+        """in place on the device vector at `dptr` (ctypes pointer / int): SUM of the first nsum entries, MAX of the next nmax"""
+        import ctypes as C
+        self._lib.check(self._lib.lib().ddp_allreduce_stats_f64_dev(self.handle.raw, self._c, C.c_void_p(getattr(dptr, "value", dptr)),
+                                                                    int(nsum), int(nmax)))
+
+    def close(self):
+        if self._c:
+            self._lib.lib().ddp_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def solve_sharded(problem, x0, u0, *, solver=None, device=None, **kw):

@@ -234,6 +234,21 @@ int ddp_ilqg_ex_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts 
 /* batch-level statistics of one pass in one launch: out4 = [sum(csum[B]), sum(dV[1,:]), sum(dV[2,:]), #(diverge != 0)];
  * any input may be NULL.  This is the vector a multi-GPU job all-reduces (one small collective per pass).               */
 int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const double *dV, const int32_t *diverge, double *out4);
+/* ---- multi-GPU: the one collective of the path -------------------------------------------------------
+ * New (the reference is single-process).  One process per GPU, trajectories sharded over the ranks, no data-path exchange; a job
+ * shares one small statistics vector per pass / solve.  RCCL is loaded at first use (no link-time dependency).
+ *   rank 0: ddp_comm_unique_id(id); ship the 128 bytes to the other ranks by any means (file, MPI, torch.distributed broadcast)
+ *   every rank: ddp_comm_create(h, nranks, rank, id, &comm)                       (= ncclCommInitRank, collective)
+ *   ddp_allreduce_stats_f64_dev(h, comm, buf, nsum, nmax): device vector buf[nsum + nmax] (<= DDP_COMM_MAX_STATS) becomes, on every
+ *   rank, the SUM over ranks of its first nsum entries and the MAX over ranks of the remaining nmax — ONE RCCL call (all-gather of
+ *   the tiny vectors + a local reduction), asynchronous on the handle's stream.                                         */
+#define DDP_COMM_ID_BYTES 128
+#define DDP_COMM_MAX_STATS 64
+typedef struct ddp_comm_s *ddp_comm;
+int ddp_comm_unique_id(char id[DDP_COMM_ID_BYTES]);
+int ddp_comm_create(ddp_handle h, int nranks, int rank, const char id[DDP_COMM_ID_BYTES], ddp_comm *out);
+int ddp_comm_destroy(ddp_comm c);
+int ddp_allreduce_stats_f64_dev(ddp_handle h, ddp_comm c, double *buf, int nsum, int nmax);
 /* Receding-horizon warm start between two MPC solves (new, the reference has no MPC loop — its hook is
  * the pre-rolled `x0[n,N]` + `cost` of src/iLQG.jl:193-197, see ddp_ilqg_warm_f64): a time-major array a[d, N, B] moves
  * `shift` steps towards the present, dst[:, i, b] = src[:, i+shift, b]; the vacated tail repeats the last column

@@ -366,3 +366,22 @@ def test_ilqg_compaction_and_line_search_groups_change_nothing(ddp, monkeypatch,
         for a, b_ in zip(r[:2] + (r[2].K, r[2].k, r[2].Σi) + r[3:6], ref[:2] + (ref[2].K, ref[2].k, ref[2].Σi) + ref[3:6]):
             assert np.array_equal(a, b_), tag
         assert np.array_equal(np.nan_to_num(r[6]["history"]["cost"]), np.nan_to_num(ref[6]["history"]["cost"])), tag
+
+
+def test_capi_comm_single_rank(ddp):
+    """ddp_comm_* / ddp_allreduce_stats_f64_dev (RCCL owned by the C ABI) with a communicator of one rank: the vector comes back
+    unchanged (SUM and MAX over one rank), asynchronously on the handle's stream.  More ranks need more GPUs: the gloo test covers
+    the sharding logic, the driver's multi-GPU bench (`bench.py --collective capi`) the real thing."""
+    from ddp_amd import sharding
+    h = ddp.default_handle()
+    comm = sharding.CApiComm(h, 0, 1, exchange=lambda b: b)
+    v = np.array([3.5, -1.25, 7.0, 2.0, 9.0])
+    d = h.to_device(v)
+    try:
+        comm.allreduce(d, 3, 2)
+        comm.allreduce(d, 5, 0)
+        assert np.array_equal(h.to_host(d, (5,)), v)
+        with pytest.raises(ddp.DDPError):
+            comm.allreduce(d, 60, 10)                       # more than DDP_COMM_MAX_STATS entries
+    finally:
+        h.free(d); comm.close()
