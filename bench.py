@@ -75,6 +75,7 @@ class PassBench:
         prob.kind, prob.n, prob.m, prob.N, prob.B = 0, n, m, N, B
         prob.A, prob.Bm, prob.Q, prob.R = self.dA.data_ptr(), self.dB.data_ptr(), self.dQ.data_ptr(), self.dR.data_ptr()
         prob.dyn_tv, prob.dyn_batched = 0, 0
+        prob.cost_diag = 1                                    # Q = h·I, R = 0.1h·I (src/demo_linear.jl:17-18): cost inside the rollout kernel
         self.prob = prob
         self.one = np.array([1.0])
         # nominal trajectory + its derivatives (outside the timed region: STEP 1 of the iteration)

@@ -111,6 +111,8 @@ class _DevProblem:
             P.g, P.l, P.h, P.d = prob.g, prob.l, prob.h, prob.d
             for i in range(4):
                 P.goal[i] = float(prob.goal[i])
+        # Q and R diagonal (the reference's demos): the rollout kernels then evaluate the cost themselves (ddp_problem::cost_diag)
+        P.cost_diag = int(not np.any(self.Q - np.diag(np.diag(self.Q))) and not np.any(self.R - np.diag(np.diag(self.R))))
         self.struct = P
         self.cost_len = N + 1 if prob.kind == 1 else N
 

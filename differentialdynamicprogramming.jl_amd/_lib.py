@@ -49,7 +49,7 @@ class Problem(C.Structure):
     _fields_ = [("kind", C.c_int), ("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("B", C.c_int),
                 ("A", vp), ("Bm", vp), ("dyn_tv", C.c_int), ("dyn_batched", C.c_int), ("Q", vp), ("R", vp),
                 ("g", C.c_double), ("l", C.c_double), ("h", C.c_double), ("d", C.c_double),
-                ("goal", C.c_double * 4)]
+                ("goal", C.c_double * 4), ("cost_diag", C.c_int)]
 
 
 class ILQGOpts(C.Structure):

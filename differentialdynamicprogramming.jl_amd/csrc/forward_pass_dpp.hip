@@ -23,6 +23,10 @@ struct FDArgs {
     double alpha[16];
     double g, l, h, d;
     double *xnew, *unew;
+    // fused cost (ddp_problem::cost_diag): Q, R (their diagonals are used), goal, outputs
+    const double *Q, *R;
+    double goal[4];
+    double *cnew, *csum;
 };
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -67,10 +71,17 @@ struct RowSum {
     }
 };
 
-template <int KIND, int NS, int MS, bool POLICY, bool LIMS>
+// FUSE (ddp_problem::cost_diag, Q and R diagonal): the per-step cost is evaluated HERE from the values the lanes already hold —
+// lane j < n contributes ½Q[j,j]·(x̂_j - goal_j)², lane n+q contributes ½R[q,q]·u_q² — instead of by a second kernel that re-reads
+// xnew, unew from HBM (98 MB of the 431 MB a C2 pass moved).  The contributions of 16 steps wait in an LDS tile; then lane t of
+// the row sums step t, stores cnew[t] (one 128-byte line per row) and keeps its part of sum(cnew): off the dependency chain,
+// ~4 instructions per step.
+template <int KIND, int NS, int MS, bool POLICY, bool LIMS, bool FUSE>
 __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
 {
-    constexpr int n = NS, m = MS, G = 16, GPW = DDP_WAVE / G;
+    constexpr int n = NS, m = MS, G = 16, GPW = DDP_WAVE / G, TS = 17;             // TS: padded row of the cost tile (no bank conflicts)
+    constexpr bool pendk = KIND == DDP_PROBLEM_PENDCART;
+    __shared__ double ctile[FUSE ? GPW * 16 * TS : 1];
     static_assert(NS <= G && MS <= G, "state must fit one DPP row");
     const int N = a.N, B = a.B;
     const int lane = threadIdx.x, grp = lane / G, j = lane % G;
@@ -117,6 +128,29 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     asm volatile("" : "+v"(one));                               // keep 1.0 in a VGPR (DPP src1 must be a VGPR)
 
     double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0;           // x̂_j
+    // fused cost: weight and offset of this lane's stored value; per-lane part of sum(cnew)
+    double cw = 0.0, cg = 0.0, cacc = 0.0, xlast = 0.0;
+    double *co = nullptr;
+    const int CL = pendk ? N + 1 : N;
+    if (FUSE) {
+        if (inx) { cw = 0.5 * a.Q[jx + n * jx]; cg = pendk ? a.goal[jx & 3] : 0.0; }
+        else if (j < n + m) cw = 0.5 * a.R[(j - n) + m * (j - n)];
+        co = a.cnew + (size_t)CL * ((size_t)b + (size_t)B * ai);
+    }
+    double *ct = &ctile[FUSE ? grp * 16 * TS : 0];
+    double *ctw = ct + j;                                        // this lane's column of tile rows (i & 8) .. (i & 8) + 7, set per group of 8 steps
+    // cost of the steps [i0c, i0c + cnt) that wait in the tile: lane t sums step i0c + t
+    auto flush_cost = [&](int i0c, int cnt) {
+        wave_sync();
+        double c = 0.0;
+#pragma unroll
+        for (int l = 0; l < n + m; ++l) c += ct[j * TS + l];
+        if (j < cnt) {
+            if (act) co[i0c + j] = c;
+            cacc += c;
+        }
+        wave_sync();
+    };
 
     // one predicated store per step: lane j < n writes xnew[j,i], lanes n..n+m-1 write unew[j-n,i]
     const bool st_u = j >= n && j < n + m;
@@ -172,6 +206,12 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
 #pragma unroll
             for (int q = 0; q < m; ++q) v = (j == n + q) ? uu[q] : v;
             if (st_on) *(double *)((char *)st_base + (size_t)i * st_stride) = v;
+            if (FUSE) {
+                const double dv = pendk ? v - cg : v;
+                const double pc = (cw * dv) * dv;
+                ctw[(i & 7) * TS] = pc;                                  // row (i & 15) of the tile; idle lanes write 0 (cw = 0)
+                if (pendk && i == N - 1) xlast = inx ? pc : 0.0;         // the extra entry re-counts x[:,N] without a control
+            }
         }
         // ---- dynamics (f is also called at i == N in the reference, its result is discarded)
         if (advance) {
@@ -205,14 +245,18 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch(d < N ? d : N - 1, ring[d]);
     int i0 = 0;
+    static_assert(D == 8, "the cost tile is addressed in groups of 8 steps");
     for (; i0 + 2 * D <= N; i0 += D) {
+        if (FUSE) ctw = ct + j + (i0 & 8) * TS;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             step(i0 + d, ring[d], true);
             fetch(i0 + d + D, ring[d]);
         }
+        if (FUSE && (i0 & 8)) flush_cost(i0 - 8, 16);                    // steps i0-8 .. i0+7 are in the tile
     }
     for (; i0 < N; i0 += D) {
+        if (FUSE) ctw = ct + j + (i0 & 8) * TS;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int i = i0 + d;
@@ -221,6 +265,24 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
                 fetch(i + D < N ? i + D : N - 1, ring[d]);
             }
         }
+        if (FUSE && ((i0 & 8) || i0 + D >= N)) {
+            const int c0 = i0 & ~15;
+            flush_cost(c0, (N - c0) < 16 ? N - c0 : 16);
+        }
+    }
+    if (FUSE) {
+        if (pendk) {                                                     // c[N] = ½ (x_N - goal)'Q(x_N - goal)  (system_pendcart.jl:105)
+            double s0 = 0.0, s1 = 0.0;
+            dpp_fence(xlast);
+            RowSum<n>::run(s0, s1, xlast, one);
+            const double cN = s0 + s1;
+            if (act && j == 0) co[N] = cN;
+            cacc += (j == 0) ? cN : 0.0;
+        }
+        double s0 = 0.0, s1 = 0.0;
+        dpp_fence(cacc);
+        RowSum<16>::run(s0, s1, cacc, one);
+        if (act && j == 0) a.csum[(size_t)b + (size_t)B * ai] = s0 + s1;
     }
 }
 
@@ -229,7 +291,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
 // sincos (and only 5 of them carry state): with the 6-11 step sizes of a line search there are enough rollouts to give every
 // lane its own — 16x fewer wave-instructions per rollout.  Same arithmetic (system_pendcart.jl:83-89, forward_pass.jl:17-24;
 // K·dx summed in index order).  Operands are prefetched DL steps ahead (a lane's loads are its own 32-byte pieces).
-template <bool POLICY, bool LIMS>
+template <bool POLICY, bool LIMS, bool FUSE>
 __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs a)
 {
     constexpr int n = 4, DL = 4;
@@ -259,6 +321,13 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
         }
     };
     double x0v = a.x0[(size_t)n * b], x1v = a.x0[(size_t)n * b + 1], x2v = a.x0[(size_t)n * b + 2], x3v = a.x0[(size_t)n * b + 3];
+    // fused cost (cost_diag): c_i = ½((x_i-goal)'Q(x_i-goal) + R u_i²), c_{N+1} = ½(x_N-goal)'Q(x_N-goal)  (system_pendcart.jl:97-106)
+    double q0 = 0, q1 = 0, q2 = 0, q3 = 0, rr = 0, cacc = 0.0, qxl = 0.0;
+    double *co = nullptr;
+    if (FUSE) {
+        q0 = a.Q[0]; q1 = a.Q[5]; q2 = a.Q[10]; q3 = a.Q[15]; rr = a.R[0];
+        co = a.cnew + (size_t)(N + 1) * rho;
+    }
     auto step = [&](int i, const Ops &o, bool advance) {
         double uu = o.u;
         if (POLICY) {
@@ -275,6 +344,14 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
             *(d2 *)(xo + (size_t)n * i) = d2{x0v, x1v};
             *(d2 *)(xo + (size_t)n * i + 2) = d2{x2v, x3v};
             uo[i] = uu;
+        }
+        if (FUSE) {
+            const double d0 = x0v - a.goal[0], d1 = x1v - a.goal[1], d2 = x2v - a.goal[2], d3 = x3v - a.goal[3];
+            const double qx = ((q0 * d0) * d0 + (q1 * d1) * d1) + ((q2 * d2) * d2 + (q3 * d3) * d3);
+            const double c = 0.5 * (qx + (rr * uu) * uu);
+            if (act) co[i] = c;
+            cacc += c;
+            qxl = qx;
         }
         if (advance) {                                                   // system_pendcart.jl:83-89
             double sn, cs;
@@ -304,6 +381,10 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
                 fetch(i + DL < N ? i + DL : N - 1, ring[d]);
             }
         }
+    }
+    if (FUSE && act) {
+        co[N] = 0.5 * qxl;
+        a.csum[rho] = cacc + 0.5 * qxl;
     }
 }
 
@@ -372,7 +453,7 @@ __global__ __launch_bounds__(DDP_WAVE) void cost_kernel(CostArgs a)
     if (lane == 0) a.csum[rho] = acc;
 }
 
-template <int KIND, int NS, int MS>
+template <int KIND, int NS, int MS, bool FUSE>
 int launch_dpp(ddp_handle h, const FDArgs &a)
 {
     const int key = (a.has_policy ? 2 : 0) | (a.has_lims ? 1 : 0);
@@ -380,10 +461,10 @@ int launch_dpp(ddp_handle h, const FDArgs &a)
     const int gpw = DDP_WAVE / 16;
     const dim3 grid((unsigned)((total + gpw - 1) / gpw)), block(DDP_WAVE);
     switch (key) {
-    case 0: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, false>), grid, block, 0, h->stream, a); break;
-    case 1: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, true>), grid, block, 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, false>), grid, block, 0, h->stream, a); break;
-    case 3: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, true>), grid, block, 0, h->stream, a); break;
+    case 0: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, false, FUSE>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, true, FUSE>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, false, FUSE>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, true, FUSE>), grid, block, 0, h->stream, a); break;
     }
     DDP_HIP(hipGetLastError());
     return 0;
@@ -405,6 +486,10 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
     a.xnew = xnew; a.unew = unew;
+    const char *fuse_env = getenv("DDP_FORWARD_FUSE");           // 0: keep the separate cost kernel (A/B timing, tests)
+    const bool fuse = p->cost_diag != 0 && !(fuse_env && fuse_env[0] == '0');     // Q, R declared diagonal: cost inside the rollout kernel
+    a.Q = p->Q; a.R = p->R; a.cnew = cnew; a.csum = csum;
+    for (int i = 0; i < 4; ++i) a.goal[i] = p->goal[i];
     int rc;
     const char *lane_env = getenv("DDP_FORWARD_LANE");          // 1 / 0 forces the lane-per-rollout pendcart kernel on / off
     const long total = (long)p->B * nalpha;
@@ -412,18 +497,26 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
     if (lane) {
         const dim3 grid((unsigned)((total + DDP_WAVE - 1) / DDP_WAVE)), block(DDP_WAVE);
         const int key = (a.has_policy ? 2 : 0) | (a.has_lims ? 1 : 0);
+#define DDP_LANE(P_, L_)                                                                                            \
+    do {                                                                                                              \
+        if (fuse) hipLaunchKernelGGL((forward_lane_pendcart_kernel<P_, L_, true>), grid, block, 0, h->stream, a);     \
+        else hipLaunchKernelGGL((forward_lane_pendcart_kernel<P_, L_, false>), grid, block, 0, h->stream, a);         \
+    } while (0)
         switch (key) {
-        case 0: hipLaunchKernelGGL((forward_lane_pendcart_kernel<false, false>), grid, block, 0, h->stream, a); break;
-        case 1: hipLaunchKernelGGL((forward_lane_pendcart_kernel<false, true>), grid, block, 0, h->stream, a); break;
-        case 2: hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, false>), grid, block, 0, h->stream, a); break;
-        case 3: hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, true>), grid, block, 0, h->stream, a); break;
+        case 0: DDP_LANE(false, false); break;
+        case 1: DDP_LANE(false, true); break;
+        case 2: DDP_LANE(true, false); break;
+        case 3: DDP_LANE(true, true); break;
         }
+#undef DDP_LANE
         DDP_HIP(hipGetLastError());
         rc = 0;
     } else {
-        rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1>(h, a);
+        if (fuse) rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2, true>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1, true>(h, a);
+        else rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2, false>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1, false>(h, a);
     }
     if (rc) return rc;
+    if (fuse) return 0;                                         // cnew, csum already written
     CostArgs c;
     c.kind = p->kind; c.n = p->n; c.m = p->m; c.N = p->N; c.B = p->B; c.nalpha = nalpha; c.Q = p->Q; c.R = p->R;
     c.active = active;

@@ -62,6 +62,7 @@ struct CProblem
     h::Cdouble
     d::Cdouble
     goal::NTuple{4,Cdouble}
+    cost_diag::Cint
 end
 
 struct ILQGOpts
@@ -162,9 +163,9 @@ dyn_tv(p::LQProblem) = (ndims(p.A) - (p.dyn_batched ? 1 : 0)) == 3
 
 # C view of a problem; `A`, `Bm`, `Q`, `R` are host or device pointers depending on the entry point it is passed to
 cproblem(p::LQProblem, N, B; A=pointer(p.A), Bm=pointer(p.B), Q=pointer(p.Q), R=pointer(p.R)) =
-    CProblem(0, size(p.A, 1), size(p.B, 2), N, B, A, Bm, dyn_tv(p), p.dyn_batched, Q, R, 0.0, 0.0, 0.0, 0.0, (0.0, 0.0, 0.0, 0.0))
+    CProblem(0, size(p.A, 1), size(p.B, 2), N, B, A, Bm, dyn_tv(p), p.dyn_batched, Q, R, 0.0, 0.0, 0.0, 0.0, (0.0, 0.0, 0.0, 0.0), isdiag(p.Q) && isdiag(p.R))
 cproblem(p::PendcartProblem, N, B; A=NULLF, Bm=NULLF, Q=pointer(p.Q), R=pointer(p.R)) =
-    CProblem(1, 4, 1, N, B, A, Bm, 0, 0, Q, R, p.g, p.l, p.h, p.d, (p.goal[1], p.goal[2], p.goal[3], p.goal[4]))
+    CProblem(1, 4, 1, N, B, A, Bm, 0, 0, Q, R, p.g, p.l, p.h, p.d, (p.goal[1], p.goal[2], p.goal[3], p.goal[4]), isdiag(p.Q) && isdiag(p.R))
 
 _f64(a) = Array{Float64}(a)      # dense column-major copy (handles Diagonal cxx, Vector cuu of the demos)
 _lims(lims) = (lims === nothing || isempty(lims)) ? Float64[] : _f64(lims)

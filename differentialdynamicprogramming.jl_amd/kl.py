@@ -314,6 +314,8 @@ def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u,
         P = _lib.Problem()
         P.kind, P.n, P.m, P.N, P.B = problem.kind, n, m, N, B
         P.Q, P.R = up(problem.Q), up(np.atleast_2d(problem.R))
+        Qh, Rh = np.asarray(problem.Q, float), np.atleast_2d(np.asarray(problem.R, float))
+        P.cost_diag = int(not np.any(Qh - np.diag(np.diag(Qh))) and not np.any(Rh - np.diag(np.diag(Rh))))
         if problem.kind == 0:
             P.A, P.Bm = up(problem.A), up(problem.B)
             P.dyn_tv, P.dyn_batched = int(problem.dyn_tv), int(problem.dyn_batched)

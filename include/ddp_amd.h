@@ -131,6 +131,10 @@ typedef struct {
     /* pendcart (n = 4, m = 1; Q [4,4], R [1,1] above) */
     double g, l, h, d;
     double goal[4];
+    /* 1: the caller declares Q and R DIAGONAL (true for the reference's demos: Q = h·I, R = 0.1h·I, Q = diag(10,1,2,1)); the rollout
+     * kernels of the n = 10 / m = 2 and pendcart shapes then evaluate the cost themselves from the values they hold instead of a
+     * second kernel re-reading xnew, unew (only the diagonals are read).  0: general Q, R.                                       */
+    int cost_diag;
 } ddp_problem;
 
 /* cost vector length per trajectory: LQ -> N, pendcart -> N+1 */

@@ -92,6 +92,7 @@ def c3(B=4096):
     prob.Q, prob.R = Q.data_ptr(), R.data_ptr()
     prob._Q, prob._R = Q, R
     prob.g, prob.l, prob.h, prob.d = 9.82, 0.35, 0.01, 0.99
+    prob.cost_diag = 1
     for i, v in enumerate([np.pi, 0, 0, 0]):
         prob.goal[i] = v
     rng = np.random.default_rng(0)

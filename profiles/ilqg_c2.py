@@ -28,6 +28,7 @@ n, m = 10, 2
 dA, dB, dQ, dR, dx0, du0 = map(f64, (P["A"], P["B"], P["Q"], P["R"], x0, u0))
 pr = _lib.Problem(); pr.kind, pr.n, pr.m, pr.N, pr.B = 0, n, m, T, B
 pr.A, pr.Bm, pr.Q, pr.R = dA.data_ptr(), dB.data_ptr(), dQ.data_ptr(), dR.data_ptr()
+pr.cost_diag = 1
 e = lambda c: torch.empty(int(c), dtype=torch.float64, device=dev)
 x, u, K, k, Quu, Vx, Vxx, cost, stats = e(n*T*B), e(m*T*B), e(m*n*T*B), e(m*T*B), e(m*m*T*B), e(n*T*B), e(n*n*T*B), e(T*B), e(8*B)
 git = C.c_int(0)

@@ -385,3 +385,42 @@ def test_capi_comm_single_rank(ddp):
             comm.allreduce(d, 60, 10)                       # more than DDP_COMM_MAX_STATS entries
     finally:
         h.free(d); comm.close()
+
+
+@pytest.mark.parametrize("family,lane", [("lq", None), ("pendcart", "0"), ("pendcart", "1")])
+@pytest.mark.parametrize("N", [1, 2, 7, 8, 15, 16, 17, 31, 32, 33, 100])
+def test_fused_cost_equals_cost_kernel(ddp, monkeypatch, family, lane, N):
+    """ddp_problem::cost_diag: the rollout kernels evaluate the cost themselves (16-step LDS tile in the row kernel, in the lane for
+    the one-lane-per-rollout pendcart kernel); every horizon remainder against the separate cost kernel and the oracle"""
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(N)
+    B = 9
+    if lane is not None:
+        monkeypatch.setenv("DDP_FORWARD_LANE", lane)
+    if family == "lq":
+        from oracle import np_restatement as npr
+        P = npr.make_lq_problem(rng, T=N)
+        Q, R = np.diag(rng.uniform(0.5, 2.0, 10)), np.diag(rng.uniform(0.1, 1.0, 2))
+        prob = ddp.LQProblem(P["A"], P["B"], Q, R)
+        n, m, lims = 10, 2, np.array([[-0.3, 0.4], [-0.2, 0.25]])
+        p = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=Q, R=R)
+    else:
+        prob = ddp.PendcartProblem(Q=np.diag(rng.uniform(0.5, 10.0, 4)), R=np.array([[0.7]]))
+        n, m, lims = 4, 1, np.array([[-5.0, 5.0]])
+        p = oc.make_problem("pendcart", 4, 1, N, Q=prob.Q, R=prob.R, pend=dict(g=prob.g, l=prob.l, h=prob.h, d=prob.d, goal=prob.goal))
+    x0 = rng.standard_normal((n, B)) + (np.array([np.pi, 0, 0, 0])[:, None] if family == "pendcart" else 0)
+    u = 0.5 * rng.standard_normal((m, N, B)); x = rng.standard_normal((n, N, B))
+    K = 0.1 * rng.standard_normal((m, n, N, B)); k = 0.1 * rng.standard_normal((m, N, B))
+    al = np.array([1.0, 0.3, 0.05])
+    pol = ddp.GaussianPolicy(N, n, m, K, k)
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DDP_FORWARD_FUSE", fuse)
+        outs[fuse] = ddp.forward_pass(pol, x0, u, x, al, prob, lims)
+    for a_, b_ in zip(outs["1"], outs["0"]):
+        assert a_.shape == b_.shape and relerr(a_, b_) < 1e-13
+    xn, un, cn = outs["1"]
+    for b in (0, B - 1):
+        for j, a in enumerate(al):
+            xr, ur, cr = oc.forward_pass(p, (K[..., b], k[..., b]), x0[:, b], u[..., b], x[..., b], float(a), lims)
+            assert relerr(cn[:, b, j], cr) < 1e-12 and relerr(xn[..., b, j], xr) < RTOL
