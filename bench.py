@@ -154,7 +154,8 @@ class PassBench:
         return {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": bp_bytes_launch,
                 "avg_launch_ms": round(bp_avg_ms, 4),
-                "forward_kernels": {"kernels": "forward_dpp_kernel + cost_kernel", "avg_launch_ms": round(fp_avg_ms, 4),
+                "forward_kernels": {"kernels": "forward_dpp_kernel (cost fused, ddp_problem::cost_diag)" if os.environ.get("DDP_FORWARD_FUSE", "1") != "0"
+                                    else "forward_dpp_kernel + cost_kernel", "avg_launch_ms": round(fp_avg_ms, 4),
                                     "bytes_per_launch": fp_bytes * N * B,
                                     "achieved_GBs": round(fp_bytes * N * B / (fp_avg_ms * 1e-3) / 1e9, 1)},
                 "pass_bytes": (bp_read + bp_write + fp_bytes) * N}
@@ -171,6 +172,7 @@ def main():
                     help="who issues the per-step statistics all-reduce: torch.distributed (backend nccl = RCCL) or the C ABI's own RCCL "
                          "communicator (ddp_allreduce_stats_f64_dev; torch.distributed then only ships the 128-byte id)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 pass lines (profiles/bench_configs.py in a child process)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories for the CPU baseline (0 = auto ~10-20 s)")
     ap.add_argument("--fill-batch", type=int, default=32768, help="machine-filling batch reported next to the headline (0 = skip)")
     args = ap.parse_args()
@@ -215,10 +217,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     roofline = pb.roofline(bp_ms, fp_ms)
+    # HBM traffic per launch comes from the PMC passes of profiles/run_profile.sh (rocprofv3 --pmc cannot wrap a process from the
+    # inside): the committed figure for THIS kernel at THIS batch, or null — never a number measured for another batch or kernel
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    roofline["traffic_source"] = None
     if os.path.exists(tfile):
         try:
-            roofline["traffic"] = json.load(open(tfile)).get(roofline["kernel"].split("<")[0] + "_bytes_per_launch_B%d" % B)
+            tj = json.load(open(tfile))
+            key = roofline["kernel"].split("<")[0] + "_bytes_per_launch_B%d" % B
+            roofline["traffic"] = tj.get(key)
+            roofline["traffic_source"] = ("profiles/pmc_traffic.json[%s]: %s — replayed from the committed profile, not measured in this run" % (key, tj.get("_source", "?"))
+                                          if key in tj else "no PMC profile committed for %s" % key)
         except Exception:
             pass
     roofline["note"] = ("each trajectory is a length-N dependency chain: at B=1024 (one wave per SIMD) the fraction is "
@@ -241,6 +250,9 @@ def main():
                     "ms_per_step": round(1e3 * e2 / 5, 3), "back_pass_kernel": r2["kernel"], "back_pass_ms": r2["avg_launch_ms"],
                     "back_pass_roofline_frac": r2["frac"], "forward_ms": r2["forward_kernels"]["avg_launch_ms"]}
             del pf
+        other = None
+        if world == 1 and not args.no_other_configs:
+            other = other_configs()
         value = B * world * args.steps / elapsed
         out = {"metric": "iLQG iterations/sec (backward+forward, n=10 m=2 T=1000)", "value": round(value, 1),
                "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -250,11 +262,41 @@ def main():
                                       "limits, regType=1, lambda=1; one step = back_pass + forward_pass(alpha=1) over the batch" % (N, B),
                           "batch_per_gpu": B, "n": n, "m": m, "N": N, "sharding": "batch (independent trajectories), "
                           "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1 (issued by %s)" % ("the C ABI, ddp_allreduce_stats_f64_dev" if args.collective == "capi" else "torch.distributed")},
-               "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill}
+               "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill, "other_configs": other}
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def other_configs():
+    """Pass time of BASELINE configs 3 and 4 on this GPU (profiles/bench_configs.py in a child process, after the timed region):
+    informational lines so that every configuration has a number in the driver's record; the graded value is config 2's."""
+    import subprocess
+    env = dict(os.environ, DDP_C4_SOLVE="0")
+    out = []
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c4"], env=env, capture_output=True, text=True,
+                           timeout=240)
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                out.append(json.loads(line))
+        if not out:
+            out = {"error": (r.stderr or "no output")[-300:]}
+    except Exception as exc:
+        out = {"error": str(exc)}
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if isinstance(out, list) and os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            for o in out:
+                tag = "C3" if o["config"].startswith("C3") else "C4"
+                o["back_pass_pmc_bytes_per_launch"] = tj.get("%s_back_pass_bytes_per_launch_B%d" % (tag, o["batch"]))
+                if tag == "C4":
+                    o["back_pass_mfma_busy_frac"] = tj.get("C4_back_pass_mfma_busy_frac")
+        except Exception:
+            pass
     return out
 
 

@@ -41,10 +41,28 @@ for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), re
 print("## PMC, mean per launch of kernels matching %r" % ksub)
 for c, v in sorted(acc.items()):
     print("  %-26s %18.1f (n=%d)" % (c, sum(v) / len(v), len(v)))
+upd = {}
 if "FETCH_SIZE" in acc and "WRITE_SIZE" in acc:
     fs = sum(acc["FETCH_SIZE"]) / len(acc["FETCH_SIZE"]); ws = sum(acc["WRITE_SIZE"]) / len(acc["WRITE_SIZE"])
     print("## HBM traffic per launch: FETCH_SIZE KiB x1024 x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KiB x1024 = %.1f MB"
           % ((2 * fs + ws) * 1024 / 1e6))
+    batch = json.loads(open(os.path.join(root, "events.json")).read().strip().splitlines()[0])["batch"]
+    upd["%s_back_pass_bytes_per_launch_B%d" % (cfg.upper(), batch)] = int((2 * fs + ws) * 1024)
+if acc.get("SQ_VALU_MFMA_BUSY_CYCLES") and acc.get("GRBM_GUI_ACTIVE") and sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"]) > 0:
+    # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of the 1024 matrix pipes (check: = MFMA instructions x their pass cycles);
+    # GRBM_GUI_ACTIVE sums the kernel's cycles over the 8 XCDs
+    mean = lambda k: sum(acc[k]) / len(acc[k])
+    frac = mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
+    print("## MFMA pipe busy: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = %.3f" % frac)
+    upd["%s_back_pass_mfma_busy_frac" % cfg.upper()] = round(frac, 4)
+if upd:
+    for tf in (os.path.join(os.path.dirname(root.rstrip("/")), "..", "profiles", "pmc_traffic.json"), os.path.join(root, "pmc_traffic_update.json")):
+        try:
+            prev = json.load(open(tf)) if os.path.exists(tf) else {}
+            prev.update(upd)
+            json.dump(prev, open(tf, "w"), indent=1)
+        except Exception as exc:
+            print("## could not update", tf, exc)
 PY
 cat $OUT/summary.txt
 find $OUT -name "*kernel_trace.csv" -size +4M -delete
