@@ -51,6 +51,7 @@ struct Q4Args {
     const int32_t *active;
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
     int32_t *diverge;
+    double *sink;               // >= 64 x 16 B that lanes without an output may write (paired kernel: stores carry no exec-mask branch)
 };
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -64,6 +65,16 @@ __device__ __forceinline__ void row_swap(double a, double b, double &x, double &
     const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
     const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
     const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    x = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
+    y = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+}
+
+// x = the lower 32 lanes' value in every lane, y = the upper 32 lanes' (v_permlane32_swap per dword)
+__device__ __forceinline__ void half_swap(double a, double &x, double &y)
+{
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a);
+    const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ua, false, false);
+    const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ua >> 32), false, false);
     x = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
     y = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
 }
@@ -293,17 +304,22 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
     const double *fxp = a.fx + a.fx_b * b + (re + 4 * c) + (odd ? 0 : a.fx_t);
     const double *fup = a.fu + a.fu_b * b + re + (odd ? 0 : a.fu_t);
     const double *cxp = a.cx + (size_t)n * N * b + re + (odd ? 0 : n);
-    const double *cup = a.cu + (size_t)N * b;
-    const double *up = LIMS ? a.u + (size_t)N * b : cup;
+    // cu and u pairs come with ONE load: rows 0, 1 of a block fetch {cu[2p], cu[2p+1]}, rows 2, 3 {u[2p], u[2p+1]}; v_permlane32_swap
+    // hands both to every lane
+    const double *cup = (LIMS && r >= 2) ? a.u + (size_t)N * b : a.cu + (size_t)N * b;
     const double *cxx = a.cxx + a.cxx_b * b, *cuu = a.cuu + a.cuu_b * b, *cxu = a.cxu + a.cxu_b * b;
-    double *Vxxp = a.Vxx + (size_t)16 * N * b + (re + 4 * c) + (odd ? 0 : 16);
+    // stores are UNCONDITIONAL: a lane without an output (inactive trajectory, lanes outside the merged store) writes its own 16 bytes
+    // of the sink instead (stride 0) — an `if` around a store costs s_and_saveexec + branch + s_or per store and step
+    double *Vxxp = act ? a.Vxx + (size_t)16 * N * b + (re + 4 * c) + (odd ? 0 : 16) : a.sink + 2 * lane;
+    const unsigned vxx_stride = act ? 32u * 8u : 0u;            // bytes per pair
     // merged 16-byte store per pair: lanes [.][0]: K pairs, [.][1]: Vx pairs (row parity selects the step like the loads),
     // lane [0][2]: {k[2p], k[2p+1]}, lane [0][3]: {Quu[2p], Quu[2p+1]}
     const bool st_K = c == 0, st_Vx = c == 1, st_s = (r == 0 && c >= 2);
     const bool st_on = act && (st_K || st_Vx || st_s);
-    double *st_base = st_K ? a.K + (size_t)n * N * b + re + (odd ? 0 : n) : st_Vx ? a.Vx + (size_t)n * N * b + re + (odd ? 0 : n)
+    double *st_base = !st_on ? a.sink + 2 * lane
+                      : st_K ? a.K + (size_t)n * N * b + re + (odd ? 0 : n) : st_Vx ? a.Vx + (size_t)n * N * b + re + (odd ? 0 : n)
                       : (c == 2) ? a.k + (size_t)N * b : a.Quu + (size_t)N * b;
-    const unsigned st_stride = (st_K || st_Vx) ? 2u * n * 8u : 16u;      // bytes per pair
+    const unsigned st_stride = !st_on ? 0u : (st_K || st_Vx) ? 2u * n * 8u : 16u;      // bytes per pair
 
     Q4Par par;
     par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;
@@ -312,19 +328,19 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
     Q4In cst;
     cst.cxx = cxx[e]; cst.cxxT = cxx[et]; cst.cxuc = cxu[r]; cst.cxur = cxu[c]; cst.cuu = cuu[0];
 
-    struct Pair { d2 fx, fu, cx, cu, u; };
+    struct Pair { d2 fx, fu, cx, cu; };
     auto fetch = [&](int p, Pair &o) {
         o.fx = *(const d2 *)(fxp + (size_t)(unsigned)(2 * a.fx_t * p));
         o.fu = *(const d2 *)(fup + (size_t)(unsigned)(2 * a.fu_t * p));
         o.cx = *(const d2 *)(cxp + (size_t)(unsigned)(2 * n * p));
         o.cu = *(const d2 *)(cup + (size_t)(unsigned)(2 * p));
-        o.u = *(const d2 *)(up + (size_t)(unsigned)(2 * p));
     };
     auto unpack = [&](const Pair &o, Q4In &A, Q4In &Bs) {
         row_swap(o.fx.x, o.fx.y, A.fx, Bs.fx);
         row_swap(o.fu.x, o.fu.y, A.fu, Bs.fu);
         row_swap(o.cx.x, o.cx.y, A.cx, Bs.cx);
-        A.cu = o.cu.y; Bs.cu = o.cu.x; A.u = o.u.y; Bs.u = o.u.x;
+        half_swap(o.cu.y, A.cu, A.u);                           // lower half of the wave holds cu, upper half u
+        half_swap(o.cu.x, Bs.cu, Bs.u);
         A.cxx = Bs.cxx = cst.cxx; A.cxxT = Bs.cxxT = cst.cxxT; A.cxuc = Bs.cxuc = cst.cxuc; A.cxur = Bs.cxur = cst.cxur;
         A.cuu = Bs.cuu = cst.cuu;
     };
@@ -332,13 +348,13 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
         if (EXP & 1) return;
         double x, y;
         row_swap(oa.Vn, ob.Vn, x, y);
-        if (act) *(d2 *)(Vxxp + (size_t)(unsigned)(32 * p)) = d2{x, y};
+        *(d2 *)((char *)Vxxp + (size_t)((unsigned)p * vxx_stride)) = d2{x, y};
         // lanes [0][2], [0][3] store {value of step 2p, value of step 2p+1}: after the swap row 0 holds x = a(row 0), y = a(row 1)
         const double sa = (c == 2) ? (r == 0 ? ob.kk : oa.kk) : (r == 0 ? ob.Quu : oa.Quu);
         const double va = st_K ? oa.Kc : st_Vx ? oa.vx : sa;
         const double vb = st_K ? ob.Kc : ob.vx;
         row_swap(va, vb, x, y);
-        if (st_on) *(d2 *)((char *)st_base + (size_t)((unsigned)p * st_stride)) = d2{x, y};
+        *(d2 *)((char *)st_base + (size_t)((unsigned)p * st_stride)) = d2{x, y};
     };
 
     Q4State s;
@@ -413,13 +429,14 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.lims = lims;
     a.u = u; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    a.sink = (double *)h->sink;
     const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
     const char *ex = getenv("DDP_Q4_EXP");
     const int exp = ex ? atoi(ex) : 0;
     const char *sg = getenv("DDP_Q4_SINGLE");                  // 1: force the one-step-at-a-time kernel (tests)
     const bool aligned16 = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu |
                               (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)(d->has_lims ? u : cu)) & 15) == 0);
-    const bool paired = !d->cost_tv && (d->N % 2 == 0) && d->N >= 4 * Q4_DP && aligned16 && !(sg && sg[0] == '1');
+    const bool paired = !d->cost_tv && (d->N % 2 == 0) && d->N >= 4 * Q4_DP && aligned16 && h->sink != nullptr && !(sg && sg[0] == '1');
 #define Q4P(L_, R_, E_) hipLaunchKernelGGL((back_pass_q4p_kernel<L_, R_, E_>), grid, block, 0, h->stream, a)
 #define Q4S(L_, C_, R_) hipLaunchKernelGGL((back_pass_q4_kernel<L_, C_, R_>), grid, block, 0, h->stream, a)
     const bool reg2 = d->regType == 2;

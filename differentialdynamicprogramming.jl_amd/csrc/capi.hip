@@ -52,6 +52,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
         return -2;
     }
     if (hipHostMalloc((void **)&h->h_pinned, 256) != hipSuccess) h->h_pinned = nullptr;
+    if (hipMalloc(&h->sink, 4096) != hipSuccess) h->sink = nullptr;
     *out = h;
     return 0;
 }
@@ -66,6 +67,7 @@ int ddp_destroy(ddp_handle h)
     hipStreamSynchronize(h->stream);
     if (h->scratch) hipFree(h->scratch);
     if (h->h_pinned) hipHostFree(h->h_pinned);
+    if (h->sink) hipFree(h->sink);
     if (h->tev_ok) for (int e = 0; e < 4; ++e) hipEventDestroy(h->tev[e]);
     if (h->owns_stream) hipStreamDestroy(h->stream);
     delete h;

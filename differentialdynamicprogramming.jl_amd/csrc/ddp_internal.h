@@ -17,6 +17,7 @@ struct ddp_handle_s {
     void        *scratch;
     size_t       scratch_bytes;
     int32_t     *h_pinned;        // small pinned buffer for polling
+    void        *sink;            // 4 KB of device memory that masked-out lanes may write (stores without an exec-mask branch)
     double      *timing;          // ddp_ilqg_set_timing: host buffer [3, timing_cap] or NULL
     int          timing_cap;
     hipEvent_t   tev[4];          // created on first use
