@@ -622,6 +622,92 @@ int ddp_launch_back_pass_gps(ddp_handle h, const ddp_bp_desc *d, const double *c
 #endif
 }
 
+// ---- odd sizes above the run-time-sized kernel's range (33 <= n <= 63 odd, or an odd m with n > 32): the 256-thread kernel
+// works on 2x2 register blocks, so the problem is embedded in the next even sizes — an extra state that stays zero and costs
+// nothing, an extra control with cuu = 1, zero gradient and no coupling (its gain is exactly zero) — and the results cut back.
+// Sums gain exact zeros only, so the outputs are those of the unpadded problem.  Compatibility path: operands and results take a
+// trip through a pad buffer owned by the handle.
+namespace {
+// dst[rp x cp x cnt] <- src[r x c x cnt] in the top-left corner, zeros elsewhere, ones on the diagonal from index `one_from` on
+__global__ __launch_bounds__(256) void pad2d_kernel(const double *src, double *dst, int r, int c, int rp, int cp, long cnt, int one_from)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)rp * cp * cnt) return;
+    const int i = (int)(e % rp), j = (int)((e / rp) % cp);
+    const long t = e / ((long)rp * cp);
+    dst[e] = (i < r && j < c) ? src[i + (long)r * (j + (long)c * t)] : ((i == j && i >= one_from) ? 1.0 : 0.0);
+}
+// dst[r x c x cnt] <- top-left corner of src[rp x cp x cnt]; `per` consecutive slices belong to one trajectory (active mask)
+__global__ __launch_bounds__(256) void unpad2d_kernel(const double *src, double *dst, int r, int c, int rp, int cp, long cnt, long per,
+                                                      const int32_t *active)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)r * c * cnt) return;
+    const int i = (int)(e % r), j = (int)((e / r) % c);
+    const long t = e / ((long)r * c);
+    if (active && active[t / per] == 0) return;
+    dst[e] = src[i + (long)rp * (j + (long)cp * t)];
+}
+}   // namespace
+
+static int launch_back_pass_padded(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu, const double *cxx, const double *cxu,
+                                   const double *cuu, const double *fx, const double *fu, const double *lambda, const double *lims,
+                                   const double *u, const int32_t *active, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                                   double *dV, int32_t *diverge)
+{
+    const int n = d->n, m = d->m, np_ = n + (n & 1), mp = m + (m & 1);
+    const long N = d->N, B = d->B;
+    const long cf = (d->fx_tv ? N : 1) * (d->fx_batched ? B : 1), cc = (d->cost_tv ? N : 1) * (d->cost_batched ? B : 1), NB = N * B;
+    auto al = [](size_t b_) { return (b_ + 255) & ~(size_t)255; };
+    const size_t s_cx = al((size_t)np_ * NB * 8), s_cu = al((size_t)mp * NB * 8), s_cxx = al((size_t)np_ * np_ * cc * 8),
+                 s_cxu = al((size_t)np_ * mp * cc * 8), s_cuu = al((size_t)mp * mp * cc * 8), s_fx = al((size_t)np_ * np_ * cf * 8),
+                 s_fu = al((size_t)np_ * mp * cf * 8), s_l = al((size_t)mp * 2 * 8), s_K = al((size_t)mp * np_ * NB * 8),
+                 s_Quu = al((size_t)mp * mp * NB * 8), s_Vxx = al((size_t)np_ * np_ * NB * 8);
+    const size_t bytes = s_cx + 2 * s_cu + s_cxx + s_cxu + s_cuu + s_fx + s_fu + s_l + s_K + s_cu + s_Quu + s_cx + s_Vxx;
+    if (bytes > h->pad_bytes) {
+        DDP_HIP(hipStreamSynchronize(h->stream));
+        if (h->pad) DDP_HIP(hipFree(h->pad));
+        h->pad = nullptr; h->pad_bytes = 0;
+        DDP_HIP(hipMalloc(&h->pad, bytes));
+        h->pad_bytes = bytes;
+    }
+    char *q = (char *)h->pad;
+    auto tk = [&](size_t b_) { double *r_ = (double *)q; q += b_; return r_; };
+    double *pcx = tk(s_cx), *pcu = tk(s_cu), *pu = tk(s_cu), *pcxx = tk(s_cxx), *pcxu = tk(s_cxu), *pcuu = tk(s_cuu), *pfx = tk(s_fx),
+           *pfu = tk(s_fu), *pl = tk(s_l), *pK = tk(s_K), *pk = tk(s_cu), *pQuu = tk(s_Quu), *pVx = tk(s_cx), *pVxx = tk(s_Vxx);
+    hipStream_t st = h->stream;
+    auto pad = [&](const double *src, double *dst, int r, int c, int rp, int cp, long cnt, int one_from) {
+        const long tot = (long)rp * cp * cnt;
+        hipLaunchKernelGGL(pad2d_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, dst, r, c, rp, cp, cnt, one_from);
+    };
+    pad(cx, pcx, n, 1, np_, 1, NB, 1 << 30); pad(cu, pcu, m, 1, mp, 1, NB, 1 << 30);
+    if (u) pad(u, pu, m, 1, mp, 1, NB, 1 << 30);
+    pad(cxx, pcxx, n, n, np_, np_, cc, 1 << 30); pad(cxu, pcxu, n, m, np_, mp, cc, 1 << 30); pad(cuu, pcuu, m, m, mp, mp, cc, m);
+    pad(fx, pfx, n, n, np_, np_, cf, 1 << 30); pad(fu, pfu, n, m, np_, mp, cf, 1 << 30);
+    if (lims) {                                                 // the extra control is free inside [-1, 1] (it stays at 0)
+        double hl[2 * DDP_MAX_M];
+        DDP_HIP(hipMemcpyAsync(hl, lims, (size_t)m * 2 * 8, hipMemcpyDeviceToHost, st));
+        DDP_HIP(hipStreamSynchronize(st));
+        double hp[2 * DDP_MAX_M + 4];
+        for (int q2 = 0; q2 < mp; ++q2) { hp[q2] = q2 < m ? hl[q2] : -1.0; hp[q2 + mp] = q2 < m ? hl[q2 + m] : 1.0; }
+        DDP_HIP(hipMemcpyAsync(pl, hp, (size_t)mp * 2 * 8, hipMemcpyHostToDevice, st));
+        DDP_HIP(hipStreamSynchronize(st));                      // hp lives on this stack frame
+    }
+    ddp_bp_desc dp = *d;
+    dp.n = np_; dp.m = mp;
+    const int rc = ddp_launch_back_pass_big(h, &dp, pcx, pcu, pcxx, pcxu, pcuu, pfx, pfu, lambda, lims ? pl : nullptr, u ? pu : nullptr, active,
+                                            pK, pk, pQuu, pVx, pVxx, dV, diverge);
+    if (rc) return rc < 0 ? rc : -1;
+    auto unpad = [&](const double *src, double *dst, int r, int c, int rp, int cp) {
+        const long tot = (long)r * c * NB;
+        hipLaunchKernelGGL(unpad2d_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, dst, r, c, rp, cp, NB, N, active);
+    };
+    unpad(pK, K, m, n, mp, np_); unpad(pk, k, m, 1, mp, 1); unpad(pQuu, Quu, m, m, mp, mp); unpad(pVx, Vx, n, 1, np_, 1);
+    unpad(pVxx, Vxx, n, n, np_, np_);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
 int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                          const double *cxx, const double *cxu, const double *cuu, const double *fx,
                          const double *fu, const double *lambda, const double *lims, const double *u,
@@ -680,7 +766,9 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
         const int rc = ddp_launch_back_pass_big(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;
     }
-    DDP_CHECK(d->n <= DDP_MAX_N_GENERIC, "back_pass: n=%d m=%d has no kernel (n <= %d any m <= %d; even n <= 64 with even m <= 8)", d->n, d->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
+    if (d->n > DDP_MAX_N_GENERIC && d->n <= 64 && ((d->n | d->m) & 1))      // odd n or m: embed in the next even sizes
+        return launch_back_pass_padded(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+    DDP_CHECK(d->n <= DDP_MAX_N_GENERIC, "back_pass: n=%d m=%d has no kernel (n <= %d with m <= %d, or n <= 64)", d->n, d->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
     return launch_nm<0, 0>(h, d, a);
 #else
     DDP_CHECK(false, "back_pass: DDP_FAST_BUILD only has the (10,2) LTI kernel");

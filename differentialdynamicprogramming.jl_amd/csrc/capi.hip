@@ -41,6 +41,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
     h->device = device;
     h->scratch = nullptr;
     h->scratch_bytes = 0;
+    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr;
     h->h_pinned = nullptr;
     h->timing = nullptr; h->timing_cap = 0; h->tev_ok = false;
     h->owns_stream = !adopt;
@@ -68,6 +69,7 @@ int ddp_destroy(ddp_handle h)
     if (h->scratch) hipFree(h->scratch);
     if (h->h_pinned) hipHostFree(h->h_pinned);
     if (h->sink) hipFree(h->sink);
+    if (h->pad) hipFree(h->pad);
     if (h->tev_ok) for (int e = 0; e < 4; ++e) hipEventDestroy(h->tev[e]);
     if (h->owns_stream) hipStreamDestroy(h->stream);
     delete h;

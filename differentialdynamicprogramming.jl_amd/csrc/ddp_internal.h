@@ -17,6 +17,8 @@ struct ddp_handle_s {
     void        *scratch;
     size_t       scratch_bytes;
     int32_t     *h_pinned;        // small pinned buffer for polling
+    void        *pad;             // operands / results of a backward pass padded to even sizes (back_pass.hip), grown on demand
+    size_t       pad_bytes;
     void        *sink;            // 4 KB of device memory that masked-out lanes may write (stores without an exec-mask branch)
     double      *timing;          // ddp_ilqg_set_timing: host buffer [3, timing_cap] or NULL
     int          timing_cap;

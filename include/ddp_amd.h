@@ -71,7 +71,10 @@ typedef struct {
  *          `active` (may be NULL): int32[B]; trajectories with active[b]==0 are skipped entirely
  * outputs: K[m,n,N,B] k[m,N,B] Quu[m,m,N,B] Vx[n,N,B] Vxx[n,n,N,B] dV[2,B] diverge int32[B]
  *          (diverge: 0 ok, else the 1-based failing time index; outputs earlier in time than the
- *          failing step are zero like the reference's zero-initialised arrays)                     */
+ *          failing step are zero like the reference's zero-initialised arrays)
+ * shapes : m <= DDP_MAX_M (8); n <= 64 (n = 10/m = 2, n = 4/m = 1 and n = 64/m = 8 have their own kernels; odd n > 32 or an odd m with
+ *          n > 32 runs embedded in the next even sizes through a pad buffer of the handle).  Larger n or m: return code < 0.
+ *          back_pass_gps: n <= 32.                                                                     */
 int ddp_back_pass_f64_dev(ddp_handle h, const ddp_bp_desc *d,
                           const double *cx, const double *cu, const double *cxx, const double *cxu,
                           const double *cuu, const double *fx, const double *fu,

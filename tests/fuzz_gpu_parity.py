@@ -20,7 +20,7 @@ def spd(rng, d, s):
 
 
 def gen_case(rng):
-    n, m = [(10, 2), (4, 1), (6, 3), (64, 8), (7, 2), (12, 4), (40, 4)][rng.integers(0, 7)]
+    n, m = [(10, 2), (4, 1), (6, 3), (64, 8), (7, 2), (12, 4), (40, 4), (37, 3), (51, 2)][rng.integers(0, 9)]
     big = rng.integers(0, 6) == 0                                 # now and then a long horizon / several waves
     N = (int(rng.integers(1, 300 if big else 40))) if n < 40 else int(rng.integers(2, 50 if big else 14))
     B = int(rng.integers(1, 70 if (big and n < 40) else 6))
@@ -49,7 +49,7 @@ def gen_case(rng):
         cuu[:, :, int(rng.integers(0, N - 1)), int(rng.integers(0, B))] = -np.eye(m)
     Q, R = spd(rng, n, h), spd(rng, m, 0.1 * h)
     x0 = rng.standard_normal((n, B)); xnom = rng.standard_normal((n, N, B))
-    impl = [None, None, None, "x", "fast", "dpp", "general", "big"][rng.integers(0, 8)]     # forced kernel (falls back when it has no such shape)
+    impl = [None, None, None, "x", "fast", "dpp", "general", "big", "q"][rng.integers(0, 9)]     # forced kernel (falls back when it has no such shape)
     return dict(impl=impl, n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, c_tv=c_tv, regType=regType, lims=lims, fx=fx, fu=fu, cxx=cxx, cuu=cuu, cxu=cxu,
                 cx=cx, cu=cu, u=u, lam=lam, Q=Q, R=R, x0=x0, xnom=xnom)
 

@@ -40,7 +40,8 @@ def _problem(rng, n, m, N, B, tv_cost):
     return cx, cu, cxx, cxu, cuu, fx, fu, u
 
 
-@pytest.mark.parametrize("n,m,impl", [(64, 8, "auto"), (64, 8, "big"), (40, 4, "auto")])   # auto at (64,8) = MFMA kernel
+@pytest.mark.parametrize("n,m,impl", [(64, 8, "auto"), (64, 8, "big"), (40, 4, "auto"),      # auto at (64,8) = MFMA kernel
+                                      (33, 2, "auto"), (35, 3, "auto"), (63, 7, "auto"), (40, 3, "auto"), (47, 8, "auto")])   # odd sizes: padded inside the launcher
 @pytest.mark.parametrize("tv_cost", [False, True])
 @pytest.mark.parametrize("regType,lims", [(1, False), (2, False), (1, True)])
 def test_back_pass_large(ddp, monkeypatch, n, m, impl, tv_cost, regType, lims):
