@@ -149,7 +149,7 @@ class PassBench:
         bp_bytes_launch = (bp_read + bp_write) * (N - 1) * B
         achieved = bp_bytes_launch / (bp_avg_ms * 1e-3) / 1e9
         force = os.environ.get("DDP_BACKPASS", "")[:1]
-        kern = {"x": "back_pass_mx_kernel<LTI>", "f": "back_pass_fast_kernel<10,LTI>", "d": "back_pass_dpp_kernel<10,2,LTI>",
+        kern = {"x": "back_pass_mx_kernel<LTI>", "d": "back_pass_dpp_kernel<10,2,LTI>",
                 "g": "back_pass_kernel<10,2>"}.get(force, "back_pass_mx_kernel<LTI>" if B < 5120 else "back_pass_dpp_kernel<10,2,LTI>")
         return {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": bp_bytes_launch,

@@ -722,12 +722,11 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     // Kernel choice.  Several implementations of the same arithmetic exist:
     //   x (mx)  one 16x16 fp64 MFMA tile per trajectory, one wave each (back_pass_mx.hip; n=10, m=2, no limits): shortest
     //           dependent chain per time step, best while the batch gives a SIMD only one or two waves (B=1024: 0.55 ms
-    //           against 0.90 ms for `fast`); measured cross-over with `dpp` between B=4096 and B=6144;
+    //           against 0.90 ms for the 64-lane vector kernel it replaced); measured cross-over with `dpp` between B=4096 and B=6144;
     //   dpp     16 lanes per trajectory (back_pass_dpp.hip): fewest instructions per trajectory-step, best once the
     //           batch gives every SIMD a few wavefronts; also the kernel for control limits;
-    //   fast    64 lanes per trajectory, LDS-lean vector kernel (back_pass_fast.hip; n=10, m=2, no limits);
     //   general 64 lanes per trajectory, any n <= 32 / m <= 8 / limits (this file).
-    // DDP_BACKPASS=x|q|general|fast|dpp|big forces one (A/B timing, tests of every code path).
+    // DDP_BACKPASS=x|q|general|dpp|big forces one (A/B timing, tests of every code path).
     const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
     if (force == 'x' || (force == 0 && d->B < 5120)) {
@@ -739,14 +738,8 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
         if (rc <= 0) return rc;
     }
     if (force != 'g' && force != 'b') {
-        if (force == 'f') {
-            const int rc = ddp_launch_back_pass_fast(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
-            if (rc <= 0) return rc;
-        }
-        if (force != 'f') {
-            const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
-            if (rc <= 0) return rc;
-        }
+        const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) return rc;
     }
     BPArgs a = {};
     a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;

@@ -74,12 +74,6 @@ int ddp_launch_back_pass_gps_lane(ddp_handle h, const ddp_bp_desc *d, const doub
                              const double *fu, const ddp_kl_cost_terms *kl, const double *lims, const double *u,
                              const int32_t *active, double *K, double *k, double *Quu, double *Quui, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge);
-// LDS-lean kernel for the unconstrained m=2 shapes; returns 1 when the shape has no fast kernel
-int ddp_launch_back_pass_fast(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
-                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
-                              const double *fu, const double *lambda, const int32_t *active, double *K,
-                              double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
-
 // n=10, m=2, no limits: one wave per trajectory, all matrices of a step in one 16x16 fp64 MFMA tile; 1 = not applicable
 int ddp_launch_back_pass_mx(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                             const double *cxx, const double *cxu, const double *cuu, const double *fx,

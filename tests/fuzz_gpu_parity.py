@@ -49,7 +49,7 @@ def gen_case(rng):
         cuu[:, :, int(rng.integers(0, N - 1)), int(rng.integers(0, B))] = -np.eye(m)
     Q, R = spd(rng, n, h), spd(rng, m, 0.1 * h)
     x0 = rng.standard_normal((n, B)); xnom = rng.standard_normal((n, N, B))
-    impl = [None, None, None, "x", "fast", "dpp", "general", "big", "q"][rng.integers(0, 9)]     # forced kernel (falls back when it has no such shape)
+    impl = [None, None, None, "x", "dpp", "dpp", "general", "big", "q"][rng.integers(0, 9)]     # forced kernel (falls back when it has no such shape)
     return dict(impl=impl, n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, c_tv=c_tv, regType=regType, lims=lims, fx=fx, fu=fu, cxx=cxx, cuu=cuu, cxu=cxu,
                 cx=cx, cu=cu, u=u, lam=lam, Q=Q, R=R, x0=x0, xnom=xnom)
 

@@ -25,7 +25,7 @@ def _lq(rng, n, m, N, B):
     return P, x, u, cx, cu
 
 
-@pytest.mark.parametrize("impl", ["general", "fast", "dpp", "x"])
+@pytest.mark.parametrize("impl", ["general", "dpp", "x"])
 @pytest.mark.parametrize("N", [1, 2, 3, 9])
 def test_back_pass_short_horizons(ddp, monkeypatch, impl, N):
     """N=1: only the terminal assignments (backward_pass.jl:234-236); N=2: a single Riccati step"""
@@ -44,7 +44,7 @@ def test_back_pass_short_horizons(ddp, monkeypatch, impl, N):
             assert np.max(np.abs(got - ref)) <= RTOL * max(1e-300, np.max(np.abs(ref)))
 
 
-@pytest.mark.parametrize("impl", ["general", "fast", "dpp", "x"])
+@pytest.mark.parametrize("impl", ["general", "dpp", "x"])
 @pytest.mark.parametrize("B", [1, 2, 5, 7])
 def test_back_pass_ragged_batches(ddp, monkeypatch, impl, B):
     """batch sizes that do not fill a wavefront's four 16-lane rows"""

@@ -239,7 +239,7 @@ def _tv_problem(rng, n, m, N, B):
     return cx, cu, cxx, cxu, cuu, fx, fu, u
 
 
-@pytest.mark.parametrize("impl", ["general", "fast", "dpp", "x"])
+@pytest.mark.parametrize("impl", ["general", "dpp", "x"])
 @pytest.mark.parametrize("variant", ["lti", "ltv", "tvcost"])
 @pytest.mark.parametrize("regType", [1, 2])
 def test_back_pass_implementations_n10m2(ddp, monkeypatch, impl, variant, regType):
@@ -277,7 +277,7 @@ def test_back_pass_implementations_limits(ddp, monkeypatch, impl, name):
         assert relerr(got, g[key]) < RTOL, (key, relerr(got, g[key]))
 
 
-@pytest.mark.parametrize("impl", ["general", "fast", "dpp", "x"])
+@pytest.mark.parametrize("impl", ["general", "dpp", "x"])
 def test_back_pass_divergence_per_trajectory(ddp, monkeypatch, impl):
     """a non-PD Quu in ONE trajectory of a batch stops that trajectory only (diverge index, zeros before it)"""
     from oracle import oracle_ctypes as oc
