@@ -31,6 +31,7 @@
 #pragma once
 #include "ddp_internal.h"
 #include "boxqp_dev.h"
+#include "boxqp_rows.h"
 
 struct BPMArgs {
     int N, B;
@@ -52,9 +53,9 @@ constexpr int oVs = 0, oFs = oVs + n * LDV, oWT = oFs + PP * LDK, ovs = oWT + n 
 #ifdef DDP_MFPROF     // per-phase cycle counts (s_memtime) of block 0, printed per wave: profiling builds only
 #define MFP_DECL long long mfp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mfp_t = __builtin_amdgcn_s_memtime()
 #define MFP(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); mfp_[k] += t_ - mfp_t; mfp_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define MFP_PRINT do { if (b == 0 && lane == 0) printf("MFPROF wave %d steps %d: ph1 %lld bar %lld ph2 %lld bar %lld ph3 %lld bar %lld stF %lld bar %lld | ph1: gemm %lld fused %lld; p3: red %lld chol+k %lld Ksolve %lld\n", wv, N - 1, \
+#define MFP_PRINT do { if (b == 0 && lane == 0) printf("MFPROF wave %d steps %d: ph1 %lld bar %lld ph2 %lld bar %lld ph3 %lld bar %lld stF %lld bar %lld | ph1: gemm %lld fused %lld; p3: red %lld chol+k %lld Ksolve %lld qp_iter_sum %lld qp_setup %lld qp_solve %lld\n", wv, N - 1, \
     mfp_[0] / (N - 1), mfp_[1] / (N - 1), mfp_[2] / (N - 1), mfp_[3] / (N - 1), mfp_[4] / (N - 1), mfp_[5] / (N - 1), mfp_[6] / (N - 1), mfp_[7] / (N - 1), \
-    mfp_[8] / (N - 1), mfp_[9] / (N - 1), mfp_[12] / (N - 1), mfp_[13] / (N - 1), mfp_[14] / (N - 1)); } while (0)
+    mfp_[8] / (N - 1), mfp_[9] / (N - 1), mfp_[12] / (N - 1), mfp_[13] / (N - 1), mfp_[14] / (N - 1), mfp_[15], mfp_[10] / (N - 1), mfp_[11] / (N - 1)); } while (0)
 #else
 #define MFP_DECL
 #define MFP(k)
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
         for (int q = 0; q < m; ++q) { limlo[q] = a.lims[q]; limhi[q] = a.lims[q + m]; }
     }
     const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};       // boxQP.jl:30-35
+    // the QP runs with one coordinate per lane (boxqp_rows.h): this lane's bounds, and u[:, i] one step ahead of its use (an HBM
+    // round trip on the serial part of every step otherwise)
+    const int qcoord = (l15 < m) ? l15 : 0;
+    double qlo = 0.0, qhi = 0.0, qu_next = 0.0;
+    if (LIMS) {
+        qlo = nolims ? -HUGE_VAL : a.lims[qcoord]; qhi = nolims ? HUGE_VAL : a.lims[qcoord + m];
+        if (N >= 2) qu_next = ug[(size_t)m * (N - 2) + qcoord];
+    }
 
     // ---- terminal step (backward_pass.jl:197-199); Vxx_{N-1} itself is streamed out by the first step below
     for (int e = tid; e < n * n; e += NT) Vs[(e & 63) + LDV * (e >> 6)] = cxx[(CTV ? nn * (N - 1) : 0) + e];
@@ -272,6 +281,11 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
 
         if (wv == 0) {
             // ================= phase 2, wave 0: reduce the partial tiles, gains (backward_pass.jl:30-68) =========
+            // This wave is the serial part of the step: a chain of dependent vector instructions that shares its SIMD with the matrix
+            // phases of the other work-groups of the CU, and a 64-cycle fp64 MFMA of theirs between two of its instructions is what
+            // stretched the 8x8 QP from 4.7 us (alone on a CU, profiles/microbench/boxqp_rows_bench.hip) to ~30 us.  Top priority
+            // lets it issue whenever it can.
+            __builtin_amdgcn_s_setprio(3);
             double x2[m], xr[m];
             {
                 // row `lane` of G[:, u|Vx]: tile lane/16, register (lane%16)/4, tile row lane%4 -> offset 9*lane
@@ -299,37 +313,64 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             wave_sync();
             double H[m * m], R[m * m], kk[m];
             unsigned clamped = 0u;
-#pragma unroll
-            for (int e = 0; e < m * m; ++e) H[e] = Quus[e];
-            if (regType == 2) {
-#pragma unroll
-                for (int e = 0; e < m * m; ++e) H[e] += Radd[e];
-            } else {
-#pragma unroll
-                for (int q = 0; q < m; ++q) H[q + m * q] += lam;
-            }
             MFP(12);
             int fail;
             double ri[m];
-            const bool use_ri = !LIMS || nolims;                     // division-free factor on the unconstrained path
+            constexpr bool use_ri = !LIMS;                           // division-free factor on the unconstrained path; a kernel compiled for
+                                                                     // limits takes the QP also for `lims[1,1] > lims[1,2]` (bounds at ±Inf)
             double qu[m];
 #pragma unroll
             for (int q = 0; q < m; ++q) qu[q] = Qs[n + q];
-            if (use_ri) {
+            if constexpr (use_ri) {
+#pragma unroll
+                for (int e = 0; e < m * m; ++e) H[e] = Quus[e];
+                if (regType == 2) {
+#pragma unroll
+                    for (int e = 0; e < m * m; ++e) H[e] += Radd[e];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < m; ++q) H[q + m * q] += lam;
+                }
                 fail = ddp_chol_rinv<m>(H, R, ri);                   // cholesky(Hermitian(QuuF))  (:35)
 #pragma unroll
                 for (int q = 0; q < m; ++q) kk[q] = qu[q];
                 ddp_rsolve_neg<m>(R, ri, kk);                        // k_i = -(R\Qu)  (:41)
             } else {
-                double g[m], lo[m], up[m], x0[m];
+                // boxQP with one coordinate per lane (boxqp_rows.h): lane l15 < m of every 16-lane row holds row and column l15 of QuuF
+                bqr::Rows<m> qr;
+                const bool qin = l15 < m;
+                const int qi = qcoord;
 #pragma unroll
-                for (int q = 0; q < m; ++q) {
-                    const double uq = ug[(size_t)m * i + q];
-                    g[q] = qu[q]; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; x0[q] = ks[q];
+                for (int j = 0; j < m; ++j) {
+                    double hr = Quus[qi + m * j], hc = Quus[j + m * qi];
+                    if (regType == 2) { hr += Radd[qi + m * j]; hc += Radd[j + m * qi]; }
+                    else if (j == qi) { hr += lam; hc += lam; }
+                    qr.Hrow[j] = qin ? hr : 0.0; qr.Hcol[j] = qin ? hc : 0.0;
                 }
+                const double uq = qu_next;                           // u[qi, i], requested a step ago
+                qu_next = ug[(size_t)m * (i > 0 ? i - 1 : 0) + qi];
+                const double gq = qin ? Qs[n + qi] : 0.0, loq = qin ? qlo - uq : 0.0, upq = qin ? qhi - uq : 0.0;   // (:45-46)
+                const double x0q = qin ? ks[qi] : 0.0;               // warm start k[:, min(i+1, N-1)] (:49)
+                double xq;
                 int iters;
-                const int result = boxqp_dev_ri<m>(m, H, g, lo, up, x0, qpo, kk, R, ri, clamped, iters);
-                fail = (result < 1);
+                MFP(10);
+                const int result = bqr::boxqp_rows<m>(qr, gq, loq, upq, x0q, qpo, l15, xq, clamped, iters);
+                MFP(11);
+                fail = (result < 1);                                 // (:53)
+#ifdef DDP_MFPROF
+                mfp_[15] += iters;                                   // profiling builds: QP iterations
+#endif
+                // every lane solves a column of K with the factor, and needs all of k
+                asm volatile("s_nop 1" : "+v"(xq));
+                bqr::sfor<0, m>([&](auto qc) { constexpr int q = decltype(qc)::value; kk[q] = bqr::bcast<q>(xq); });
+                bqr::sfor<0, m>([&](auto cc) {
+                    constexpr int c2 = decltype(cc)::value;
+                    ri[c2] = qr.ri[c2];
+                    bqr::sfor<0, m>([&](auto kc) {
+                        constexpr int k2 = decltype(kc)::value;
+                        if constexpr (k2 < c2) R[k2 + m * c2] = bqr::bcast<c2>(qr.Rcol[k2]); else R[k2 + m * c2] = 0.0;     // R[k2][c2] lives in lane c2
+                    });
+                });
             }
             MFP(13);
             if (lane == 0) flag[0] = fail ? 1.0 : 0.0;
@@ -387,6 +428,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                     for (int q = 0; q < m; ++q) { Quuks[q] = quuk[q]; ks[q] = kk[q]; kg[(size_t)m * i + q] = kk[q]; }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         } else {
             // ================= phase 2, wave c = 1..3: column tile c of W = Vxx·F for the four row tiles ==========
             d4 acc[4];
