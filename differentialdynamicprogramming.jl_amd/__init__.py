@@ -359,7 +359,7 @@ STATUS = {1: "SUCCESS: gradient norm < tol_grad", 2: "SUCCESS: cost change < tol
 
 def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0,
          λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0, verbosity=0, trace_cap=None, cost=None,
-         handle=None):
+         timing=True, handle=None):
     """Drop-in for ``iLQG(f,costfun,df,x0,u0; lims, α, tol_fun, ...)`` (iLQG.jl:143-163) with a registered
     ``problem`` standing in for the three closures.  ``u0[m,N,B]`` / ``x0[n,B]`` solve a batch of
     independent problems, each with its own λ schedule, line search and termination.
@@ -367,6 +367,7 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     keys that survive batching (``:cost`` per iteration) plus the per-trajectory summary ``stats``.
     ``x0[n,N]`` (``x0[n,N,B]`` with a batch) is a PRE-ROLLED initial trajectory (iLQG.jl:193-197: no initial rollout;
     ``cost`` as given or ``costfun(x0,u0)``) — the warm start of an MPC loop.
+    ``timing=False`` drops the ``time_*`` trace keys: the driver then synchronises with the host every fourth batch iteration only.
     Returns ``None`` when the initial control sequence diverges (iLQG.jl:205-210) in the unbatched case."""
     h = handle or default_handle()
     u0, x0 = _lib.f64(u0), _lib.f64(x0)
@@ -411,9 +412,10 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     cost = np.zeros((CL, B), order="F")
     tr7 = np.zeros((7, cap, B), order="F")
     tcap = 4 * max_iter + 1000                                 # the driver's bound on global iterations
+    timing_on = bool(timing)
     timing = np.full((3, tcap), np.nan)
     t_start = _time.time()
-    _lib.check(_lib.lib().ddp_ilqg_set_timing(h.raw, _lib.ptr(timing), tcap))
+    _lib.check(_lib.lib().ddp_ilqg_set_timing(h.raw, _lib.ptr(timing) if timing_on else None, tcap if timing_on else 0))
     try:
         _lib.check(_lib.lib().ddp_ilqg_ex_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x0), int(prerolled), _lib.ptr(u0),
                                               _lib.ptr(c0), _lib.ptr(L), *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), cap,

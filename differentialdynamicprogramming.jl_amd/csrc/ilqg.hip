@@ -471,6 +471,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     int32_t *more2 = more + B;
 
     int git = 0;
+    constexpr int POLL = 4;
     const long hard_cap = 4L * oo->max_iter + 1000;      // every global iteration advances iter or λ of each running trajectory
     // ddp_ilqg_set_timing: the time_derivs / time_backward / time_forward keys of the reference's trace (iLQG.jl:227,241,281)
     // per global iteration, from HIP events on the stream (the loop synchronises once per iteration anyway)
@@ -482,8 +483,9 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     auto launch_stats = [&](int only_finished) {
         hipLaunchKernelGGL(stats_kernel, dim3((unsigned)((Bw + 255) / 256)), dim3(256), 0, st, (int)Bw, ws.s, ws.map, only_finished, stats);
     };
+    bool polled = true;
     while (running > 0 && git < hard_cap) {
-        if (may_compact && (size_t)running * 2 <= Bw && Bw >= min_slots) {
+        if (polled && may_compact && (size_t)running * 2 <= Bw && Bw >= min_slots) {      // `running` is exact right after a poll only
             // ---- drop the finished slots: their summary and (from a compacted set) their results go to the caller's arrays first
             launch_stats(1);
             if (ws.map) hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, 0, ws, user);
@@ -512,6 +514,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
             Bw = R;
             pw.B = (int)R; d.B = (int)R;
         }
+        polled = false;
         if (timed) DDP_HIP(hipEventRecord(h->tev[0], st));
         rc = ddp_df_f64_dev(h, &pw, ws.x, ws.u, ws.s.dodf, cx, cu, fxw, fuw);                                  // STEP 1
         if (rc) return rc;
@@ -538,20 +541,31 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
             if (rc) return rc;
         }
         if (timed) DDP_HIP(hipEventRecord(h->tev[3], st));
-        DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
+        // The host looks at the number of running trajectories every POLL iterations only (every iteration while the per-iteration
+        // timing keys are recorded): a synchronisation per iteration leaves the GPU idle for a round trip, and iterations launched
+        // after the last trajectory has stopped find nothing to do (every wave leaves at once).  Each iteration of a group writes
+        // its own count, so `global_iters` stays exact.
+        const int slot = git % POLL;
+        DDP_HIP(hipMemsetAsync(counter + slot, 0, 4, st));
         hipLaunchKernelGGL(accept_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)Bw, (int)CL, o, dV, xn,
-                           un, cn, cs, ws.s, ws.x, ws.u, ws.cost, ws.k, trace_cap, trace_cost, trace7, ws.map, counter);    // STEP 4
-        DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
-        DDP_HIP(hipStreamSynchronize(st));
-        running = h->h_pinned[0];
-        if (timed && git < h->timing_cap) {
-            for (int e = 0; e < 3; ++e) {
-                float ms = 0.0f;
-                DDP_HIP(hipEventElapsedTime(&ms, h->tev[e], h->tev[e + 1]));
-                h->timing[(size_t)h->timing_cap * e + git] = 1e-3 * (double)ms;
+                           un, cn, cs, ws.s, ws.x, ws.u, ws.cost, ws.k, trace_cap, trace_cost, trace7, ws.map, counter + slot);    // STEP 4
+        ++git;
+        if (timed || slot == POLL - 1 || git >= hard_cap) {
+            const int cnt = slot + 1;
+            DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4 * cnt, hipMemcpyDeviceToHost, st));
+            DDP_HIP(hipStreamSynchronize(st));
+            running = h->h_pinned[cnt - 1];
+            polled = true;
+            for (int e2 = 0; e2 < cnt; ++e2)
+                if (h->h_pinned[e2] == 0) { git -= cnt - 1 - e2; running = 0; break; }     // the iterations after it did nothing
+            if (timed && git - 1 < h->timing_cap) {
+                for (int e = 0; e < 3; ++e) {
+                    float ms = 0.0f;
+                    DDP_HIP(hipEventElapsedTime(&ms, h->tev[e], h->tev[e + 1]));
+                    h->timing[(size_t)h->timing_cap * e + (git - 1)] = 1e-3 * (double)ms;
+                }
             }
         }
-        ++git;
     }
     launch_stats(0);                                       // trajectories still running here: DDP_EXIT_CAP (the driver's own bound)
     if (ws.map) hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, 1, ws, user);

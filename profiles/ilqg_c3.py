@@ -19,3 +19,9 @@ for it in range(2):
     parts = {k: float(np.nansum(tr[k])) for k in ("time_derivs", "time_backward", "time_forward")}
     print("   GPU phases (HIP events, s): derivs %.3f  back %.3f  forward(+cost, %d alphas) %.3f  | other (host, H2D/D2H, state machine) %.3f"
           % (parts["time_derivs"], parts["time_backward"], len(kw["α"]), parts["time_forward"], tr["time_total"] - sum(parts.values())))
+for it in range(2):
+    t = time.perf_counter()
+    r = ddp_amd.iLQG(ddp_amd.PendcartProblem(), x0, u0, lims=5.0 * np.array([[-1.0, 1.0]]), timing=False, **kw)
+    dt = time.perf_counter() - t
+    print("C3 iLQG pendcart B=%d without the time_* keys (host poll every 4th batch iteration): %.3f s, %.3f s inside the C call, %d batch iterations"
+          % (B, dt, r[6]["time_total"], r[6]["global_iters"]))

@@ -354,14 +354,17 @@ def test_ilqg_compaction_and_line_search_groups_change_nothing(ddp, monkeypatch,
         u0 = 0.1 * rng.standard_normal((2, T, B)) * (1 + 3 * np.arange(B))[None, None, :]
         kw = dict(tol_fun=10.0 ** rng.uniform(-9, -3))                      # spread of iteration counts comes from u0
     runs = {}
-    for tag, compact, groups in (("plain", "0", "0"), ("compact", "4", "0"), ("groups", "0", "1"), ("both", "4", "1")):     # forced on
+    for tag, compact, groups in (("plain", "0", "0"), ("compact", "4", "0"), ("groups", "0", "1"), ("both", "4", "1"),     # forced on
+                                 ("sparse_poll", "0", "0"), ("sparse_poll_compact", "4", "0")):
         monkeypatch.setenv("DDP_ILQG_COMPACT", compact); monkeypatch.setenv("DDP_ILQG_LSGROUPS", groups)
-        runs[tag] = ddp.iLQG(prob, x0, u0, **kw)
+        # without the time_* keys the driver looks at the running count every 4th batch iteration only
+        runs[tag] = ddp.iLQG(prob, x0, u0, timing=not tag.startswith("sparse_poll"), **kw)
     ref = runs["plain"]
     its = ref[6]["stats"][1]
     assert its.max() >= 2 * np.median(its) or family == "lq"               # stragglers: compaction really happens
-    for tag in ("compact", "groups", "both"):
+    for tag in ("compact", "groups", "both", "sparse_poll", "sparse_poll_compact"):
         r = runs[tag]
+        assert r[6]["global_iters"] == ref[6]["global_iters"], tag
         assert np.array_equal(r[6]["stats"][:5], ref[6]["stats"][:5]), tag  # status, iter, accepted_iter, n_backpass, n_forward
         for a, b_ in zip(r[:2] + (r[2].K, r[2].k, r[2].Σi) + r[3:6], ref[:2] + (ref[2].K, ref[2].k, ref[2].Σi) + ref[3:6]):
             assert np.array_equal(a, b_), tag
