@@ -27,6 +27,7 @@ EXPORTS = [
     "ddp_ilqg_default_opts", "ddp_ilqg_f64", "ddp_ilqg_f64_dev", "ddp_ilqg_warm_f64", "ddp_ilqg_warm_f64_dev", "ddp_ilqg_ex_f64", "ddp_ilqg_ex_f64_dev", "ddp_ilqg_set_timing", "ddp_mpc_shift_f64_dev", "ddp_costfun_f64_dev", "ddp_batch_stats_f64_dev",
     "ddp_kl_terms_f64_dev", "ddp_kl_terms_f64", "ddp_back_pass_gps_f64_dev", "ddp_back_pass_gps_f64",
     "ddp_forward_covariance_f64_dev", "ddp_forward_covariance_f64", "ddp_kl_div_f64_dev", "ddp_kl_div_f64",
+    "ddp_kl_dual_begin_f64_dev", "ddp_kl_dual_retry_f64_dev", "ddp_kl_dual_update_f64_dev",
     "ddp_comm_unique_id", "ddp_comm_create", "ddp_comm_destroy", "ddp_allreduce_stats_f64_dev",
 ]
 
@@ -38,6 +39,10 @@ class BPDesc(C.Structure):
 
 class KLCostTerms(C.Structure):
     _fields_ = [("cx", vp), ("cu", vp), ("cxx", vp), ("cxu", vp), ("cuu", vp), ("eta", vp), ("eta_tv", C.c_int)]
+
+
+class KLDual(C.Structure):
+    _fields_ = [(k, vp) for k in ("etab", "eta", "del_", "divergence", "satisfied", "status", "live", "pend", "iters", "nback")]
 
 
 class QPOpts(C.Structure):

@@ -203,6 +203,60 @@ __global__ __launch_bounds__(DDP_WAVE) void kl_div_kernel(int n, int m, int N, c
     if (lane == 0) klmean[b] = threw ? INFINITY : acc / N;
 }
 
+// ---- the dual variable of the KL constraint, one thread per trajectory (calc_η klutils.jl:112-133, the bracket/exit logic of
+// iLQGkl.jl:91-178).  op 0: start of an iteration, 1: after a back pass, 2: after the divergence of the new trajectory is known.
+__global__ void kl_dual_kernel(int op, int B, int it, double kl_step, ddp_kl_dual s, const int32_t *__restrict__ diverge,
+                               const double *__restrict__ klmean, int32_t *__restrict__ count)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int one = 0;
+    if (b < B) {
+        double *e = s.etab + 3 * (long)b;
+        if (op == 0) {                                                        // iLQGkl.jl:91-95
+            const int lv = s.live[b];
+            s.pend[b] = lv;
+            if (lv) { s.iters[b] = it; s.eta[b] = e[1]; }
+            one = lv;
+        } else if (op == 1) {                                                 // :100-122
+            if (s.pend[b]) {
+                s.nback[b] += 1;
+                if (diverge[b] > 0) {                                         // :103-105  η += del; del *= 2; back pass again
+                    e[1] += s.del[b];
+                    s.del[b] *= 2.0;
+                    s.eta[b] = e[1];
+                    one = 1;
+                } else s.pend[b] = 0;
+            }
+        } else if (s.live[b]) {                                               // :141 calc_η, :169-177
+            bool sat = true;
+            double dv = 0.0;
+            if (kl_step > 0) {                                                // klutils.jl:113
+                dv = klmean[b];
+                const double viol = dv - kl_step;                             // :116
+                sat = fabs(viol) < 0.1 * kl_step;                             // :118
+                if (!sat) {
+                    if (viol < 0) {                                           // :121-124  η was too big
+                        e[2] = e[1];
+                        const double g = sqrt(e[0] * e[2]), o = 0.1 * e[2];
+                        e[1] = (o > g) ? o : g;
+                    } else {                                                  // :126-129  η was too small (also a NaN divergence)
+                        e[0] = e[1];
+                        const double g = sqrt(e[0] * e[2]), o = 10.0 * e[0];
+                        e[1] = (o < g) ? o : g;
+                    }
+                }
+            }
+            s.divergence[b] = dv;
+            s.satisfied[b] = sat;
+            if (sat) { s.status[b] = 1; s.live[b] = 0; }                      // iLQGkl.jl:169
+            else if (e[1] > 0.999 * e[2]) { s.status[b] = 2; s.live[b] = 0; } // :174  (the back pass of this η never happens)
+            one = s.live[b];
+        }
+    }
+    const unsigned long long bal = __ballot(one);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+}
+
 size_t fcov_lds(int n, int m) { return ((size_t)3 * n * n + 2 * (size_t)n * m) * sizeof(double); }
 
 }   // namespace
@@ -263,6 +317,43 @@ int ddp_kl_div_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *x
                        kldiv, klmean);
     DDP_HIP(hipGetLastError());
     return 0;
+}
+
+static int kl_dual_launch(ddp_handle h, int op, int B, int it, double kl_step, const ddp_kl_dual *s, const int32_t *diverge,
+                          const double *klmean, int *count)
+{
+    DDP_DEVICE(h);
+    DDP_CHECK(s && count && B >= 1, "kl_dual: null argument");
+    DDP_CHECK(s->etab && s->eta && s->del && s->divergence && s->satisfied && s->status && s->live && s->pend && s->iters && s->nback,
+              "kl_dual: null state array");
+    void *cnt = nullptr;
+    int rc = ddp_scratch(h, 256, &cnt);
+    if (rc) return rc;
+    DDP_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(kl_dual_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, op, B, it, kl_step, *s, diverge, klmean,
+                       (int32_t *)cnt);
+    DDP_HIP(hipGetLastError());
+    DDP_HIP(hipMemcpyAsync(h->h_pinned, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    *count = h->h_pinned[0];
+    return 0;
+}
+
+int ddp_kl_dual_begin_f64_dev(ddp_handle h, int B, int it, const ddp_kl_dual *s, int *n_live)
+{
+    return kl_dual_launch(h, 0, B, it, 0.0, s, nullptr, nullptr, n_live);
+}
+
+int ddp_kl_dual_retry_f64_dev(ddp_handle h, int B, const ddp_kl_dual *s, const int32_t *diverge, int *n_pending)
+{
+    DDP_CHECK(diverge, "kl_dual_retry: null argument");
+    return kl_dual_launch(h, 1, B, 0, 0.0, s, diverge, nullptr, n_pending);
+}
+
+int ddp_kl_dual_update_f64_dev(ddp_handle h, int B, double kl_step, const ddp_kl_dual *s, const double *klmean, int *n_live)
+{
+    DDP_CHECK(klmean, "kl_dual_update: null argument");
+    return kl_dual_launch(h, 2, B, 0, kl_step, s, nullptr, klmean, n_live);
 }
 
 // ---- host-pointer flavours (stage through the handle's scratch; PCIe-inclusive, for drop-in use with host arrays)

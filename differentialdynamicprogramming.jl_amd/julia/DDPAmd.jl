@@ -90,6 +90,20 @@ struct KLCostTerms
     eta_tv::Cint
 end
 
+# ddp_kl_dual (include/ddp_amd.h): device pointers
+struct KLDual
+    etab::Ptr{Float64}
+    eta::Ptr{Float64}
+    del::Ptr{Float64}
+    divergence::Ptr{Float64}
+    satisfied::Ptr{Int32}
+    status::Ptr{Int32}
+    live::Ptr{Int32}
+    pend::Ptr{Int32}
+    iters::Ptr{Int32}
+    nback::Ptr{Int32}
+end
+
 const NULLF = Ptr{Float64}(C_NULL)
 const NULLI = Ptr{Int32}(C_NULL)
 
@@ -577,7 +591,54 @@ function kl_div_wiki(xnew, xold, Σ_new, traj_new, traj_prev; handle::Handle=def
     end
     return isinf(mean_[1]) && all(isfinite, kld) ? Inf : kld
 end
-# calc_η, geom and the iLQGkl loop stay the reference's scalar Julia code (klutils.jl:112-155, iLQGkl.jl): with the four
-# functions above rebound, src/iLQGkl.jl:90,100,133 and klutils.jl:114 run on the GPU unchanged.
+# For ONE trajectory calc_η, geom and the iLQGkl loop stay the reference's scalar Julia code (klutils.jl:112-155, iLQGkl.jl): with
+# the four functions above rebound, src/iLQGkl.jl:90,100,133 and klutils.jl:114 run on the GPU unchanged.  A BATCH of
+# KL-constrained solves keeps the dual variable of every trajectory on the device:
+
+"""
+    KLDualState(ηbracket::Matrix (3×B), del0; handle) — the per-trajectory dual state of a batch (device arrays)
+    kl_dual_begin!(s, it) -> n_live;  kl_dual_retry!(s, diverge::DevArray{Int32}) -> n_pending;
+    kl_dual_update!(s, kl_step, klmean::DevArray) -> n_live        (calc_η klutils.jl:112-133, iLQGkl.jl:91-122,169-177)
+`s.eta` is the array `KLCostTerms.eta` points at for `ddp_back_pass_gps_f64_dev`.
+"""
+struct KLDualState
+    etab::DevArray{Float64}
+    eta::DevArray{Float64}
+    del::DevArray{Float64}
+    divergence::DevArray{Float64}
+    satisfied::DevArray{Int32}
+    status::DevArray{Int32}
+    live::DevArray{Int32}
+    pend::DevArray{Int32}
+    iters::DevArray{Int32}
+    nback::DevArray{Int32}
+    handle::Handle
+end
+function KLDualState(ηbracket::AbstractMatrix, del0::Real; handle::Handle=default_handle())
+    B = size(ηbracket, 2)
+    size(ηbracket, 1) == 3 || throw(ArgumentError("ηbracket must be 3×B"))
+    zi() = DevArray(zeros(Int32, B); handle=handle)
+    KLDualState(DevArray(_f64(ηbracket); handle=handle), DevArray(_f64(ηbracket[2, :]); handle=handle), DevArray(fill(Float64(del0), B); handle=handle),
+                DevArray(zeros(B); handle=handle), zi(), zi(), DevArray(ones(Int32, B); handle=handle), zi(), zi(), zi(), handle)
+end
+_kldual(s::KLDualState) = KLDual(s.etab.ptr, s.eta.ptr, s.del.ptr, s.divergence.ptr, s.satisfied.ptr, s.status.ptr, s.live.ptr, s.pend.ptr,
+                                 s.iters.ptr, s.nback.ptr)
+function kl_dual_begin!(s::KLDualState, it::Integer)
+    c = Ref{Cint}(0); B = prod(s.eta.dims)
+    GC.@preserve s check(@ccall libddp.ddp_kl_dual_begin_f64_dev(s.handle.ptr::Ptr{Cvoid}, B::Cint, it::Cint, Ref(_kldual(s))::Ptr{KLDual}, c::Ptr{Cint})::Cint)
+    return Int(c[])
+end
+function kl_dual_retry!(s::KLDualState, diverge::DevArray{Int32})
+    c = Ref{Cint}(0); B = prod(s.eta.dims)
+    GC.@preserve s diverge check(@ccall libddp.ddp_kl_dual_retry_f64_dev(s.handle.ptr::Ptr{Cvoid}, B::Cint, Ref(_kldual(s))::Ptr{KLDual},
+                                                                          diverge.ptr::Ptr{Int32}, c::Ptr{Cint})::Cint)
+    return Int(c[])
+end
+function kl_dual_update!(s::KLDualState, kl_step::Real, klmean::DevArray{Float64})
+    c = Ref{Cint}(0); B = prod(s.eta.dims)
+    GC.@preserve s klmean check(@ccall libddp.ddp_kl_dual_update_f64_dev(s.handle.ptr::Ptr{Cvoid}, B::Cint, kl_step::Cdouble, Ref(_kldual(s))::Ptr{KLDual},
+                                                                          klmean.ptr::Ptr{Float64}, c::Ptr{Cint})::Cint)
+    return Int(c[])
+end
 
 end # module

@@ -283,8 +283,8 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
 
 def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u, derivs, kl, dynb, etab, del0, status, iters, nback,
                         divergence, satisfied, live):
-    """The iteration of iLQGkl (iLQGkl.jl:91-178) with every array resident on the device: per iteration only η[B] goes up and
-    diverge[B], mean KL[B] come down.  Each pass recomputes ALL trajectories with their current η — a trajectory that has
+    """The iteration of iLQGkl (iLQGkl.jl:91-178) with every array resident on the device, the dual variable η and its bracket
+    included (ddp_kl_dual_*): per iteration only the counts of live / still-diverging trajectories come down.  Each pass recomputes ALL trajectories with their current η — a trajectory that has
     already met its constraint keeps its η, so it is recomputed to the same result and the final arrays are right for everyone
     (the host-array loop, DDP_KL_HOSTLOOP=1, gathers the live ones instead and moved ~1.5 GB over PCIe per pass at B = 4096)."""
     L_ = _lib.lib()
@@ -295,6 +295,11 @@ def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u,
 
     def up(a):
         p_ = h.to_device(_lib.f64(a)); bufs.append(p_); return p_
+
+    def up_i(a):
+        p_ = h.malloc(a.nbytes); bufs.append(p_)
+        _lib.check(L_.ddp_memcpy_h2d(h.raw, p_, _lib.ptr(a), _C.c_size_t(a.nbytes)))
+        return p_
 
     def dev(shape, dtype=np.float64):
         p_ = h.malloc(int(np.prod(shape)) * np.dtype(dtype).itemsize); bufs.append(p_); return p_
@@ -329,30 +334,28 @@ def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u,
         desc = _lib.BPDesc(n, m, N, B, 1, int(fx.ndim == 4), 1, int(cxx.ndim == 4), 1, int(Lh is not None))
         terms = _lib.KLCostTerms(*d_kl, d_eta, 0)
         one = np.array([1.0])
-        # η each trajectory was last computed with.  calc_η moves ηbracket[2, b] BEFORE the `η > 0.999 ηmax` exit test (iLQGkl.jl:141,174):
-        # a trajectory that leaves that way must keep the results of the η it was computed with (the reference breaks right there), so
-        # only live trajectories take a new η; the finished ones are recomputed to the same result by every later pass.
-        eta_h = etab[1].copy()
+        # the dual variable lives on the device (ddp_kl_dual_*, csrc/kl.hip): per iteration only three counts cross PCIe.
+        # calc_η moves ηbracket[2, b] BEFORE the `η > 0.999 ηmax` exit test (iLQGkl.jl:141,174): a trajectory that leaves that way
+        # keeps the results of the η it was computed with (the reference breaks right there), so `eta` is only rewritten for
+        # live trajectories; the finished ones are recomputed to the same result by every later pass.
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)                                                 # noqa: E731
+        d_etab, d_del, d_dvg = up(etab), up(del0), up(divergence)
+        d_sat, d_stat, d_live, d_pend = up_i(i32(satisfied)), up_i(i32(status)), up_i(i32(live)), dev((B,), np.int32)
+        d_it, d_nb = up_i(i32(iters)), up_i(i32(nback))
+        _lib.check(L_.ddp_memcpy_h2d(h.raw, d_eta, _lib.ptr(np.ascontiguousarray(etab[1])), _C.c_size_t(8 * B)))
+        dual = _lib.KLDual(d_etab, d_eta, d_del, d_dvg, d_sat, d_stat, d_live, d_pend, d_it, d_nb)
+        cnt = _C.c_int(0)
         for it in range(1, max_iter + 1):                                                                       # :91
-            idx = np.flatnonzero(live)
-            if idx.size == 0:
+            _lib.check(L_.ddp_kl_dual_begin_f64_dev(h.raw, B, it, _C.byref(dual), _C.byref(cnt)))
+            if cnt.value == 0:
                 break
-            iters[idx] = it
-            pend = live.copy()
             guard = 0
             while True:                                        # back passes until the regularised Quu is positive definite (:95-122)
-                eta_h[pend] = etab[1, pend]
-                _lib.check(L_.ddp_memcpy_h2d(h.raw, d_eta, _lib.ptr(eta_h), _C.c_size_t(eta_h.nbytes)))
                 _lib.check(L_.ddp_back_pass_gps_f64_dev(h.raw, _C.byref(desc), d_cx, d_cu, d_cxx, d_cxu, d_cuu, d_fx, d_fu, _C.byref(terms),
                                                         d_L, d_u, None, d_K, d_k, d_Quu, d_Quui, d_Vx, d_Vxx, d_dV, d_div))
-                div = h.to_host(d_div, (B,), np.int32)
-                nback[pend] += 1
-                bad = pend & (div > 0)
-                if not bad.any():
+                _lib.check(L_.ddp_kl_dual_retry_f64_dev(h.raw, B, _C.byref(dual), d_div, _C.byref(cnt)))        # :103-105
+                if cnt.value == 0:
                     break
-                etab[1, bad] += del0[bad]                                                                        # :103-105
-                del0[bad] *= 2
-                pend = bad
                 guard += 1
                 if guard > 200:
                     raise RuntimeError("back_pass_gps keeps diverging (the reference would loop forever)")
@@ -360,15 +363,14 @@ def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u,
                                                    d_xn, d_un, d_cn, d_cs))                                     # :132
             _lib.check(L_.ddp_forward_covariance_f64_dev(h.raw, n, m, N, B, d_mfx, int(mfx.ndim == 4), d_R1, d_K, d_Quui, d_sig))   # :133
             _lib.check(L_.ddp_kl_div_f64_dev(h.raw, n, m, N, B, d_xn, d_x, d_sig, d_K, d_k, d_Quui, d_pK, d_pk, d_pS, d_pSi, d_kld, d_klm))
-            mean = h.to_host(d_klm, (B,))
-            for b in idx:                                                                                       # :141, :169-177
-                eb, sat, dv = calc_η(None, None, None, etab[:, b], None, None, kl_step, _mean=mean[b])
-                etab[:, b] = eb
-                divergence[b], satisfied[b] = dv, sat
-                if sat:
-                    status[b], live[b] = 1, False
-                elif etab[1, b] > 0.999 * etab[2, b]:
-                    status[b], live[b] = 2, False
+            _lib.check(L_.ddp_kl_dual_update_f64_dev(h.raw, B, _C.c_double(kl_step), _C.byref(dual), d_klm, _C.byref(cnt)))   # :141, :169-177
+        etab[...] = h.to_host(d_etab, (3, B))
+        divergence[...] = h.to_host(d_dvg, (B,))
+        satisfied[...] = h.to_host(d_sat, (B,), np.int32) != 0
+        status[...] = h.to_host(d_stat, (B,), np.int32)
+        live[...] = h.to_host(d_live, (B,), np.int32) != 0
+        iters[...] = h.to_host(d_it, (B,), np.int32)
+        nback[...] = h.to_host(d_nb, (B,), np.int32)
         return dict(x=h.to_host(d_xn, (n, N, B)), u=h.to_host(d_un, (m, N, B)), cost=h.to_host(d_cn, (CL, B)), K=h.to_host(d_K, (m, n, N, B)),
                     S=h.to_host(d_Quui, (m, m, N, B)), Si=h.to_host(d_Quu, (m, m, N, B)), Vx=h.to_host(d_Vx, (n, N, B)),
                     Vxx=h.to_host(d_Vxx, (n, n, N, B)), dV=h.to_host(d_dV, (2, B)))

@@ -267,9 +267,9 @@ int ddp_costfun_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, con
 
 /* ---- KL-constrained path (BASELINE config 5) ------------------------------------------------------
  * reference: back_pass_gps src/backward_pass.jl:259-350 (called from src/iLQGkl.jl:100,191), ∇kl and kl_div_wiki
- * src/klutils.jl:8-23,70-103, forward_covariance src/forward_pass.jl:37-56.  calc_η and the iLQGkl loop are scalar
- * host logic (host mirror / Julia wrapper).  `df(model,·)` / `covariance(model,·)` belong to the un-vendored dependency
- * LinearTimeVaryingModelsBase: the model is passed as the arrays it would return (fx, R1).                     */
+ * src/klutils.jl:8-23,70-103, forward_covariance src/forward_pass.jl:37-56, calc_η src/klutils.jl:112-133 (ddp_kl_dual_*).
+ * `df(model,·)` / `covariance(model,·)` belong to the un-vendored dependency LinearTimeVaryingModelsBase: the model is
+ * passed as the arrays it would return (fx, R1).                                                                 */
 typedef struct {
     const double *cx, *cu;       /* cxkl[n,N,B], cukl[m,N,B]                                                     */
     const double *cxx, *cxu;     /* cxxkl[n,n,N,B], cxukl[m,n,N,B]  (m x n, the layout ∇kl returns, klutils.jl:20) */
@@ -317,6 +317,29 @@ int ddp_kl_div_f64(ddp_handle h, int n, int m, int N, int B, const double *xnew,
                    const double *sigmanew, const double *Kn, const double *kn, const double *Sn,
                    const double *Kp, const double *kp, const double *Sp, const double *Sip,
                    double *kldiv, double *klmean);
+
+/* The dual variable η of the KL constraint, per trajectory, on the device: calc_η (src/klutils.jl:112-133, scalar kl_step) and the
+ * bracket / retry / exit logic of the iLQGkl loop (src/iLQGkl.jl:91-122,141,169-177).  All arrays are device pointers owned by
+ * the caller; `eta` is what ddp_kl_cost_terms.eta points at.  A host loop is
+ *     begin(it) -> n_live;  do { back_pass_gps;  retry(diverge) -> n_pending } while (n_pending);
+ *     forward_pass; forward_covariance; kl_div;  update(klmean) -> n_live
+ * and only those counts cross PCIe.  A trajectory that has left (status 1/2) keeps its `eta`, so recomputing it with the
+ * others reproduces its results.                                                                                      */
+typedef struct {
+    double  *etab;        /* [3,B]  ηbracket of every trajectory (in/out)                                              */
+    double  *eta;         /* [B]    η of the next / last back pass                                                     */
+    double  *del;         /* [B]    del (iLQGkl.jl:54,103-105), initialised to del0                                    */
+    double  *divergence;  /* [B]    mean KL divergence at the last update                                              */
+    int32_t *satisfied;   /* [B]                                                                                       */
+    int32_t *status;      /* [B]    0 running, 1 constraint satisfied (:169), 2 η > 0.999 ηmax (:174)                  */
+    int32_t *live;        /* [B]    1 while the trajectory iterates (initialise to 1)                                  */
+    int32_t *pend;        /* [B]    scratch: still needs a back pass in this iteration                                 */
+    int32_t *iters;       /* [B]    last iteration the trajectory took part in                                         */
+    int32_t *nback;       /* [B]    back passes spent                                                                  */
+} ddp_kl_dual;
+int ddp_kl_dual_begin_f64_dev(ddp_handle h, int B, int it, const ddp_kl_dual *s, int *n_live);
+int ddp_kl_dual_retry_f64_dev(ddp_handle h, int B, const ddp_kl_dual *s, const int32_t *diverge, int *n_pending);
+int ddp_kl_dual_update_f64_dev(ddp_handle h, int B, double kl_step, const ddp_kl_dual *s, const double *klmean, int *n_live);
 
 #ifdef __cplusplus
 }

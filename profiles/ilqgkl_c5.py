@@ -1,12 +1,12 @@
-"""C5 (= C3 + KL constraint): a batch of KL-constrained pendcart solves through the host mirror (kl.iLQGkl): every device call of
-the loop goes through the host-pointer entry points, so this line includes the H2D/D2H traffic of each call (the KL path is
-correct but not tuned)."""
+"""C5 (= C3 + KL constraint): a batch of KL-constrained pendcart solves through the host mirror (kl.iLQGkl): the iteration runs on
+device-resident arrays with the dual variable η updated on the device (ddp_kl_dual_*); the time includes the upload of the
+derivative arrays and the download of the results."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddp_amd
 import ddp_amd.kl as kl
-B, N = int(os.environ.get("C5_B", 512)), 600
+B, N = int(os.environ.get("C5_B", 4096)), 600
 rng = np.random.default_rng(0)
 prob = ddp_amd.PendcartProblem()
 lims = 5.0 * np.array([[-1.0, 1.0]])

@@ -205,3 +205,63 @@ def test_demo_linear_kl_smoke(ddp):
     x, u, traj, Vx, Vxx, cost, tr = ddp.kl.demo_linear_kl(kl_step=0.01, rng=np.random.default_rng(3), T=80, outer=4, max_iter=20)
     oc_ = tr["outercosts"]
     assert np.isfinite(oc_).all() and np.all(np.diff(oc_) < 0) and abs(float(tr["divergence"]) - 0.01) < 0.1 * 0.01 + 1e-12
+
+
+def test_kl_dual_kernels_match_calc_eta(ddp):
+    """ddp_kl_dual_begin / retry / update (csrc/kl.hip) against calc_η and the loop bookkeeping of the host mirror (klutils.jl:112-133,
+    iLQGkl.jl:91-122,169-177), bit for bit, on random brackets and divergences incl. NaN / Inf and kl_step <= 0"""
+    import ctypes as C
+    _lib = ddp._lib
+    kl = ddp.kl
+    h = ddp.default_handle()
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    B = 777
+    for kl_step in (0.5, 0.0):
+        lo = 10.0 ** rng.uniform(-8, -2, B); hi = lo * 10.0 ** rng.uniform(0.001, 12, B)
+        etab = np.asfortranarray(np.stack([lo, np.sqrt(lo * hi), hi]))
+        etab[1, ::7] = 0.9995 * etab[2, ::7]                               # some sit right at the bracket exit
+        del0 = 10.0 ** rng.uniform(-5, -1, B)
+        mean = kl_step + rng.standard_normal(B) * np.where(rng.random(B) < 0.4, 0.03, 1.0)
+        mean[5], mean[6], mean[7] = np.nan, np.inf, 0.0
+        live = (rng.random(B) < 0.8).astype(np.int32)
+        div = (rng.random(B) < 0.3).astype(np.int32)
+        i32z = lambda: np.zeros(B, dtype=np.int32)                        # noqa: E731
+        host = dict(etab=etab.copy(order="F"), eta=np.full(B, -1.0), del_=del0.copy(), divergence=np.zeros(B), satisfied=i32z(), status=i32z(),
+                    live=live.copy(), pend=i32z(), iters=i32z(), nback=i32z())
+        devp = {k_: h.to_device(v) if v.dtype == np.float64 else None for k_, v in host.items()}
+        for k_, v in host.items():
+            if devp[k_] is None:
+                devp[k_] = h.malloc(v.nbytes)
+                _lib.check(L.ddp_memcpy_h2d(h.raw, devp[k_], _lib.ptr(v), C.c_size_t(v.nbytes)))
+        dual = _lib.KLDual(*[devp[k_] for k_ in ("etab", "eta", "del_", "divergence", "satisfied", "status", "live", "pend", "iters", "nback")])
+        d_div, d_mean = h.malloc(4 * B), h.to_device(mean)
+        _lib.check(L.ddp_memcpy_h2d(h.raw, d_div, _lib.ptr(div), C.c_size_t(4 * B)))
+        cnt = C.c_int(-1)
+        # --- begin
+        _lib.check(L.ddp_kl_dual_begin_f64_dev(h.raw, B, 9, C.byref(dual), C.byref(cnt)))
+        assert cnt.value == live.sum()
+        host["pend"] = live.copy(); host["iters"][live == 1] = 9; host["eta"][live == 1] = host["etab"][1, live == 1]
+        # --- retry
+        _lib.check(L.ddp_kl_dual_retry_f64_dev(h.raw, B, C.byref(dual), d_div, C.byref(cnt)))
+        bad = (host["pend"] == 1) & (div > 0)
+        assert cnt.value == bad.sum()
+        host["nback"][host["pend"] == 1] += 1
+        host["etab"][1, bad] += host["del_"][bad]; host["del_"][bad] *= 2; host["eta"][bad] = host["etab"][1, bad]
+        host["pend"] = bad.astype(np.int32)
+        # --- update
+        _lib.check(L.ddp_kl_dual_update_f64_dev(h.raw, B, C.c_double(kl_step), C.byref(dual), d_mean, C.byref(cnt)))
+        for b in np.flatnonzero(live):
+            eb, sat, dv = kl.calc_η(None, None, None, host["etab"][:, b], None, None, kl_step, _mean=mean[b])
+            host["divergence"][b], host["satisfied"][b] = dv, int(sat)
+            if sat:
+                host["status"][b], host["live"][b] = 1, 0
+            elif host["etab"][1, b] > 0.999 * host["etab"][2, b]:
+                host["status"][b], host["live"][b] = 2, 0
+        assert cnt.value == host["live"].sum()
+        for k_, v in host.items():
+            got = h.to_host(devp[k_], v.shape, v.dtype)
+            assert np.array_equal(got, v, equal_nan=(v.dtype == np.float64)), (k_, kl_step)
+        assert {0, 1, 2} <= set(host["status"]) or kl_step == 0.0
+        for p_ in list(devp.values()) + [d_div, d_mean]:
+            h.free(p_)

@@ -22,11 +22,13 @@ CTYPES = {
     "int": {"Cint", "Int32"}, "size_t": {"Csize_t", "UInt"}, "double": {"Cdouble", "Float64"},
     "const ddp_bp_desc *": {"Ptr{BPDesc}"}, "const ddp_problem *": {"Ptr{CProblem}"}, "const ddp_ilqg_opts *": {"Ptr{ILQGOpts}"},
     "ddp_ilqg_opts *": {"Ptr{ILQGOpts}"}, "const ddp_qp_opts *": {"Ptr{QPOpts}"}, "const ddp_kl_cost_terms *": {"Ptr{KLCostTerms}"},
+    "const ddp_kl_dual *": {"Ptr{KLDual}"},
     "const char *": {"Cstring"}, "void": {"Cvoid"},
 }
 STRUCTS = {"ddp_bp_desc": "BPDesc", "ddp_qp_opts": "QPOpts", "ddp_problem": "CProblem", "ddp_ilqg_opts": "ILQGOpts",
-           "ddp_kl_cost_terms": "KLCostTerms"}
-FIELD = {"int": {"Cint"}, "double": {"Cdouble", "Float64"}, "const double *": {"Ptr{Float64}"}}
+           "ddp_kl_cost_terms": "KLCostTerms", "ddp_kl_dual": "KLDual"}
+FIELD = {"int": {"Cint"}, "double": {"Cdouble", "Float64"}, "const double *": {"Ptr{Float64}"}, "double *": {"Ptr{Float64}"},
+         "int32_t *": {"Ptr{Int32}"}}
 
 
 def _strip_comments(src):
