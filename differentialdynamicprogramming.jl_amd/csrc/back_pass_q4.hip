@@ -93,22 +93,23 @@ __device__ __forceinline__ void boxqp1_two_iterations(double H, double g, double
     const double x1 = clampf(x0, lower, upper);                                                 // :58
     const double v1 = val(x1);
     const double grad1 = g + H * x1;                                                            // :85
-    const bool c1 = ((x1 == lower) && (grad1 > 0)) || ((x1 == upper) && (grad1 < 0));          // :92-95 -> result 6 (:98-101)
+    // (the tests are combined with & and |, not && and ||: short-circuit evaluation costs an exec-mask branch per term here)
+    const bool c1 = bool(((x1 == lower) & (grad1 > 0)) | ((x1 == upper) & (grad1 < 0)));        // :92-95 -> result 6 (:98-101)
     rH = ddp_rcp_nr(H);
     const double search = -(g * rH) - x1;                                                       // :127-129
     const double sdotg = search * grad1;                                                        // :132
     const double xc = clampf(x1 + search, lower, upper);                                        // step = 1 (:138-141)
     const double vc = val(xc);
     // iteration 1 runs to its end with step 1: H > 0 (:111), |grad| >= minGrad (:120), sdotg < 0 (:133), Armijo holds (:142)
-    const bool plain = (H > 0.0) && !(fabs(grad1) < o.minGrad) && (sdotg < 0) && !((vc - v1) > o.Armijo * sdotg);
+    const bool plain = bool((H > 0.0) & !(fabs(grad1) < o.minGrad) & (sdotg < 0) & !((vc - v1) > o.Armijo * sdotg));
     // second iteration
     const bool relimp = (v1 - vc) < o.minRelImprove * fabs(v1);                                 // result 4 (:78-81), free set of iteration 1
     const double grad2 = g + H * xc;
-    const bool c2 = ((xc == lower) && (grad2 > 0)) || ((xc == upper) && (grad2 < 0));          // result 6
+    const bool c2 = bool(((xc == lower) & (grad2 > 0)) | ((xc == upper) & (grad2 < 0)));        // result 6
     const bool small2 = fabs(grad2) < o.minGrad;                                                // result 5
-    slow = !c1 && !(plain && (relimp || c2 || small2));
+    slow = bool(!c1 & !(plain & (relimp | c2 | small2)));
     x = c1 ? x1 : xc;
-    clamped = c1 || (!relimp && c2);
+    clamped = bool(c1 | (!relimp & c2));
 }
 
 struct Q4In { double fx, fu, cx, cu, u, cxx, cxxT, cxuc, cxur, cuu; };    // operands of one step (layout L / column / row forms)
@@ -116,8 +117,12 @@ struct Q4State { double V, VT, vxc, kprev, dV0, dV1; int diverge; };        // V
 struct Q4Out { double Vn, Kc, vx, kk, Quu; };
 struct Q4Par { double lam, limlo, limhi; bool nolims; };
 
-template <bool LIMS, bool REG2, int EXP>
-__device__ __forceinline__ void q4_step(int i, const Q4In &o, Q4State &s, Q4Out &out, const Q4Par &p)
+struct Q4NoMid { __device__ __forceinline__ void operator()() const {} };
+
+// `mid` runs once the matrix instructions of the step have been issued (the LDS-chunk kernel puts the LDS writes of the PREVIOUS
+// step there: behind the products their latency costs nothing, in front of them it delays the first product)
+template <bool LIMS, bool REG2, int EXP, class Mid = Q4NoMid>
+__device__ __forceinline__ void q4_step(int i, const Q4In &o, Q4State &s, Q4Out &out, const Q4Par &p, Mid mid = Mid())
 {
     const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};                                   // boxQP.jl:30-35
     // ---- products that do not depend on Vxx (regType 2: Vxx_reg = Vxx + λI adds λ·fu'fx, λ·fu'fu; :245-247)
@@ -137,6 +142,7 @@ __device__ __forceinline__ void q4_step(int i, const Q4In &o, Q4State &s, Q4Out 
     const double Quxr = mm(W2, o.fx, o.cxur);
     const double Qxx = mm(o.fx, W, o.cxx);
     const double QxxT = mm(W, o.fx, o.cxxT);
+    mid();
     const double QuuF = Quu + (REG2 ? p.lam * ff : p.lam);    // :247
     const double Qrc = Quxc + (REG2 ? p.lam * Fc : 0.0);      // Qux_reg, both forms (:246)
     const double Qrr = Quxr + (REG2 ? p.lam * Fr : 0.0);
@@ -408,6 +414,140 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
     if (act && q16 == 0) { a.dV[2 * b] = s.dV0; a.dV[2 * b + 1] = s.dV1; a.diverge[b] = s.diverge; }
 }
 
+// ---- CHUNKS OF EIGHT TIME STEPS THROUGH THE LDS (N a multiple of 8, time-varying fx/fu, time-invariant cost)
+// A vector-memory instruction costs a lone wave ~60 issue cycles and the pair kernel above still spends ~50 further instructions
+// per step on addresses, lane swaps and the select tree of its merged store.  Here the global side moves whole chunks: seven
+// direct-to-LDS loads (global_load_lds_dwordx4: fx in four pieces, fu, cx, cu|u) fetch the operands of 8 steps x 4 trajectories one
+// chunk ahead, seven 16-byte stores write their results back; per step the wave only issues LDS instructions whose addresses are
+// one register + an immediate:  3 reads (fx; fu, cx; cu, u) and 3 writes (Vxx; K, Vx; k, Quu).  Replicated values are written by
+// their first lane only; the other lanes aim at a dump area, so no select and no exec mask is needed.
+constexpr int Q4L_CH = 8;
+constexpr int Q4L_IN = 896;          // doubles per input buffer: fx [4 pieces][4 traj][32] | fu [4][32] | cx [4][32] | cu,u [4][32] (8 + 8 used)
+constexpr int Q4L_IFU = 512, Q4L_ICX = 640, Q4L_ICU = 768;
+constexpr int Q4L_OK = 512;          // outputs: Vxx [4][4][32] | K [4][32] + dump 96 | Vx [4][32] + dump 96 | k,Quu [4][16] + dump 144
+constexpr int Q4L_KD = 224;          // distance K -> Vx block (the two offsets of one ds_write2_b64)
+constexpr int Q4L_OKQ = Q4L_OK + 2 * Q4L_KD, Q4L_OUT = Q4L_OKQ + 64 + 144;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <bool LIMS, bool REG2>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
+{
+    constexpr int n = 4, CH = Q4L_CH;
+    __shared__ __attribute__((aligned(16))) double lin[2][Q4L_IN];
+    __shared__ __attribute__((aligned(16))) double lout[Q4L_OUT];
+    const int N = a.N, NC = N / CH;
+    const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3, q16 = 4 * r + c;
+    long tb = (long)blockIdx.x * 4 + blk;
+    const bool valid = tb < a.B;
+    if (!valid) tb = a.B - 1;
+    const int b = (int)tb;
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;
+    const int e = r + 4 * c, et = c + 4 * r;
+    // the lane's trajectory on the global side (lane-linear LDS image: 16 lanes x 16 bytes per trajectory and piece)
+    const int tl = lane >> 4, q = lane & 15;
+    long tbd = (long)blockIdx.x * 4 + tl;
+    const bool validd = tbd < a.B;
+    if (!validd) tbd = a.B - 1;
+    const int bd = (int)tbd;
+    const bool actd = validd && !(a.active && a.active[bd] == 0);
+
+    const double *gfx = a.fx + a.fx_b * bd + 2 * q, *gfu = a.fu + a.fu_b * bd + 2 * q, *gcx = a.cx + (size_t)n * N * bd + 2 * q;
+    const double *gcu = ((LIMS && q >= 4) ? a.u : a.cu) + (size_t)N * bd + 2 * (q & 3);
+    auto dma = [&](int ch, double *in) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void *)(gfx + (size_t)ch * (16 * CH) + 32 * j), (lds_void *)(in + 128 * j), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(gfu + (size_t)ch * (4 * CH)), (lds_void *)(in + Q4L_IFU), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(gcx + (size_t)ch * (4 * CH)), (lds_void *)(in + Q4L_ICX), 16, 0, 0);
+        if (q < 8) __builtin_amdgcn_global_load_lds((glb_void *)(gcu + (size_t)ch * CH), (lds_void *)(in + Q4L_ICU), 16, 0, 0);
+    };
+    // global side of the results: a lane without an output (inactive trajectory) writes its 16 bytes of the sink
+    double *gV = actd ? a.Vxx + (size_t)16 * N * bd + 2 * q : a.sink + 2 * lane;
+    double *gK = actd ? a.K + (size_t)n * N * bd + 2 * q : a.sink + 2 * lane;
+    double *gX = actd ? a.Vx + (size_t)n * N * bd + 2 * q : a.sink + 2 * lane;
+    double *gS = actd ? ((q >= 4) ? a.Quu : a.k) + (size_t)N * bd + 2 * (q & 3) : a.sink + 2 * lane;
+    const size_t on = actd ? 1 : 0;
+    auto drain = [&](int ch) {
+        d2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *(const d2 *)(lout + 128 * j + 2 * lane);
+        const d2 vk = *(const d2 *)(lout + Q4L_OK + 2 * lane), vx = *(const d2 *)(lout + Q4L_OK + Q4L_KD + 2 * lane);
+        const d2 vs = *(const d2 *)(lout + Q4L_OKQ + 16 * tl + 2 * (q & 7));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(d2 *)(gV + on * ((size_t)ch * (16 * CH) + 32 * j)) = v[j];
+        *(d2 *)(gK + on * ((size_t)ch * (4 * CH))) = vk;
+        *(d2 *)(gX + on * ((size_t)ch * (4 * CH))) = vx;
+        if (q < 8) *(d2 *)(gS + on * ((size_t)ch * CH)) = vs;
+    };
+
+    Q4Par par;
+    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;
+    if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }
+    const double *cxx = a.cxx + a.cxx_b * b, *cuu = a.cuu + a.cuu_b * b, *cxu = a.cxu + a.cxu_b * b;
+    Q4In cst;
+    cst.cxx = cxx[e]; cst.cxxT = cxx[et]; cst.cxuc = cxu[r]; cst.cxur = cxu[c]; cst.cuu = cuu[0];
+
+    // per-lane LDS offsets (doubles) of the compute side
+    const int ofx = 32 * blk + e, ofu = Q4L_IFU + 32 * blk + r, ocu = Q4L_ICU + 32 * blk;
+    double *wV = lout + 32 * blk + e;
+    double *wK = lout + Q4L_OK + ((c == 0) ? 32 * blk + r : 128 + lane);                        // K_i[0, r] | Vx_i[r] at + Q4L_KD
+    double *wS = lout + Q4L_OKQ + ((q16 == 0) ? 16 * blk : 64 + (lane & 7) + 16 * (lane >> 3)); // k_i | Quu_i at + 8
+    auto readin = [&](const double *in, int sidx, Q4In &o) __attribute__((always_inline)) {
+        o.fx = in[ofx + 128 * (sidx >> 1) + 16 * (sidx & 1)];
+        o.fu = in[ofu + 4 * sidx];
+        o.cx = in[ofu + (Q4L_ICX - Q4L_IFU) + 4 * sidx];
+        o.cu = in[ocu + sidx];
+        o.u = LIMS ? in[ocu + 8 + sidx] : 0.0;
+        o.cxx = cst.cxx; o.cxxT = cst.cxxT; o.cxuc = cst.cxuc; o.cxur = cst.cxur; o.cuu = cst.cuu;
+    };
+    auto writeout = [&](int sidx, const Q4Out &o) __attribute__((always_inline)) {
+        wV[128 * (sidx >> 1) + 16 * (sidx & 1)] = o.Vn;
+        wK[4 * sidx] = o.Kc; wK[Q4L_KD + 4 * sidx] = o.vx;
+        wS[sidx] = o.kk; wS[8 + sidx] = o.Quu;
+    };
+
+    Q4State s;
+    s.kprev = 0.0; s.dV0 = 0.0; s.dV1 = 0.0; s.diverge = 0;
+    double *cur = lin[0], *nxt = lin[1];
+    dma(NC - 1, cur);
+    if (NC > 1) dma(NC - 2, nxt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Q4In in;
+    Q4Out prev;
+    readin(cur, CH - 1, in);
+    for (int ch = NC - 1; ch >= 0; --ch) {
+#pragma unroll
+        for (int sidx = CH - 1; sidx >= 0; --sidx) {
+            Q4In nx;
+            if (sidx > 0) readin(cur, sidx - 1, nx);
+            else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk was requested a whole chunk ago
+                readin(nxt, CH - 1, nx);
+            }
+            Q4Out o;
+            if (sidx == CH - 1 && ch == NC - 1) {
+                // terminal step (backward_pass.jl:21-23 / :234-236), see back_pass_q4_kernel
+                s.V = cst.cxx; s.VT = cst.cxxT; s.vxc = in.cx;
+                o.Vn = s.V; o.Kc = 0.0; o.vx = in.cx; o.kk = 0.0; o.Quu = cst.cuu;
+            } else if (sidx == CH - 1)
+                q4_step<LIMS, REG2, 0>(CH * ch + sidx, in, s, o, par);
+            else
+                q4_step<LIMS, REG2, 0>(CH * ch + sidx, in, s, o, par, [&]() __attribute__((always_inline)) { writeout(sidx + 1, prev); });
+            if (sidx == 0) { writeout(0, o); }
+            prev = o;
+            in = nx;
+        }
+        drain(ch);
+        if (ch >= 2) dma(ch - 2, cur);
+        double *t = cur; cur = nxt; nxt = t;
+    }
+    if (s.diverge && act) q4_zero_fill(a, b, q16, s.diverge);
+    if (act && q16 == 0) { a.dV[2 * b] = s.dV0; a.dV[2 * b + 1] = s.dV1; a.diverge[b] = s.diverge; }
+}
+
 }   // namespace
 
 // returns 1 if this shape has no such kernel (caller falls back), 0 launched, <0 error
@@ -440,7 +580,13 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
 #define Q4P(L_, R_, E_) hipLaunchKernelGGL((back_pass_q4p_kernel<L_, R_, E_>), grid, block, 0, h->stream, a)
 #define Q4S(L_, C_, R_) hipLaunchKernelGGL((back_pass_q4_kernel<L_, C_, R_>), grid, block, 0, h->stream, a)
     const bool reg2 = d->regType == 2;
-    if (paired) {
+    const char *lv = getenv("DDP_Q4_LDS");                     // 0: never the LDS-chunk kernel (A/B, tests)
+    const bool chunked = paired && d->fx_tv && (d->N % Q4L_CH == 0) && d->N >= 2 * Q4L_CH && exp == 0 && !(lv && lv[0] == '0');
+    if (chunked) {
+#define Q4L(L_, R_) hipLaunchKernelGGL((back_pass_q4l_kernel<L_, R_>), grid, block, 0, h->stream, a)
+        if (d->has_lims && reg2) Q4L(true, true); else if (d->has_lims) Q4L(true, false); else if (reg2) Q4L(false, true); else Q4L(false, false);
+#undef Q4L
+    } else if (paired) {
         if (d->has_lims && reg2) {
             switch (exp) {
             case 1: Q4P(true, true, 1); break; case 2: Q4P(true, true, 2); break; case 3: Q4P(true, true, 3); break;

@@ -55,6 +55,7 @@ def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warm
                                               p(dl) if dl is not None else None, None, p(dxn), p(dun), p(dcn), p(dcsn)))
         if ev: L.ddp_event_record(h.raw, ev[2])
 
+    steps = int(os.environ.get("DDP_BC_STEPS", steps)); warmup = int(os.environ.get("DDP_BC_WARMUP", warmup))     # A/B runs: many steps, clocks settled
     for _ in range(warmup):
         step()
     evs = []
@@ -79,6 +80,7 @@ def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warm
     fp_bytes = ((m * n + m + n + m) + (n * n + n * m if (tv and not pend) else 0) + (n + m + 1)) * 8 * N * B
     out = {"config": name, "n": n, "m": m, "N": N, "batch": B, "iterations_per_s": round(B * steps / el, 1), "ms_per_pass_batch": round(1e3 * el / steps, 3),
            "back_pass_ms": round(float(np.mean(bp)), 3), "forward_ms": round(float(np.mean(fp)), 3),
+           "back_pass_ms_median": round(float(np.median(bp)), 4), "back_pass_ms_min": round(float(np.min(bp)), 4),
            "back_pass_alg_bytes_per_launch": int(bp_bytes), "back_pass_alg_GBs": round(bp_bytes / (np.mean(bp) * 1e-3) / 1e9, 1), "back_pass_frac_of_8TBs": round(bp_bytes / (np.mean(bp) * 1e-3) / 8e12, 4),
            "forward_alg_GBs": round(fp_bytes / (np.mean(fp) * 1e-3) / 1e9, 1), "diverged": int(ddiv.sum().item())}
     print(json.dumps(out))

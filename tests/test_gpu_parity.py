@@ -265,6 +265,46 @@ def test_back_pass_implementations_n10m2(ddp, monkeypatch, impl, variant, regTyp
             assert relerr(got, ref) < RTOL
 
 
+@pytest.mark.parametrize("lims", [False, True])
+@pytest.mark.parametrize("regType", [1, 2])
+@pytest.mark.parametrize("N", [16, 40, 72])
+def test_back_pass_q4_kernel_variants(ddp, monkeypatch, lims, regType, N):
+    """n = 4, m = 1 on the 4x4x4 matrix instruction (csrc/back_pass_q4.hip): the one-step kernel, the paired-step kernel and the
+    LDS-chunk kernel against the oracle per trajectory, and bit-identical to each other; one trajectory of the batch diverges"""
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(100 * N + 10 * regType + int(lims))
+    n, m, B = 4, 1, 11
+    cx, cu, cxx, cxu, cuu, fx, fu, u = _tv_problem(rng, n, m, N, B)
+    cxx, cxu, cuu = cxx[:, :, 0, 0].copy(), cxu[:, :, 0, 0].copy(), cuu[:, :, 0, 0].copy()       # time-invariant cost: all three kernels apply
+    fu[:, :, N // 3, 4] = 0.0; fx[:, :, N // 3, 4] *= 1e-3
+    cxx_b, cxu_b, cuu_b = (np.repeat(a_[:, :, None], B, 2) for a_ in (cxx, cxu, cuu))
+    cuu_b[:, :, 4] = -1.0; cxx_b[:, :, 4] *= -1.0                                                # trajectory 4: Quu < 0 somewhere -> diverges
+    L = np.array([[-0.2, 0.25]]) if lims else None
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    outs = {}
+    for name, env in (("single", {"DDP_Q4_SINGLE": "1"}), ("paired", {"DDP_Q4_LDS": "0"}), ("chunked", {})):
+        for k_ in ("DDP_Q4_SINGLE", "DDP_Q4_LDS"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        outs[name] = ddp.back_pass(cx, cu, cxx_b, cxu_b, cuu_b, fx, fu, lam, regType, L, None, u, cost_batched=True)
+    div, pol, Vx, Vxx, dV = outs["chunked"]
+    assert div[4] > 0 and not np.delete(div, 4).any()
+    for b in range(B):
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], cxx_b[..., b], cxu_b[..., b], cuu_b[..., b], fx[..., b], fu[..., b],
+                                                  lam[b], regType, L, None, u[..., b])
+        assert d == div[b]
+        for got, ref in ((pol.K[..., b], K), (pol.k[..., b], k), (Vx[..., b], vx), (Vxx[..., b], vxx), (dV[:, b], dv)):
+            assert relerr(got, ref) < RTOL
+        if not d:
+            assert relerr(pol.Σi[..., b], Quu) < RTOL
+    for name in ("single", "paired"):
+        d2, p2, Vx2, Vxx2, dV2 = outs[name]
+        assert np.array_equal(d2, div)
+        for got, ref in ((p2.K, pol.K), (p2.k, pol.k), (Vx2, Vx), (Vxx2, Vxx), (dV2, dV), (p2.Σi, pol.Σi)):
+            assert np.array_equal(got, ref, equal_nan=True), name
+
+
 @pytest.mark.parametrize("impl", ["general", "dpp"])
 @pytest.mark.parametrize("name", ["bp_lti_n10m2_lims", "bp_ltv_pendcart_lims", "bp_ltv_pendcart_nolims"])
 def test_back_pass_implementations_limits(ddp, monkeypatch, impl, name):
