@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--collective", choices=["torch", "capi"], default="torch",
                     help="who issues the per-step statistics all-reduce: torch.distributed (backend nccl = RCCL) or the C ABI's own RCCL "
                          "communicator (ddp_allreduce_stats_f64_dev; torch.distributed then only ships the 128-byte id)")
+    ap.add_argument("--preheat", type=int, default=200, help="untimed passes BEFORE the warmup so that the GPU clocks have settled (a pass is "
+                    "0.7 ms; a cold device ramps its clocks over the first ~50 ms); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 pass lines (profiles/bench_configs.py in a child process)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories for the CPU baseline (0 = auto ~10-20 s)")
@@ -211,6 +213,8 @@ def main():
     if use_dist and args.collective == "capi":
         from ddp_amd import sharding
         pb.comm = sharding.CApiComm(h, rank, world)
+    if args.preheat > 0:
+        pb.timed(1, args.preheat, fence, dist if use_dist else None)       # untimed: clocks ramped, caches and TLBs as in steady operation
     elapsed, bp_ms, fp_ms = pb.timed(args.steps, args.warmup, fence, dist if use_dist else None)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -255,7 +259,7 @@ def main():
             other = other_configs()
         value = B * world * args.steps / elapsed
         out = {"metric": "iLQG iterations/sec (backward+forward, n=10 m=2 T=1000)", "value": round(value, 1),
-               "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_steps": args.preheat,
                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "BASELINE config 2: demo_linear LTI n=10 m=2 N=%d, batch=%d trajectories per GPU, no control "

@@ -47,6 +47,17 @@ constexpr int n = 10, m = 2, p = 12, VC = 12;      // VC: tile column that carri
 constexpr int PD = 8;                               // prefetch distance (time steps) of the streamed operands
 constexpr int TLD = 17;                             // leading dimension of the LDS transpose tile (odd: no bank conflicts)
 constexpr int TZERO = TLD * 16;                     // a cell that stays 0.0
+// LCH mode: the results of a group of PD time steps are collected in the LDS as one record per step, in the order they have in
+// memory, and written back by 16-byte stores at the end of the group; the vector [cx;cu] of the group arrives by one
+// direct-to-LDS load a group ahead.  A vector-memory instruction costs this lone wave ~50 issue cycles, an LDS access ~8.
+constexpr int REC = 136;                            // doubles per step record: Vxx 100 | Vx 10 | K 20 | k 2 | Quu 4
+constexpr int R_VX = 100, R_K = 110, R_KV = 130, R_QUU = 132;
+constexpr int LOUT = REC * PD;                      // the records of a group; behind them the cells lanes without an output write to
+constexpr int LDUMP = LOUT, LDUMP_SZ = 64 + 16 + REC * (PD - 1);
+constexpr int EREC = 12;                            // [cx; cu] of a step
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 template <int L>
 __device__ __forceinline__ double row_bcast(double x) { return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + L, 0xf, 0xf, true); }
@@ -117,7 +128,7 @@ struct Stream {          // a per-lane operand that moves by `stride` bytes per 
     __device__ __forceinline__ void back() { cur -= stride; }
 };
 
-template <bool FXTV, bool CTV, bool REG2>
+template <bool FXTV, bool CTV, bool REG2, bool LCH>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
 {
     const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
@@ -126,6 +137,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
 
     __shared__ __attribute__((aligned(16))) double lds[TLD * 16 + 16];      // transpose tile + zero cells
+    __shared__ __attribute__((aligned(16))) double lout[LCH ? LOUT + LDUMP_SZ : 2];
+    __shared__ __attribute__((aligned(16))) double leb[2][LCH ? 128 : 2];
 
     const double *cx = a.cx + (size_t)n * N * b, *cu = a.cu + (size_t)m * N * b;
     const double *fx = a.fx + (a.fx_batched ? nn * (FXTV ? N : 1) * b : 0);
@@ -204,6 +217,27 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
                                : (l15 == VC ? (char *)(kg + (size_t)m * (tl - 1) + a2) : (char *)(Quug + mm * (tl - 1) + a2 + m * (l15 < p ? l15 - n : 0))));
     const unsigned kq_stride = !hi2 ? vst_stride : (l15 < n ? (unsigned)(nm * 8) : (l15 == VC ? (unsigned)(m * 8) : (unsigned)(mm * 8)));
 
+    // ---- LCH: where this lane's results go in a step record, and its share of the write-back of a group
+    // accumulator registers 0, 1 (and 2 in 16-lane rows 0, 1): Vxx[l4+4s, l15] | column VC: Vx[l4+4s]; register 2 of rows 2, 3: K | k | Quu
+    const int w1 = l15 < n ? l4 + n * l15 : (l15 == VC ? R_VX + l4 : LDUMP + lane);
+    const int w2 = !hi2 ? w1 + 8
+                        : (l15 < n ? R_K + a2 + m * l15 : (l15 == VC ? R_KV + a2 : (l15 < p ? R_QUU + a2 + m * (l15 - n) : LDUMP + lane)));
+    // write-back: Vxx of one step = 50 lanes x 16 bytes; Vx, K, k, Quu of three steps = 54 lanes x 16 bytes
+    const int msub = lane / 18, mw = lane % 18;
+    const int mL = REC * msub + (mw < 5 ? R_VX + 2 * mw : (mw < 15 ? R_K + 2 * (mw - 5) : (mw == 15 ? R_KV : R_QUU + 2 * (mw - 16))));
+    const unsigned mstep = mw < 5 ? n * 8u : (mw < 15 ? (unsigned)(nm * 8) : (mw == 15 ? m * 8u : (unsigned)(mm * 8)));     // bytes per time step
+    char *pV = nullptr, *pM = nullptr;
+    const char *pE = nullptr;
+    if (LCH) {
+        const long t0 = (long)N - 2 - (PD - 1);              // lowest step of the first group
+        pV = (char *)(Vxxg + (long)nn * t0 + 2 * (lane < 50 ? lane : 0));
+        char *mb = mw < 5 ? (char *)(Vxg + 2 * mw) : (mw < 15 ? (char *)(Kg + 2 * (mw - 5)) : (mw == 15 ? (char *)kg : (char *)(Quug + 2 * (mw - 16))));
+        pM = mb + (long)mstep * (t0 + (lane < 54 ? msub : 0));
+        const int et = lane < 48 ? lane / 6 : 0, ew = lane % 6;                                                             // [cx; cu] of step t0 + et, pair ew
+        pE = ew < 5 ? (const char *)(cx + (long)n * (t0 + et) + 2 * ew) : (const char *)(cu + (long)m * (t0 + et));
+    }
+    const unsigned estep = (lane % 6) < 5 ? n * 8u : m * 8u;
+
     // ---- register-resident operands -------------------------------------------------------------------------------
     const double hmask = l15 < p ? 0.5 : 0.0;
     double F[3], Fh[3], Hc[4];                               // F_s (A of GEMM2), ½F_s without the repeated columns (B of GEMM1: A carries 2 Vxx), C (H)
@@ -212,7 +246,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
 #pragma unroll
     for (int j = 0; j < PD; ++j) {
         const int t = i0 - j > 0 ? i0 - j : 0;
-        er[j] = eS.at(t);
+        er[j] = LCH ? 0.0 : eS.at(t);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if (FXTV && s < 3) fr[j][s] = fS[s].at(t);
@@ -246,6 +280,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         }
     }
     const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+    double *ecur = leb[0], *enxt = leb[1];
+    auto dma_e = [&](double *dst) {                 // [cx; cu] of the PD steps pE points at -> PD records of EREC doubles
+        if (lane < 48) __builtin_amdgcn_global_load_lds((glb_void *)pE, (lds_void *)dst, 16, 0, 0);
+    };
+    if (LCH && i0 >= PD - 1) { dma_e(ecur); pE -= (size_t)PD * estep; }
     wave_sync();
     // all set-up loads have landed: the waits inside the loop are then computed from the steady state only
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
@@ -255,15 +294,18 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     // One time step.  No exits inside: a diverged trajectory (wave-uniform) keeps stepping through garbage with its
     // stores switched off until the loop around the step looks at `diverge` — an exit edge here would make the waits at
     // the loop head cover the path "just refilled this ring slot -> loop head" and drain the memory queue every time.
-    auto step = [&](const int i, auto slot_c) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slot_c)::value;
+    // mode 0: operands and results straight from / to global memory; 1 (LCH groups): [cx;cu] from the LDS, results into the step
+    // record of the group; 2 (LCH, the steps left over below the last group): like 0, er[] was loaded for them
+    auto step = [&](const int i, auto slot_c, auto mode_c) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_c)::value, mode = decltype(mode_c)::value;
+        constexpr int tau = PD - 1 - slot;                  // position of the step in its group (ascending time)
         const bool okp = diverge == 0;
         // ---- operands of this step (ring slot `slot`; the slot is refilled at the END of the step, when its old
         //      contents are dead, so that the prefetch lands in the same registers: no copies, no early waits)
         // C operand of GEMM2: H only.  The vector e = [cx;cu] of column VC enters later and in place: G[:,VC] is used by the
         // u-rows (Qu, below) and, linearly, by V[:,VC] = Vx (added after the value MFMA).
         const d4 c = CTV ? d4{hr[slot][0], hr[slot][1], hr[slot][2], hr[slot][3]} : Hc4;
-        const double e = er[slot];
+        const double e = mode == 1 ? ecur[EREC * tau + eidx] : er[slot];
         if (FXTV) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) { F[s] = fr[slot][s]; Fh[s] = hmask * F[s]; }
@@ -314,12 +356,16 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         const double Bop = hi2 ? (quu_lane ? Z : Ksel) : Tsel;   // (columns 10,11 of V are junk: their B lanes carry Quu for the store below)
         const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Bop, g, 0, 0, 0);
         // ---- while the value MFMA runs: outputs that do not depend on it, bookkeeping
-        const bool badu = __builtin_amdgcn_ballot_w64(bad) != 0;
-        if (okp && !badu) {                                // column VC: k'Qu and k_a (Quu k + Qu)_a  (:68)
+        // wave-uniform branches, not selects: the common path is two multiply-adds
+        const bool badu = (__builtin_amdgcn_ballot_w64(!(F00 > 0.0)) | __builtin_amdgcn_ballot_w64(!(det > 0.0))) != 0;
+        if (__builtin_expect(badu || !okp, 0)) {
+            asm volatile("" ::: "memory");
+            if (okp) diverge = i + 1;                      // diverge = i (:37-38)
+        } else {                                           // column VC: k'Qu and k_a (Quu k + Qu)_a  (:68)
+            asm volatile("" ::: "memory");
             dVa = fma(K1, Q1, fma(K0, Q0, dVa));
             dVp = fma(Ksel, Tsel, dVp);
         }
-        if (okp && badu) diverge = i + 1;                  // diverge = i (:37-38)
         // ---- ½(V + V') through the transpose tile; registers keep V + V' (column VC: Vx)
         lds[wr] = v.x; lds[wr + 4] = v.y; lds[wr + 8] = v.z;
         wave_sync();
@@ -329,23 +375,29 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         fmac_bcast<8>(S[2], e, mask12);
         // Stores are unconditional: a diverged trajectory writes garbage into time steps that are zero-filled after the loop
         // (behind a vmcnt(0) wait); the failing step itself leaves the Quu_i the reference returns.
-        store2_masked(vst, vscl * S[0], vscl * S[1], lanes01);
-        // rows 8, 9 of Vxx | Vx (16-lane rows 0,1) and K | k | Quu (:75-76) (rows 2,3) share one store
-        store_masked(kq, hi2 ? Bop : vscl * S[2], lanes2k);
-        vst -= vst_stride;
-        kq -= kq_stride;
+        if (mode == 1) {
+            lout[w1 + REC * tau] = vscl * S[0];
+            lout[w1 + 4 + REC * tau] = vscl * S[1];
+            lout[w2 + REC * tau] = hi2 ? Bop : vscl * S[2];
+        } else {
+            store2_masked(vst, vscl * S[0], vscl * S[1], lanes01);
+            // rows 8, 9 of Vxx | Vx (16-lane rows 0,1) and K | k | Quu (:75-76) (rows 2,3) share one store
+            store_masked(kq, hi2 ? Bop : vscl * S[2], lanes2k);
+            vst -= vst_stride;
+            kq -= kq_stride;
+        }
         wave_sync();                                       // the tile is free again
         {   // refill the ring slot with the step PD ahead (clamped: always a valid load)
             const int tp = i - PD > 0 ? i - PD : 0;
             asm volatile("" ::: "memory");
-            er[slot] = eS.next();
+            if (mode == 0) er[slot] = eS.next();
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (FXTV && s < 3) fr[slot][s] = fS[s].next();
                 if (CTV) hr[slot][s] = hS[s].next();
             }
             if (i - PD > 0) {
-                eS.back();
+                if (mode == 0) eS.back();
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     if (FXTV && s < 3) fS[s].back();
@@ -355,13 +407,46 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         }
     };
     int i = i0;
-    while (i >= PD - 1 && diverge == 0) {
-        static_for<0, PD>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc); });
-        i -= PD;
+    if (!LCH) {
+        while (i >= PD - 1 && diverge == 0) {
+            static_for<0, PD>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc, IC<0>{}); });
+            i -= PD;
+        }
+        static_for<0, PD - 1>([&](auto sc) __attribute__((always_inline)) {    // the last (N-1) mod PD steps
+            if (i >= 0 && diverge == 0) { step(i, sc, IC<0>{}); --i; }
+        });
+    } else {
+        while (i >= PD - 1 && diverge == 0) {
+            if (i - PD >= PD - 1) { dma_e(enxt); pE -= (size_t)PD * estep; }       // [cx;cu] of the next group, a whole group ahead
+            static_for<0, PD>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc, IC<1>{}); });
+            // the direct-to-LDS load issued at the top has landed once at most the ring refills of this group are outstanding
+            // (in-order return); the stores below are issued after the wait and never waited for
+            if (FXTV && CTV) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+            else if (CTV) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (FXTV) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- write the PD step records back: Vxx one step per instruction, the small arrays three steps per instruction
+            if (lane < 50) {
+#pragma unroll
+                for (int t = 0; t < PD; ++t) *(d2 *)(pV + nn * 8 * t) = *(const d2 *)(lout + REC * t + 2 * lane);
+            }
+            if (lane < 54) {
+                *(d2 *)pM = *(const d2 *)(lout + mL);
+                *(d2 *)(pM + 3 * (size_t)mstep) = *(const d2 *)(lout + mL + 3 * REC);
+                if (lane < 36) *(d2 *)(pM + 6 * (size_t)mstep) = *(const d2 *)(lout + mL + 6 * REC);
+            }
+            pV -= nn * 8 * PD; pM -= (size_t)mstep * PD;
+            double *t_ = ecur; ecur = enxt; enxt = t_;
+            i -= PD;
+        }
+        // the steps below the last whole group go the direct way
+        vst -= (size_t)vst_stride * (unsigned)(i0 - i); kq -= (size_t)kq_stride * (unsigned)(i0 - i);
+#pragma unroll
+        for (int j = 0; j < PD - 1; ++j) er[j] = eS.at(i - j > 0 ? i - j : 0);
+        static_for<0, PD - 1>([&](auto sc) __attribute__((always_inline)) {
+            if (i >= 0 && diverge == 0) { step(i, sc, IC<2>{}); --i; }
+        });
     }
-    static_for<0, PD - 1>([&](auto sc) __attribute__((always_inline)) {    // the last (N-1) mod PD steps
-        if (i >= 0 && diverge == 0) { step(i, sc); --i; }
-    });
 
     if (diverge) {   // outputs earlier in time than the failing step are zero (backward_pass.jl:226-229)
         const size_t ie = (size_t)diverge;          // = i + 1
@@ -380,16 +465,16 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     if (lane == 0) a.diverge[b] = diverge;
 }
 
-template <bool REG2>
+template <bool REG2, bool LCH>
 int launch_mx(ddp_handle h, const ddp_bp_desc *d, const BPXArgs &a)
 {
     const dim3 grid(d->B), block(DDP_WAVE);
     const int key = (d->fx_tv ? 2 : 0) | (d->cost_tv ? 1 : 0);
     switch (key) {
-    case 0: hipLaunchKernelGGL((back_pass_mx_kernel<false, false, REG2>), grid, block, 0, h->stream, a); break;
-    case 1: hipLaunchKernelGGL((back_pass_mx_kernel<false, true, REG2>), grid, block, 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((back_pass_mx_kernel<true, false, REG2>), grid, block, 0, h->stream, a); break;
-    case 3: hipLaunchKernelGGL((back_pass_mx_kernel<true, true, REG2>), grid, block, 0, h->stream, a); break;
+    case 0: hipLaunchKernelGGL((back_pass_mx_kernel<false, false, REG2, LCH>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((back_pass_mx_kernel<false, true, REG2, LCH>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((back_pass_mx_kernel<true, false, REG2, LCH>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((back_pass_mx_kernel<true, true, REG2, LCH>), grid, block, 0, h->stream, a); break;
     }
     DDP_HIP(hipGetLastError());
     return 0;
@@ -408,5 +493,9 @@ int ddp_launch_back_pass_mx(ddp_handle h, const ddp_bp_desc *d, const double *cx
     a.N = d->N; a.B = d->B; a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched;
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
-    return d->regType == 2 ? launch_mx<true>(h, d, a) : launch_mx<false>(h, d, a);
+    // the group write-back needs 16-byte aligned arrays (every per-step size of this shape is a multiple of 16 bytes)
+    const char *lv = getenv("DDP_MX_LDS");                    // 0: results straight to global memory, step by step (A/B, tests)
+    const bool al16 = ((((uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx) & 15) == 0);
+    if (al16 && !(lv && lv[0] == '0')) return d->regType == 2 ? launch_mx<true, true>(h, d, a) : launch_mx<false, true>(h, d, a);
+    return d->regType == 2 ? launch_mx<true, false>(h, d, a) : launch_mx<false, false>(h, d, a);
 }

@@ -25,3 +25,10 @@ for it in range(2):
     dt = time.perf_counter() - t
     print("C3 iLQG pendcart B=%d without the time_* keys (host poll every 4th batch iteration): %.3f s, %.3f s inside the C call, %d batch iterations"
           % (B, dt, r[6]["time_total"], r[6]["global_iters"]))
+# straggler cost of the lock-step batch iteration: how many iterations each trajectory needs vs the number of batch iterations
+it_ = r[6]["stats"][1].astype(int)
+q = np.percentile(it_, [0, 10, 25, 50, 75, 90, 99, 100]).astype(int)
+print("   iterations per trajectory: min/p10/p25/p50/p75/p90/p99/max = %s; sum %d = %.1f %% of (batch iterations x B) %d"
+      % ("/".join(map(str, q)), it_.sum(), 100.0 * it_.sum() / (r[6]["global_iters"] * B), r[6]["global_iters"] * B))
+live = [(it_ > g).sum() for g in range(0, int(it_.max()), max(1, int(it_.max()) // 12))]
+print("   live trajectories after every %d batch iterations: %s" % (max(1, int(it_.max()) // 12), live))
