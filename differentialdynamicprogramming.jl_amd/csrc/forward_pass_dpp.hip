@@ -297,10 +297,13 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
     constexpr int n = 4, DL = 4;
     const int N = a.N, B = a.B;
     const long total = (long)B * a.nalpha;
-    long rho = (long)blockIdx.x * DDP_WAVE + threadIdx.x;
-    const bool valid = rho < total;
-    if (!valid) rho = total - 1;
-    const int b = (int)(rho % B), ai = (int)(rho / B);
+    // the step sizes of ONE trajectory sit in neighbouring lanes: their loads of K_i, k_i, x_i, ū_i hit the same cache lines, so a
+    // load instruction touches 64/nalpha lines instead of 64 (the address unit works line by line)
+    long lin = (long)blockIdx.x * DDP_WAVE + threadIdx.x;
+    const bool valid = lin < total;
+    if (!valid) lin = total - 1;
+    const int b = (int)(lin / a.nalpha), ai = (int)(lin % a.nalpha);
+    const long rho = (long)b + (long)B * ai;                    // index of the rollout in xnew / unew / cnew / csum
     const bool act = valid && !(a.active && a.active[b] == 0);
     if (!__any(act)) return;                                    // every rollout of this wave belongs to a finished trajectory
     const double alpha = a.alpha[ai];
