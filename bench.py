@@ -117,20 +117,23 @@ class PassBench:
         _lib, L, h = self._lib, self.L, self.h
         for _ in range(warmup):
             self.step(None, dist)
-        events = []
-        for _ in range(steps):
+        # HIP events bracket the kernels of every `every`-th step (at least 8 samples): an event record costs a few microseconds of
+        # stream time, three of them per 0.7 ms step are 1-2 % of the very number being measured
+        every = max(1, min(4, steps // 8))
+        events = {}
+        for i in range(0, steps, every):
             ev = [C.c_void_p() for _ in range(3)]
             for e in ev:
                 _lib.check(L.ddp_event_create(h.raw, C.byref(e)))
-            events.append(ev)
+            events[i] = ev
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
-            self.step(events[i], dist)
+            self.step(events.get(i), dist)
         fence()
         elapsed = time.perf_counter() - t0
         bp_ms, fp_ms = [], []
-        for ev in events:
+        for ev in events.values():
             ms = C.c_float(0)
             _lib.check(L.ddp_event_elapsed_ms(h.raw, ev[0], ev[1], C.byref(ms))); bp_ms.append(ms.value)
             _lib.check(L.ddp_event_elapsed_ms(h.raw, ev[1], ev[2], C.byref(ms))); fp_ms.append(ms.value)
@@ -153,7 +156,7 @@ class PassBench:
                 "g": "back_pass_kernel<10,2>"}.get(force, "back_pass_mx_kernel<LTI>" if B < 5120 else "back_pass_dpp_kernel<10,2,LTI>")
         return {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": bp_bytes_launch,
-                "avg_launch_ms": round(bp_avg_ms, 4),
+                "avg_launch_ms": round(bp_avg_ms, 4), "avg_launch_ms_samples": "HIP events around every 4th launch of the timed region (every launch when steps < 32)",
                 "forward_kernels": {"kernels": "forward_dpp_kernel (cost fused, ddp_problem::cost_diag)" if os.environ.get("DDP_FORWARD_FUSE", "1") != "0"
                                     else "forward_dpp_kernel + cost_kernel", "avg_launch_ms": round(fp_avg_ms, 4),
                                     "bytes_per_launch": fp_bytes * N * B,
@@ -279,6 +282,8 @@ def other_configs():
     informational lines so that every configuration has a number in the driver's record; the graded value is config 2's."""
     import subprocess
     env = dict(os.environ, DDP_C4_SOLVE="0")
+    env.setdefault("DDP_BC_WARMUP", "20")                       # clocks settled here too (C3: 60 passes of 0.6 ms, C4: 25 of 10 ms)
+    env.setdefault("DDP_BC_STEPS", "40")
     out = []
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c4"], env=env, capture_output=True, text=True,

@@ -55,7 +55,9 @@ def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warm
                                               p(dl) if dl is not None else None, None, p(dxn), p(dun), p(dcn), p(dcsn)))
         if ev: L.ddp_event_record(h.raw, ev[2])
 
-    steps = int(os.environ.get("DDP_BC_STEPS", steps)); warmup = int(os.environ.get("DDP_BC_WARMUP", warmup))     # A/B runs: many steps, clocks settled
+    steps = int(os.environ.get("DDP_BC_STEPS", steps)); warmup = int(os.environ.get("DDP_BC_WARMUP", warmup))
+    if n >= 64:                                                 # C4: a pass is 10 ms, fewer of them
+        steps, warmup = max(5, steps // 4), max(1, warmup // 4)     # A/B runs: many steps, clocks settled
     for _ in range(warmup):
         step()
     evs = []

@@ -8,7 +8,8 @@ TAG=$1; CFG=$2; KSUB=$3; shift 3
 for kv in "$@"; do export "$kv"; done
 export DDP_C4_SOLVE=0
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
-python profiles/bench_configs.py $CFG > $OUT/events.json 2> $OUT/events.err
+DDP_BC_STEPS=120 DDP_BC_WARMUP=40 python profiles/bench_configs.py $CFG > $OUT/events.json 2> $OUT/events.err     # clocks settled
+export DDP_BC_STEPS=12 DDP_BC_WARMUP=2                       # the profiled runs: few launches (every launch is serialised by the counters)
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $REPO/profiles/bench_configs.py $CFG > $OUT/stats.log 2>&1
 P0="FETCH_SIZE"

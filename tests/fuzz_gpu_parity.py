@@ -23,6 +23,8 @@ def gen_case(rng):
     n, m = [(10, 2), (4, 1), (6, 3), (64, 8), (7, 2), (12, 4), (40, 4), (37, 3), (51, 2)][rng.integers(0, 9)]
     big = rng.integers(0, 6) == 0                                 # now and then a long horizon / several waves
     N = (int(rng.integers(1, 300 if big else 40))) if n < 40 else int(rng.integers(2, 50 if big else 14))
+    if rng.integers(0, 3) == 0:
+        N = max(8, N // 8 * 8)                                    # the kernels that move groups of 8 steps through the LDS (q4l, mx)
     B = int(rng.integers(1, 70 if (big and n < 40) else 6))
     fx_tv, fx_b = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     c_tv = bool(rng.integers(0, 2))
