@@ -110,7 +110,13 @@ class PassBench:
             _lib.check(L.ddp_batch_stats_f64_dev(h.raw, self.B, p(self.dcsn), p(self.ddV), p(self.ddiv), p(self.stats)))
             if self.comm is not None:
                 self.comm.allreduce(self.stats.data_ptr(), 4, 0)     # RCCL through the C ABI (ddp_allreduce_stats_f64_dev)
+            elif dist.get_backend() == "gloo":                        # test mode (DDP_BENCH_BACKEND=gloo)
+                t = self.stats.cpu()
+                dist.all_reduce(t)
+                self.stats.copy_(t)
             else:
+                # in line on the pass's stream: moving it to a stream of its own (event record / wait per step) measured SLOWER
+                # (+30 µs per step instead of +12..23) than the all-reduce itself
                 dist.all_reduce(self.stats)
 
     def timed(self, steps, warmup, fence, dist=None):
@@ -191,13 +197,18 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    backend = os.environ.get("DDP_BENCH_BACKEND", "nccl")   # "gloo": test mode — several ranks may share one GPU (RCCL refuses that), the
+    local = local % torch.cuda.device_count() if backend == "gloo" else local     # statistics vector travels through host memory
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run the collective path runs even with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import ddp_amd
     from ddp_amd import _lib
@@ -220,7 +231,7 @@ def main():
         pb.timed(1, args.preheat, fence, dist if use_dist else None)       # untimed: clocks ramped, caches and TLBs as in steady operation
     elapsed, bp_ms, fp_ms = pb.timed(args.steps, args.warmup, fence, dist if use_dist else None)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     roofline = pb.roofline(bp_ms, fp_ms)
