@@ -27,6 +27,7 @@ struct FDArgs {
     const double *Q, *R;
     double goal[4];
     double *cnew, *csum;
+    double *sink;               // >= 64 x 8 B that lanes without an output write to (stores carry no exec-mask branch); NULL: masked stores
 };
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -76,7 +77,9 @@ struct RowSum {
 // xnew, unew from HBM (98 MB of the 431 MB a C2 pass moved).  The contributions of 16 steps wait in an LDS tile; then lane t of
 // the row sums step t, stores cnew[t] (one 128-byte line per row) and keeps its part of sum(cnew): off the dependency chain,
 // ~4 instructions per step.
-template <int KIND, int NS, int MS, bool POLICY, bool LIMS, bool FUSE>
+// FAST: time-invariant dynamics and a sink for the lanes without an output — the step then has no branch at all (a taken branch costs a
+// lone wave ~28 cycles, the save-exec / branch / restore around a masked store ~25: profiles/microbench/branch_cost.hip)
+template <int KIND, int NS, int MS, bool POLICY, bool LIMS, bool FUSE, bool FAST = false>
 __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
 {
     constexpr int n = NS, m = MS, G = 16, GPW = DDP_WAVE / G, TS = 17;             // TS: padded row of the cost tile (no bank conflicts)
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     // one predicated store per step: lane j < n writes xnew[j,i], lanes n..n+m-1 write unew[j-n,i]
     const bool st_u = j >= n && j < n + m;
     const bool st_on = act && (inx || st_u);
-    double *st_base = st_u ? uo + (j - n) : xo + jx;
-    const unsigned st_stride = (st_u ? m : n) * (unsigned)sizeof(double);
+    double *st_base = (FAST && !st_on) ? a.sink + lane : (st_u ? uo + (j - n) : xo + jx);
+    const unsigned st_stride = (FAST && !st_on) ? 0u : (st_u ? m : n) * (unsigned)sizeof(double);
 
     // Loads are UNCONDITIONAL (clamped lane index): a load inside an exec-masked branch makes the compiler
     // drain all outstanding loads (s_waitcnt vmcnt(0)) at the join and would serialise the prefetch ring.
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
             double v = xh;
 #pragma unroll
             for (int q = 0; q < m; ++q) v = (j == n + q) ? uu[q] : v;
-            if (st_on) *(double *)((char *)st_base + (size_t)i * st_stride) = v;
+            if (FAST || st_on) *(double *)((char *)st_base + (size_t)i * st_stride) = v;
             if (FUSE) {
                 const double dv = pendk ? v - cg : v;
                 const double pc = (cw * dv) * dv;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
         if (advance) {
             double xp;
             if (KIND == DDP_PROBLEM_LQ) {
-                if (a.dyn_tv) load_dyn(i);
+                if (!FAST && a.dyn_tv) load_dyn(i);
                 double s0 = 0.0, s1 = 0.0, t = 0.0;
                 RowDot<n>::run(s0, s1, xh, Arow);                        // Σ_l A[j,l] x̂_l
 #pragma unroll
@@ -463,6 +466,13 @@ int launch_dpp(ddp_handle h, const FDArgs &a)
     const long total = (long)a.B * a.nalpha;
     const int gpw = DDP_WAVE / 16;
     const dim3 grid((unsigned)((total + gpw - 1) / gpw)), block(DDP_WAVE);
+    const char *fv = getenv("DDP_FORWARD_FAST");                // 0: the variant with the run-time dyn_tv test and masked stores (A/B, tests)
+    if (a.has_policy && !a.dyn_tv && a.sink && !(fv && fv[0] == '0')) {
+        if (a.has_lims) hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, true, FUSE, true>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, false, FUSE, true>), grid, block, 0, h->stream, a);
+        DDP_HIP(hipGetLastError());
+        return 0;
+    }
     switch (key) {
     case 0: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, false, FUSE>), grid, block, 0, h->stream, a); break;
     case 1: hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, false, true, FUSE>), grid, block, 0, h->stream, a); break;
@@ -488,7 +498,7 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
     a.A = p->A; a.Bm = p->Bm; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.lims = lims; a.active = active;
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
-    a.xnew = xnew; a.unew = unew;
+    a.xnew = xnew; a.unew = unew; a.sink = (double *)h->sink;
     const char *fuse_env = getenv("DDP_FORWARD_FUSE");           // 0: keep the separate cost kernel (A/B timing, tests)
     const bool fuse = p->cost_diag != 0 && !(fuse_env && fuse_env[0] == '0');     // Q, R declared diagonal: cost inside the rollout kernel
     a.Q = p->Q; a.R = p->R; a.cnew = cnew; a.csum = csum;
