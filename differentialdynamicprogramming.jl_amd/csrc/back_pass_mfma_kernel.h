@@ -67,7 +67,7 @@ __device__ __forceinline__ d4 mf(double x, double y, d4 c) { return __builtin_am
 // NTL MFMA chains that share one operand (A if SHA, else B): 1 + NTL LDS reads per k-step instead of 2·NTL — with all four
 // waves in a product phase the LDS, not the matrix pipe, is what saturates at two reads per MFMA.
 template <int NK, int PF, int NTL, int SS, int SO, bool SHA>
-__device__ __forceinline__ void mfma_chain_shared(const double *sp, const double *const (&op)[3], d4 (&c)[3])
+__device__ __forceinline__ void mfma_chain_shared(const double *sp, const double *const *op, d4 *c)
 {
     double r[PF + 1][1 + NTL];
 #pragma unroll
@@ -167,17 +167,31 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
     // upper-triangle tile t = 0..9 of the 4 x 4 Qxx tiling, column-major: (0,0) (0,1) (1,1) (0,2) ...
     // phase-3 tiles of a wave share an operand: wave w < 3 takes row w of the upper triangle ((0,0) (0,1) (0,2) | (1,1) (1,2) (1,3) |
     // (2,2) (2,3)), A = F[:, 16w..] shared; wave 3 the two left-over tiles of column 3, (0,3) and (3,3), B = W[:, 48..] shared
+    // EARLY3 (control limits: the box-QP makes wave 0's serial part ~5 us, longer than the products of the other waves): the tiles belong
+    // to the waves 1..3 BY COLUMN — wave c computes column tile c of W = Vxx·F in phase 2 and goes straight on, without a barrier, to
+    // the K-independent part cxx + fx'W of the tiles (ti, c), ti <= c, whose B operand is that column (shared by the chains of the
+    // wave); wave 1 also takes (0,0), whose W column comes from phase 1.  All of that runs beside the QP; only the rank-16 update
+    // ½(K'Y + Y'K) waits for the gains.  Without limits the gains are shorter than phase 2 and the four-wave split above is faster
+    // (measured: 7.7 ms against 9.1 ms with the column split, which leaves wave 0 idle).
+    constexpr bool EARLY3 = LIMS;
     auto tile_w = [](int w, int u, int &ti, int &tj) -> bool {
+        if (EARLY3) {
+            if (w == 1) { ti = (u == 2) ? 1 : 0; tj = (u == 0) ? 0 : 1; return u < 3; }          // (0,0) | (0,1) (1,1)
+            if (w == 2) { ti = min(u, 2); tj = 2; return u < 3; }                              // (0,2) (1,2) (2,2)
+            if (w == 3) { ti = min(u, 3); tj = 3; return u < 4; }                              // (0,3) (1,3) (2,3) (3,3)
+            ti = 0; tj = 0; return false;
+        }
+        if (u >= 3) { ti = 0; tj = 0; return false; }
         if (w < 3) { ti = w; tj = min(w + u, 3); return u < (w == 2 ? 2 : 3); }
         ti = (u == 0) ? 0 : 3; tj = 3; return u < 2;
     };
     double dV0 = 0.0, dV1 = 0.0;
     int diverge = 0;
-    double cxxr[3][4], cxur[m], preq[2];              // cost-Hessian operands of this thread (reloaded per step only if CTV)
+    double cxxr[4][4], cxur[m], preq[2];              // cost-Hessian operands of this thread (reloaded per step only if CTV)
     auto load_cost = [&](int i) {
         const double *cxxi = cxx + (CTV ? nn * i : 0), *cxui = cxu + (CTV ? nm * i : 0), *cuui = cuu + (CTV ? mm * i : 0);
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {               // C operands of this wave's Vxx tiles (phase 3)
+        for (int u = 0; u < (EARLY3 ? 4 : 3); ++u) { // C operands of this wave's Vxx tiles (phase 3)
             int ti, tj;
             tile_w(wv, u, ti, tj);
             const double *cp = cxxi + 16 * ti + l4 + n * (16 * tj + l15);
@@ -279,6 +293,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
         __syncthreads();
         MFP(1);
 
+        d4 acc3[4];                                                  // EARLY3: this wave's tiles of Vxx_i (waves 1..3)
         if (wv == 0) {
             // ================= phase 2, wave 0: reduce the partial tiles, gains (backward_pass.jl:30-68) =========
             // This wave is the serial part of the step: a chain of dependent vector instructions that shares its SIMD with the matrix
@@ -469,6 +484,24 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 double *wp = WT + 16 * wv + l15 + LD * (16 * rb + l4);
                 wp[0] = acc[rb].x; wp[LD * 4] = acc[rb].y; wp[LD * 8] = acc[rb].z; wp[LD * 12] = acc[rb].w;
             }
+            if (EARLY3) {
+                // ================= phase 3a (no barrier: this wave's own W column): cxx + fx'W of the tiles (ti, c) ==========
+                wave_sync();
+                const double *apt[4], *bpt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int ti, tj;
+                    tile_w(wv, u, ti, tj);
+                    acc3[u] = d4{cxxr[u][0], cxxr[u][1], cxxr[u][2], cxxr[u][3]};
+                    apt[u] = Fs + l4 + LDK * (16 * ti + l15);             // A[i][k] = F[k, 16ti+i]
+                    bpt[u] = WT + 16 * tj + l15 + LD * l4;                // B[k][j] = W[k, 16tj+j]
+                }
+                if (wv == 1) {
+                    mfma_chain_shared<16, 2, 1, LD * 4, 4, false>(bpt[0], apt, acc3);               // (0,0)
+                    mfma_chain_shared<16, 2, 2, LD * 4, 4, false>(bpt[1], apt + 1, acc3 + 1);       // (0,1) (1,1): B = W[:, 16..31] shared
+                } else if (wv == 2) mfma_chain_shared<16, 2, 3, LD * 4, 4, false>(bpt[0], apt, acc3);
+                else mfma_chain_shared<16, 2, 4, LD * 4, 4, false>(bpt[0], apt, acc3);
+            }
         }
         MFP(2);
         __syncthreads();
@@ -476,7 +509,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
         if (flag[0] != 0.0) { diverge = i + 1; break; }              // block-uniform
 
         // ================= phase 3: Vxx_i = cxx + fx'W + ½(K'Y + Y'K), symmetrised (:69-72, :210); Vx_i ==========
-        {
+        if (!EARLY3) {
             d4 acc[3];
             const double *apt[3], *bpt[3];
             double kA[3][2], yA[3][2], kB[3][2], yB[3][2], *qp[3], *mp[3];
@@ -520,7 +553,30 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
                 }
             }
         }
-        if (wv == 3) {                                               // Vx_i (:69)
+        // ================= EARLY3, phase 3b: + ½(K'Y + Y'K) on the accumulators of phase 3a, symmetrised ==========
+        if (EARLY3 && wv != 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int ti, tj;
+                if (!tile_w(wv, u, ti, tj)) continue;
+                const int gj = 16 * tj + l15, gi0 = 16 * ti + l4;
+                double *qp = Vs + gj + LDV * gi0;                     // Vxx[gi, gj] stored at (gj, gi): lanes contiguous
+                double *mp = Vs + gi0 + LDV * gj;                     // mirror position (gi, gj)
+                const int ia = l4 + KS * (16 * ti + l15), ib = l4 + KS * gj;
+                d4 c = acc3[u];
+                c = mf(Ks[ia], 0.5 * Ys[ib], c);
+                c = mf(Ks[ia + 4], 0.5 * Ys[ib + 4], c);
+                c = mf(Ys[ia], 0.5 * Ks[ib], c);
+                c = mf(Ys[ia + 4], 0.5 * Ks[ib + 4], c);
+                const double av[4] = {c.x, c.y, c.z, c.w};
+                const bool diag = ti == tj;                           // see the note on diagonal tiles above
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!diag || l4 + 4 * r <= l15) { qp[LDV * 4 * r] = av[r]; mp[4 * r] = av[r]; }
+                }
+            }
+        }
+        if (wv == (EARLY3 ? 0 : 3)) {                                // Vx_i (:69)
             double s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
             for (int q = 0; q < m; ++q) {
@@ -532,7 +588,7 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             vs[lane] = v; Vxg[(size_t)n * i + lane] = v;
         }
         MFP(4);
-        __syncthreads();                                             // every wave is done reading Fs
+        if (!EARLY3) __syncthreads();                                // every wave is done reading Fs (EARLY3: its last reader, phase 3a, sits in front of the barrier above)
         MFP(5);
         if (ldF) store_F(pfF);
         MFP(6);
