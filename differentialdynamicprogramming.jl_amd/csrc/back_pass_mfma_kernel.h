@@ -31,6 +31,7 @@
 #pragma once
 #include "ddp_internal.h"
 #include "boxqp_dev.h"
+#include <type_traits>
 #include "boxqp_rows.h"
 
 struct BPMArgs {
@@ -554,27 +555,46 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             }
         }
         // ================= EARLY3, phase 3b: + ½(K'Y + Y'K) on the accumulators of phase 3a, symmetrised ==========
-        if (EARLY3 && wv != 0) {
+        auto phase3b = [&](auto wc) __attribute__((always_inline)) {
+            constexpr int W_ = decltype(wc)::value;               // the wave as a compile-time constant: its tile list unrolls without tests
+            double kA[4][2], yA[4][2], kB[4][2], yB[4][2], *qp[4], *mp[4];
+            bool diag[4], valid[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int ti, tj;
-                if (!tile_w(wv, u, ti, tj)) continue;
+                valid[u] = tile_w(W_, u, ti, tj);
+                diag[u] = ti == tj;
+                if (!valid[u]) continue;
                 const int gj = 16 * tj + l15, gi0 = 16 * ti + l4;
-                double *qp = Vs + gj + LDV * gi0;                     // Vxx[gi, gj] stored at (gj, gi): lanes contiguous
-                double *mp = Vs + gi0 + LDV * gj;                     // mirror position (gi, gj)
+                qp[u] = Vs + gj + LDV * gi0;                          // Vxx[gi, gj] stored at (gj, gi): lanes contiguous
+                mp[u] = Vs + gi0 + LDV * gj;                          // mirror position (gi, gj)
                 const int ia = l4 + KS * (16 * ti + l15), ib = l4 + KS * gj;
-                d4 c = acc3[u];
-                c = mf(Ks[ia], 0.5 * Ys[ib], c);
-                c = mf(Ks[ia + 4], 0.5 * Ys[ib + 4], c);
-                c = mf(Ys[ia], 0.5 * Ks[ib], c);
-                c = mf(Ys[ia + 4], 0.5 * Ks[ib + 4], c);
-                const double av[4] = {c.x, c.y, c.z, c.w};
-                const bool diag = ti == tj;                           // see the note on diagonal tiles above
+                kA[u][0] = Ks[ia]; kA[u][1] = Ks[ia + 4]; yA[u][0] = Ys[ia]; yA[u][1] = Ys[ia + 4];
+                kB[u][0] = 0.5 * Ks[ib]; kB[u][1] = 0.5 * Ks[ib + 4]; yB[u][0] = 0.5 * Ys[ib]; yB[u][1] = 0.5 * Ys[ib + 4];
+            }
+            // the four products of a tile depend on each other: run the tiles of the wave side by side
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (valid[u]) acc3[u] = mf(kA[u][0], yB[u][0], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (valid[u]) acc3[u] = mf(kA[u][1], yB[u][1], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (valid[u]) acc3[u] = mf(yA[u][0], kB[u][0], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (valid[u]) acc3[u] = mf(yA[u][1], kB[u][1], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!valid[u]) continue;
+                const double av[4] = {acc3[u].x, acc3[u].y, acc3[u].z, acc3[u].w};      // see the note on diagonal tiles above
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (!diag || l4 + 4 * r <= l15) { qp[LDV * 4 * r] = av[r]; mp[4 * r] = av[r]; }
+                    if (!diag[u] || l4 + 4 * r <= l15) { qp[u][LDV * 4 * r] = av[r]; mp[u][4 * r] = av[r]; }
                 }
             }
+        };
+        if (EARLY3) {
+            if (wv == 1) phase3b(std::integral_constant<int, 1>{});
+            else if (wv == 2) phase3b(std::integral_constant<int, 2>{});
+            else if (wv == 3) phase3b(std::integral_constant<int, 3>{});
         }
         if (wv == (EARLY3 ? 0 : 3)) {                                // Vx_i (:69)
             double s1 = 0.0, s2 = 0.0, s3 = 0.0;
