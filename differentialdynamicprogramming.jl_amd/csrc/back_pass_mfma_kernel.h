@@ -23,6 +23,9 @@
 //            saturates at two operand reads per MFMA (measured 115 cycles per MFMA against 72 of the pipe), not the
 //            matrix cores.  The upper triangle is mirrored (exactly symmetric Vxx); Vx_i on wave 3
 //   then the next Jacobian goes to Fs (two more barriers: everybody is done reading Fs / before it is read again).
+// With control limits (EARLY3) the box-QP makes wave 0's phase 2 the longest part of the step, so the cut is different there: the
+// tiles of Vxx_i belong to the waves 1..3 by W column, each goes from its W column straight to cxx + fx'W of its tiles (phase 3a, no
+// barrier in between), phase 3b behind the gains barrier is only the rank-16 update, and Fs is free one barrier earlier.
 // Measured (profiles/microbench/mfma_f64_bench.hip): 30 ns per MFMA per wave with ONE wave per SIMD (66-70 TF/s of the
 // 78.6 TF/s peak) — unlike the fp64 VALU, the matrix pipe does not need several waves to fill.
 // Included by back_pass_mfma.hip (no control limits; built with -amdgpu-mfma-vgpr-form) and back_pass_mfma_lims.hip
