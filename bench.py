@@ -121,17 +121,20 @@ class PassBench:
 
     def timed(self, steps, warmup, fence, dist=None):
         _lib, L, h = self._lib, self.L, self.h
-        for _ in range(warmup):
-            self.step(None, dist)
-        # HIP events bracket the kernels of every `every`-th step (at least 8 samples): an event record costs a few microseconds of
-        # stream time, three of them per 0.7 ms step are 1-2 % of the very number being measured
-        every = max(1, min(4, steps // 8))
+        # HIP events bracket the kernels of THREE steps spread over the timed region: an event record costs ~25 µs of stream time here
+        # (profiles/sync_latency.py: 0.697 ms per step without events; 15 records in a region added 0.38 ms whatever its length), three
+        # of them on every 0.7 ms step would be 10 % of the very number being measured.  Launch times are stable to +-0.5 %.
+        every = max(1, steps // 3)
+        if os.environ.get("DDP_BENCH_NOEVENTS") == "1":       # diagnosis of the fixed cost of a timed region
+            every = 10 ** 9
         events = {}
-        for i in range(0, steps, every):
+        for i in range(min(every // 2, steps - 1) if every < 10 ** 9 else steps, steps, every):
             ev = [C.c_void_p() for _ in range(3)]
             for e in ev:
                 _lib.check(L.ddp_event_create(h.raw, C.byref(e)))
             events[i] = ev
+        for _ in range(warmup):                                  # right in front of the timed region (the events exist already): no idle gap
+            self.step(None, dist)
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -147,7 +150,7 @@ class PassBench:
                 L.ddp_event_destroy(h.raw, e)
         assert int(self.ddiv.sum().item()) == 0, "synthetic LQ batch must not diverge"
         assert np.isfinite(float(self.dcsn.sum().item()))
-        return elapsed, float(np.mean(bp_ms)), float(np.mean(fp_ms))
+        return elapsed, float(np.mean(bp_ms)) if bp_ms else float("nan"), float(np.mean(fp_ms)) if fp_ms else float("nan")
 
     def roofline(self, bp_avg_ms, fp_avg_ms):
         """algorithmic bytes of SURVEY.md §8(d) / DESIGN.md for the dominant kernel (back_pass)"""
@@ -162,7 +165,7 @@ class PassBench:
                 "g": "back_pass_kernel<10,2>"}.get(force, "back_pass_mx_kernel<LTI>" if B < 5120 else "back_pass_dpp_kernel<10,2,LTI>")
         return {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": bp_bytes_launch,
-                "avg_launch_ms": round(bp_avg_ms, 4), "avg_launch_ms_samples": "HIP events around every 4th launch of the timed region (every launch when steps < 32)",
+                "avg_launch_ms": round(bp_avg_ms, 4), "avg_launch_ms_samples": "HIP events around three launches spread over the timed region",
                 "forward_kernels": {"kernels": "forward_dpp_kernel (cost fused, ddp_problem::cost_diag)" if os.environ.get("DDP_FORWARD_FUSE", "1") != "0"
                                     else "forward_dpp_kernel + cost_kernel", "avg_launch_ms": round(fp_avg_ms, 4),
                                     "bytes_per_launch": fp_bytes * N * B,
@@ -228,7 +231,15 @@ def main():
         from ddp_amd import sharding
         pb.comm = sharding.CApiComm(h, rank, world)
     if args.preheat > 0:
-        pb.timed(1, args.preheat, fence, dist if use_dist else None)       # untimed: clocks ramped, caches and TLBs as in steady operation
+        # Untimed passes, then untimed dress rehearsals of the timed region (same K, bounded).  What they are for (profiles/sync_latency3.py):
+        # a region that follows an idle gap of even a few milliseconds runs 5-7 % slower (0.735-0.75 ms per step after 50 ms of sleep
+        # against 0.69-0.70 back to back: the clocks fall quickly), and so does the first region after a long burst followed by a
+        # host-side pause; regions run back to back repeat to +-1 %.
+        pb.timed(1, args.preheat, fence, dist if use_dist else None)
+        for r in range(int(os.environ.get("DDP_BENCH_REHEARSALS", "3"))):
+            e_, _, _ = pb.timed(max(1, min(args.steps, 50)), args.warmup, fence, dist if use_dist else None)
+            if os.environ.get("DDP_BENCH_VERBOSE") == "1":
+                print("rehearsal %d: %.4f ms per step" % (r, 1e3 * e_ / max(1, min(args.steps, 50))), file=sys.stderr)
     elapsed, bp_ms, fp_ms = pb.timed(args.steps, args.warmup, fence, dist if use_dist else None)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
