@@ -580,8 +580,11 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
 #define Q4P(L_, R_, E_) hipLaunchKernelGGL((back_pass_q4p_kernel<L_, R_, E_>), grid, block, 0, h->stream, a)
 #define Q4S(L_, C_, R_) hipLaunchKernelGGL((back_pass_q4_kernel<L_, C_, R_>), grid, block, 0, h->stream, a)
     const bool reg2 = d->regType == 2;
-    const char *lv = getenv("DDP_Q4_LDS");                     // 0: never the LDS-chunk kernel (A/B, tests)
-    const bool chunked = paired && d->fx_tv && (d->N % Q4L_CH == 0) && d->N >= 2 * Q4L_CH && exp == 0 && !(lv && lv[0] == '0');
+    const char *lv = getenv("DDP_Q4_LDS");                     // 0 / 1: never / whenever possible the LDS-group kernel (A/B, tests)
+    // the LDS-group kernel is the latency kernel: 24 KB of LDS per wave let 6 of them share a CU, and from two waves per SIMD on the
+    // pair kernel hides its issue gaps behind the other wave (B = 8192: 0.66 ms against 0.90 ms; B = 6144: 0.61 against 0.53, B = 4096: 0.44 against 0.39)
+    const bool few = lv ? lv[0] == '1' : d->B <= 6144;
+    const bool chunked = paired && d->fx_tv && (d->N % Q4L_CH == 0) && d->N >= 2 * Q4L_CH && exp == 0 && few;
     if (chunked) {
 #define Q4L(L_, R_) hipLaunchKernelGGL((back_pass_q4l_kernel<L_, R_>), grid, block, 0, h->stream, a)
         if (d->has_lims && reg2) Q4L(true, true); else if (d->has_lims) Q4L(true, false); else if (reg2) Q4L(false, true); else Q4L(false, false);

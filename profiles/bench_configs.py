@@ -169,6 +169,6 @@ def solve(name, prob, n, m, N, B, dx0, du0, nalpha=11, max_iter=50):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c4"]
     if "c3" in which:
-        c3()
+        c3(int(os.environ.get("DDP_C3_B", 4096)))
     if "c4" in which:
         c4()
