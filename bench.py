@@ -119,6 +119,36 @@ class PassBench:
                 # (+30 µs per step instead of +12..23) than the all-reduce itself
                 dist.all_reduce(self.stats)
 
+    def line_search_variant(self, fence, steps=20, warmup=5):
+        """the "full line-search" variant — one back_pass + the rollouts of ALL 11 step sizes of the reference's
+        default α = exp10.(range(0, stop=-3, length=11)) (iLQG.jl:148) per trajectory; informational, outside the timed region."""
+        torch, _lib, L, h, p = self.torch, self._lib, self.L, self.h, self.p
+        n, m, N, B = self.n, self.m, self.N, self.B
+        alpha = 10.0 ** np.linspace(0, -3, 11)
+        na = len(alpha)
+        xn = torch.empty(n * N * B * na, dtype=torch.float64, device=self.dev)
+        un = torch.empty(m * N * B * na, dtype=torch.float64, device=self.dev)
+        cn = torch.empty(N * B * na, dtype=torch.float64, device=self.dev)
+        cs = torch.empty(B * na, dtype=torch.float64, device=self.dev)
+
+        def step():
+            _lib.check(L.ddp_back_pass_f64_dev(h.raw, C.byref(self.desc), p(self.dcx), p(self.dcu), p(self.dQ), p(self.dcxu), p(self.dR),
+                                               p(self.dA), p(self.dB), p(self.dlam), None, None, None, p(self.dK), p(self.dk),
+                                               p(self.dQuu), p(self.dVx), p(self.dVxx), p(self.ddV), p(self.ddiv)))
+            _lib.check(L.ddp_forward_pass_f64_dev(h.raw, C.byref(self.prob), p(self.dK), p(self.dk), p(self.dx0), p(self.du), p(self.dx),
+                                                  _lib.ptr(alpha), na, None, None, p(xn), p(un), p(cn), p(cs)))
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        assert np.isfinite(float(cs.sum().item()))
+        return {"definition": "1 back_pass + forward_pass for all 11 step sizes alpha = 10^(0..-3) per trajectory (SURVEY.md 8d, iLQG.jl:148)",
+                "value": round(B * steps / el, 1), "unit": "iterations/s", "ms_per_step": round(1e3 * el / steps, 4), "n_alpha": na}
+
     def timed(self, steps, warmup, fence, dist=None):
         _lib, L, h = self._lib, self.L, self.h
         # HIP events bracket the kernels of THREE steps spread over the timed region: an event record costs ~25 µs of stream time here
@@ -267,6 +297,12 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(pb, args.cpu_sample)
+        ls = None
+        if world == 1 and not args.no_other_configs:
+            try:
+                ls = pb.line_search_variant(fence)
+            except Exception as exc:                            # informational: never in the way of the headline
+                ls = {"error": str(exc)[-200:]}
         fill = None
         if world == 1 and args.fill_batch and args.fill_batch != B:
             A_, Bm_, Q_, R_, x0_ = pb.host
@@ -291,7 +327,7 @@ def main():
                                       "limits, regType=1, lambda=1; one step = back_pass + forward_pass(alpha=1) over the batch" % (N, B),
                           "batch_per_gpu": B, "n": n, "m": m, "N": N, "sharding": "batch (independent trajectories), "
                           "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1 (issued by %s)" % ("the C ABI, ddp_allreduce_stats_f64_dev" if args.collective == "capi" else "torch.distributed")},
-               "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill, "other_configs": other}
+               "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill, "full_line_search": ls, "other_configs": other}
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -89,10 +89,12 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     const int N = a.N, B = a.B;
     const int lane = threadIdx.x, grp = lane / G, j = lane % G;
     const long total = (long)B * a.nalpha;
-    long rho = (long)blockIdx.x * GPW + grp;
-    const bool valid = rho < total;
-    if (!valid) rho = total - 1;                                // keep all lanes alive (DPP reads every lane)
-    const int b = (int)(rho % B), ai = (int)(rho / B);
+    // the step sizes of ONE trajectory are neighbours (rows of the same wave, neighbouring waves): their loads of K_i, k_i, x_i, ū_i hit
+    // the same cache lines, and a finished trajectory takes whole waves out of a line search
+    long lin = (long)blockIdx.x * GPW + grp;
+    const bool valid = lin < total;
+    if (!valid) lin = total - 1;                                // keep all lanes alive (DPP reads every lane)
+    const int b = (int)(lin / a.nalpha), ai = (int)(lin % a.nalpha);
     const bool act = valid && !(a.active && a.active[b] == 0);
     if (!__any(act)) return;                                    // every rollout of this wave belongs to a finished trajectory
     const double alpha = a.alpha[ai];
