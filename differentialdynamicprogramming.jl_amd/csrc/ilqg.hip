@@ -465,8 +465,11 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     const size_t min_slots = (cenv && atoi(cenv) > 1) ? (size_t)atoi(cenv) : (size_t)(2048.0 * tpw);
     const char *genv = getenv("DDP_ILQG_LSGROUPS");
     const double rpw = pend ? 64.0 : (n <= 16 ? 4.0 : 1.0);                       // rollouts per wave of the forward kernels
-    (void)rpw;
-    const bool groups = na > 1 && genv && genv[0] == '1';                                  // measured: no gain even at B = 32768 (0.93 vs 0.88 s of rollouts) -> off unless forced
+    // Measured: it pays where the rollouts of all step sizes together are throughput-bound (two waves per SIMD and more) AND the first
+    // step size is usually accepted, as in the linear-quadratic family (1 024 n=10 solves with 11 step sizes: 15.7 -> 10.6 ms); the
+    // pendulum's line search regularly needs the later ones (B = 32 768: 0.93 vs 0.88 s of rollouts) and its lane-per-rollout
+    // launches are latency-bound below that (B = 4 096: 0.083 -> 0.19 s).  Results are the same either way.
+    const bool groups = na > 1 && (genv ? genv[0] == '1' : (p->kind == DDP_PROBLEM_LQ && (double)na * (double)B / rpw >= 2048.0));
     int32_t *more = (int32_t *)take(0);                    // two masks of B int32 were reserved behind x0c (see `bytes`)
     int32_t *more2 = more + B;
 

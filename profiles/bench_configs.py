@@ -111,6 +111,7 @@ def c4(B=1024):
     import scipy.linalg as sla
     n, m, N = 64, 8, 256
     rng = np.random.default_rng(1)
+    torch.manual_seed(1)                                        # the per-trajectory perturbation of A below: same problem in every run
     h_ = 0.01
     a0 = rng.standard_normal((n, n))
     A = sla.expm(h_ * (a0 - a0.T))
