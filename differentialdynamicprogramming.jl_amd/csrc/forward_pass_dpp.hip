@@ -202,9 +202,21 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
             for (int q = 0; q < m; ++q) uu[q] = o.u[q];
         }
 #pragma unroll
-        for (int q = 0; q < m; ++q) {
-            if (LIMS) uu[q] = clampd(uu[q], lo[q], hi[q]);
-            if (uu[q] != uu[q]) uu[q] = 0.0;
+        for (int q = 0; q < m; ++q) if (LIMS) uu[q] = clampd(uu[q], lo[q], hi[q]);
+        {   // u[isnan.(u)] .= 0 (demo_linear.jl:36, system_pendcart.jl:120).  A NaN control is rare: one test of the sum (NaN if any
+            // entry is; Inf - Inf is a false alarm the slow path sorts out) and a wave-uniform branch instead of a compare and two
+            // selects per entry in every step
+            if constexpr (m == 1) {
+                if (uu[0] != uu[0]) uu[0] = 0.0;                         // one entry: the plain select is as cheap (measured)
+            } else {
+                double t = uu[0];
+#pragma unroll
+                for (int q = 1; q < m; ++q) t += uu[q];
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(t != t) != 0, 0)) {
+#pragma unroll
+                    for (int q = 0; q < m; ++q) if (uu[q] != uu[q]) uu[q] = 0.0;
+                }
+            }
         }
         {
             double v = xh;
