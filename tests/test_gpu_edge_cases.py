@@ -427,3 +427,33 @@ def test_fused_cost_equals_cost_kernel(ddp, monkeypatch, family, lane, N):
         for j, a in enumerate(al):
             xr, ur, cr = oc.forward_pass(p, (K[..., b], k[..., b]), x0[:, b], u[..., b], x[..., b], float(a), lims)
             assert relerr(cn[:, b, j], cr) < 1e-12 and relerr(xn[..., b, j], xr) < RTOL
+
+
+def test_results_are_reproducible_bit_for_bit(ddp):
+    """No atomics, no order-dependent reductions on the path: the same call twice gives the same bits — backward pass (matrix-core
+    kernels of both families), rollout with the fused cost, and whole batched solves with their per-trajectory bookkeeping."""
+    rng = np.random.default_rng(77)
+    # n = 10, m = 2 (back_pass_mx + forward_dpp) and n = 4, m = 1 with limits (back_pass_q4l + pendcart rollout)
+    B, N = 9, 64
+    for (n, m, lims) in ((10, 2, None), (4, 1, np.array([[-0.3, 0.3]]))):
+        h = 0.05
+        fx = np.eye(n)[:, :, None, None] + h * rng.standard_normal((n, n, N, B)) / np.sqrt(n)
+        fu = h * rng.standard_normal((n, m, N, B))
+        a = rng.standard_normal((n, n)); cxx = h * (a @ a.T / n + 0.5 * np.eye(n))
+        cuu = 0.1 * h * np.eye(m); cxu = np.zeros((n, m))
+        cx = h * rng.standard_normal((n, N, B)); cu = 0.1 * h * rng.standard_normal((m, N, B)); u = 0.2 * rng.standard_normal((m, N, B))
+        outs = [ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, lims, None, u) for _ in range(2)]
+        (d0, p0, vx0, vxx0, dv0), (d1, p1, vx1, vxx1, dv1) = outs
+        for x_, y_ in ((d0, d1), (p0.K, p1.K), (p0.k, p1.k), (p0.Σi, p1.Σi), (vx0, vx1), (vxx0, vxx1), (dv0, dv1)):
+            assert np.array_equal(x_, y_, equal_nan=True)
+    # whole solves
+    import scipy.linalg as sla
+    n, m, T, B = 10, 2, 120, 7
+    A0 = rng.standard_normal((n, n)); A = sla.expm(0.01 * (A0 - A0.T)); Bm = 0.01 * rng.standard_normal((n, m))
+    prob = ddp.LQProblem(A, Bm, 0.01 * np.eye(n), 0.001 * np.eye(m))
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B)); u0 = 0.1 * rng.standard_normal((m, T, B))
+    r0 = ddp.iLQG(prob, x0, u0, lims=0.05 * np.array([[-1.0, 1.0], [-1.0, 1.0]]))
+    r1 = ddp.iLQG(prob, x0, u0, lims=0.05 * np.array([[-1.0, 1.0], [-1.0, 1.0]]))
+    for k_ in (0, 1, 3, 4, 5):
+        assert np.array_equal(r0[k_], r1[k_], equal_nan=True), k_
+    assert np.array_equal(r0[2].K, r1[2].K) and np.array_equal(r0[6]["stats"], r1[6]["stats"])
