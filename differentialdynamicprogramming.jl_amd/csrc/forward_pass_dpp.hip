@@ -184,6 +184,8 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     auto step = [&](int i, const Ops &o, bool advance) {
         // ---- controls (forward_pass.jl:17-24): u = ū + α k + K (x̂ - x), clamp, NaN -> 0 (inside f)
         double uu[m];
+        double ax = 0.0;                                                 // (A x̂)_j once it has been formed
+        bool ax_done = false;
         if (POLICY) {
             double pr[m];
             const double dx = xh - o.x;
@@ -215,7 +217,16 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
                 double t = uu[0];
 #pragma unroll
                 for (int q = 1; q < m; ++q) t += uu[q];
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(t != t) != 0 || !minmax_ok, 0)) {
+                unsigned long long nanmask = __builtin_amdgcn_ballot_w64(t != t);
+                asm volatile("" : "+s"(nanmask));                         // the compare is issued HERE ...
+                if (KIND == DDP_PROBLEM_LQ && advance && (FAST || !a.dyn_tv)) {
+                    // ... and the part of the dynamics that does not depend on the controls runs while its result travels to the
+                    // scalar unit (the branch below would otherwise wait for it)
+                    double s0 = 0.0, s1 = 0.0;
+                    RowDot<n>::run(s0, s1, xh, Arow);                     // Σ_l A[j,l] x̂_l
+                    ax = s0 + s1; ax_done = true;
+                }
+                if (__builtin_expect(nanmask != 0 || !minmax_ok, 0)) {
 #pragma unroll
                     for (int q = 0; q < m; ++q) {
                         if (LIMS) uu[q] = clampd(uu[q], lo[q], hi[q]);
@@ -244,11 +255,21 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
             double xp;
             if (KIND == DDP_PROBLEM_LQ) {
                 if (!FAST && a.dyn_tv) load_dyn(i);
-                double s0 = 0.0, s1 = 0.0, t = 0.0;
-                RowDot<n>::run(s0, s1, xh, Arow);                        // Σ_l A[j,l] x̂_l
+                double t = 0.0;
+                if (!ax_done) {
+                    double s0 = 0.0, s1 = 0.0;
+                    RowDot<n>::run(s0, s1, xh, Arow);                    // Σ_l A[j,l] x̂_l
+                    ax = s0 + s1;
+                }
+                if (ax_done) {                                           // two dependent multiply-adds on the chain u -> x̂⁺ instead of three operations
+                    xp = ax;
 #pragma unroll
-                for (int q = 0; q < m; ++q) t += Brow[q] * uu[q];
-                xp = (s0 + s1) + t;                                      // A*x + B*u
+                    for (int q = 0; q < m; ++q) xp = fma(Brow[q], uu[q], xp);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < m; ++q) t += Brow[q] * uu[q];
+                    xp = ax + t;                                         // A*x + B*u
+                }
             } else {                                                     // system_pendcart.jl:83-89
                 const double x0v = row_bcast<0>(xh), x1v = row_bcast<1>(xh), x3v = row_bcast<3>(xh);
                 const double gl = a.g / a.l, h = a.h;
