@@ -343,9 +343,22 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         // positive definite <=> F00 > 0 and det > 0 — the pivots of cholesky(Hermitian(QuuF)) (:35-38)
         const double det = fma(F00, F11, -(F01 * F01));
         const bool bad = !(F00 > 0.0) || !(det > 0.0);
-        const double nidet = -rcp_nr(det);
-        const double K0 = fma(F11, Q0, -(F01 * Q1)) * nidet;
-        const double K1 = fma(F00, Q1, -(F01 * Q0)) * nidet;
+        // 1/det (hardware estimate + two Newton steps, rcp_nr) with the numerators of the 2x2 solve in the stalls of its dependent
+        // chain: the compiler's schedule put them behind it (a dependent fp64 instruction issues ~10 cycles after its producer, an
+        // independent one after 6)
+        auto pin = [](double &x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
+        double y = __builtin_amdgcn_rcp(det); pin(y);
+        double t01 = F01 * Q1; pin(t01);
+        double e1 = fma(-det, y, 1.0); pin(e1);
+        double t10 = F01 * Q0; pin(t10);
+        y = fma(y, e1, y); pin(y);
+        double n0 = fma(F11, Q0, -t01); pin(n0);
+        double e2 = fma(-det, y, 1.0); pin(e2);
+        double n1 = fma(F00, Q1, -t10); pin(n1);
+        y = fma(y, e2, y);
+        const double nidet = -y;
+        const double K0 = n0 * nidet;
+        const double K1 = n1 * nidet;
         // my u-row: K_a, T_a = Qux_a + Quu[a,:]·K  (:64); a = parity of the 16-lane row
         const double Ksel = odd ? K1 : K0;
         double Tsel = Z;
