@@ -19,7 +19,7 @@ void ddp_set_error(const char *fmt, ...)
 extern "C" {
 
 const char *ddp_last_error(void) { return g_err; }
-const char *ddp_version(void) { return "ddp_amd 0.1.0 (gfx950, fp64)"; }
+const char *ddp_version(void) { return "ddp_amd 0.2.0 (gfx950, fp64)"; }
 
 int ddp_device_count(void)
 {
