@@ -109,6 +109,11 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
                             const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
                             const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);
 
+// LQ n=10/m=2 rollout as a producer/consumer pipeline of one work-group per 4 rollouts (forward_pass_pipe.hip); 1 = not applicable
+int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
+                            const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
+                            const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);
+
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps -> ~1 ulp.  The caller checks x > 0.
 __device__ __forceinline__ double ddp_rsqrt(double x)
 {

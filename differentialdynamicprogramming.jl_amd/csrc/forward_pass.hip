@@ -250,6 +250,8 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     const char *fwd_env = getenv("DDP_FORWARD");               // read per call so tests can switch paths
     const bool force_group = fwd_env && fwd_env[0] == 103;
     if (!force_group) {
+        const int rp = ddp_launch_forward_pipe(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
+        if (rp <= 0) return rp;
         const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rc <= 0) return rc;
     }

@@ -1,0 +1,475 @@
+// forward_pass_pipe.hip — closed-loop rollout of the linear-quadratic family (n = 10, m = 2, a policy, no control limits,
+// time-invariant dynamics) as a PRODUCER / CONSUMER PIPELINE inside one work-group.  src/forward_pass.jl:9-33 with
+// f, costfun of src/demo_linear.jl:42-49.
+//
+// Why: the rollout is a strict chain x̂_i -> x̂_{i+1}.  At the BASELINE batch (1 024 rollouts, 4 per wave) the row kernel of
+// forward_pass_dpp.hip runs ONE wave per CU — three of the four SIMDs idle — and that wave spends ~400 cycles per step, a good
+// part of it on work that is not on the chain: operand addresses and loads, the NaN test of the controls, the stores, the cost.
+// Here a work-group of four waves (one per SIMD) shares 4 rollouts; the time axis is cut into chunks of G steps and the waves meet
+// at one s_barrier per chunk ("period"):
+//   DMA wave     K_i, x_i, ū_i, k_i of chunk c+2 -> LDS by direct-to-LDS loads (global_load_lds_dwordx4: 1 KB per instruction,
+//                unit-stride, no address arithmetic per step), two periods of flight time per chunk
+//   2 chain waves C(c): two rollouts each, TWO 16-lane rows per rollout: row h forms control h,
+//                u_h = ū_h + α k_h + Σ_l K_i[h,l] dx_l (10 v_fmac_f64_dpp row_newbcast instead of 20), the rows swap their
+//                controls (v_permlane16_swap), both form x̂_{i+1} = A x̂_i + B u.  Operands come from the LDS image by four
+//                8-byte reads a step ahead; x̂_i and u_h go back to the LDS.  ~34 vector instructions per step.
+//   output wave  O(c-1): NaN test of the controls, per-step cost c_i = Σ ½Q_jj x̂_j² + Σ ½R_qq u_q² (ddp_problem::cost_diag) and its
+//                sum, coalesced stores of xnew / unew / cnew
+// Same statements and summation order as the row kernel for u_i and x̂_{i+1} (forward_pass.jl:17-24, demo_linear.jl:42-46).
+// `u[isnan.(u)] .= 0` inside f (demo_linear.jl:43) would put a compare and two selects on the chain: a NaN control is detected in O
+// and the rollout is then recomputed by a plain step-by-step loop with the reference's statement order (slow, practically never taken).
+//
+// (A variant that moved B·K_i and B(ū + αk) to helper waves — 23 instructions on the chain — was LDS-bound: the expanded 10x10
+// matrix per step costs ~13 LDS cycles per KB written, 0.17 ms per rollout pass against 0.166 for the row kernel.)
+#include <stdlib.h>
+#include "ddp_internal.h"
+
+#ifndef PIPE_EXP
+#define PIPE_EXP 0          // timing experiments (profiles/ab_pipe_exp.sh): 1 no O, 3 no chain arithmetic, 4 no DMA
+#endif
+
+#ifdef PIPE_PROF
+// phase profile of work-group 0 (profiles/ab_pipe_exp.sh prof): [wave][0] cycles working, [1] cycles waiting at the period barrier,
+// [2] time to issue a chunk's DMA
+__device__ long long pipe_prof[5][8];
+extern "C" int ddp_debug_pipe_prof(long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pipe_prof), sizeof(pipe_prof)); }
+#define PROF_DECL long long pf_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pt_ = __builtin_amdgcn_s_memtime();
+#define PROF(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); pf_[k] += t_ - pt_; pt_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PROF_DUMP(w) do { if (blockIdx.x == 0 && lane == 0) for (int q_ = 0; q_ < 8; ++q_) pipe_prof[w][q_] = pf_[q_]; } while (0)
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_DUMP(w)
+#endif
+
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct FPipeArgs {
+    int N, B, nalpha, dyn_batched;
+    const double *A, *Bm, *K, *k, *x0, *u, *x, *Q, *R;
+    const int32_t *active;
+    double alpha[16];
+    double *xnew, *unew, *cnew, *csum;
+    double *sink;                                   // >= 64 x 8 B of device memory for the lanes without an output
+};
+
+// acc += src0[lane L of this 16-lane row] * src1
+template <int L>
+__device__ __forceinline__ void fmac_bc(double &acc, double src0, double src1)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src0), "v"(src1), "n"(L));
+}
+// a VGPR written by a VALU instruction needs 2 wait states before a DPP instruction reads it (the hazard recogniser does
+// not look inside inline asm)
+__device__ __forceinline__ void dpp_fence(double &v) { asm volatile("s_nop 1" : "+v"(v)); }
+__device__ __forceinline__ void dpp_fence(double &a, double &b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int I, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn &&f)
+{
+    if constexpr (I < E) { f(IC<I>{}); static_for<I + 1, E>(f); }
+}
+
+// s{0,1} += Σ_{l<NN} src[lane l] * w[l], two interleaved accumulators
+template <int NN, int L = 0>
+struct RowDot {
+    static __device__ __forceinline__ void run(double &s0, double &s1, double src, const double (&w)[NN])
+    {
+        if constexpr (L < NN) {
+            if constexpr (L % 2 == 0) fmac_bc<L>(s0, src, w[L]); else fmac_bc<L>(s1, src, w[L]);
+            RowDot<NN, L + 1>::run(s0, s1, src, w);
+        }
+    }
+};
+template <int NN, int L = 0>
+struct RowSum {
+    static __device__ __forceinline__ void run(double &s0, double &s1, double src, double one)
+    {
+        if constexpr (L < NN) {
+            if constexpr (L % 2 == 0) fmac_bc<L>(s0, src, one); else fmac_bc<L>(s1, src, one);
+            RowSum<NN, L + 1>::run(s0, s1, src, one);
+        }
+    }
+};
+
+// A store the compiler's wait-count pass does not see.  With stores AND loads pending it assumes out-of-order returns and waits
+// vmcnt(0) in front of the first use of ANY load — which would drain the helpers' one-chunk-ahead prefetch every period.  Loads
+// return in order among themselves, so its counted waits (computed from the loads alone) stay sufficient with these stores in
+// flight: "at most n operations pending" still implies that every load older than the last n has returned.
+__device__ __forceinline__ void store_untracked(void *ptr, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
+}
+// 16 bytes per lane from global memory straight into the LDS at lds_base + 16·lane (wave-uniform base in M0)
+__device__ __forceinline__ void dma16(const void *g, unsigned lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory");
+}
+
+// the waves of the work-group meet; only LDS traffic is waited for (global loads / stores stay in flight)
+__device__ __forceinline__ void pipe_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int PN = 10, PM = 2, R4 = 4;
+
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+// v holds one value per 16-lane row; q0 <- the value of the even row of my pair of rows, q1 <- of the odd row (one
+// v_permlane16_swap per dword: .x = rows (0,0,2,2), .y = rows (1,1,3,3), profiles/microbench/permlane_swap_probe.hip)
+__device__ __forceinline__ void spread_pair(double v, double &q0, double &q1)
+{
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u2v e = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u2v f = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    q0 = __hiloint2double((int)f.x, (int)e.x);
+    q1 = __hiloint2double((int)f.y, (int)e.y);
+}
+
+// LDS map (bytes).  Raw image of a chunk, per rollout, in 16-byte slots: K (10 per step) | x (5 per step) | ū (1) | k (1)
+template <int G>
+struct Lds {
+    static constexpr int RAW_PER_ROLL = G * (10 + 5 + 1 + 1);
+    static constexpr int RAW_K = 0, RAW_X = G * 10, RAW_U = G * 15, RAW_KV = G * 16;
+    static constexpr int RAW_SLOTS = (R4 * RAW_PER_ROLL + 63) / 64 * 64;       // whole wave instructions
+    static constexpr int RAW_INSTR = RAW_SLOTS / 64;
+    static constexpr int RAW_BUF = RAW_SLOTS * 16, NRAW = 3;
+    static constexpr int RAW_OFF = 0;
+    // x̂_i[j] from the chain: [buf][step][rollout][row h][16] x 8 B; the strides are padded so that the output wave's lanes
+    // (one per rollout and step) spread over the banks
+    static constexpr int XH_OFF = RAW_OFF + NRAW * RAW_BUF;
+    static constexpr int XH_ROLL = 2 * 16 * 8 + 8, XH_STEP = R4 * XH_ROLL + 16, XH_BUF = G * XH_STEP;
+    static constexpr int XU_OFF = XH_OFF + 2 * XH_BUF;                         // u_i[h]: [buf][step][rollout][h] x 8 B
+    static constexpr int XU_STEP = R4 * 16 + 16, XU_BUF = G * XU_STEP;
+    static constexpr int CF_OFF = XU_OFF + 2 * XU_BUF;                         // per-lane parts of sum(cnew)
+    static constexpr int FLAG_OFF = CF_OFF + 64 * 8;
+    static constexpr int TOTAL = FLAG_OFF + 16;
+};
+
+// G: steps per chunk.  Wave 0: output, wave 1: DMA, waves 2, 3: the chains of rollouts {0, 1} and {2, 3} (a work-group's waves go
+// to the SIMDs in cyclic order, one each).
+template <int G, bool FUSE>
+__global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
+{
+    constexpr int n = PN, m = PM;
+    using L = Lds<G>;
+    static_assert(R4 * G <= 64 && L::TOTAL <= 80 * 1024, "chunk size");
+    __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+    const int N = a.N, B = a.B;
+    const int wave = threadIdx.x / DDP_WAVE, lane = threadIdx.x % DDP_WAVE;
+    const long total = (long)B * a.nalpha;
+    constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    // rollout r of this work-group: trajectory, step size, active?
+    auto roll = [&](int r, int &b, int &ai, bool &act) {
+        long lin = (long)blockIdx.x * R4 + r;
+        const bool valid = lin < total;
+        if (!valid) lin = total - 1;
+        b = (int)(lin / a.nalpha); ai = (int)(lin % a.nalpha);
+        act = valid && !(a.active && a.active[b] == 0);
+    };
+    {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R4; ++r) { int b, ai; bool act; roll(r, b, ai, act); any = any || act; }
+        if (!any) return;                                       // every rollout of this work-group belongs to a finished trajectory
+    }
+    const int NC = (N + G - 1) / G;                             // chunks
+    const int NPH = NC + 3;                                     // periods (= barriers) of every wave: p = -2 .. NC
+    int *nanflag = (int *)(smem + L::FLAG_OFF);
+    if (threadIdx.x < R4) nanflag[threadIdx.x] = 0;
+
+    if (wave >= 2) {
+        // ================================================ the chains ====================================================
+        const int row = lane / 16, j = lane % 16, h = row & 1, r = 2 * (wave - 2) + (row >> 1);
+        const bool inx = j < n;
+        const int jx = inx ? j : 0, jj = inx ? j : n - 1;       // idle lanes repeat lane n-1's reads (their values are never broadcast)
+        int b, ai; bool act; roll(r, b, ai, act);
+        const double alpha = a.alpha[ai];
+        const double *Ab = a.A + (a.dyn_batched ? nn * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * b : 0);
+        const double z = inx ? 1.0 : 0.0;
+        double Arow[n];
+#pragma unroll
+        for (int l = 0; l < n; ++l) Arow[l] = z * Ab[jx + n * l];
+        const double B0 = z * Bb[jx], B1 = z * Bb[jx + n];
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
+        double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0;
+        dpp_fence(xh);
+        // this lane's operands of step t of a chunk: K_i[h, j] | x_i[j] | ū_i[h] | k_i[h]
+        const char *rK = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_K + jj) * 16 + h * 8;
+        const char *rX = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + jj * 8;
+        const char *rU = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_U) * 16 + h * 8;
+        const char *rV = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_KV) * 16 + h * 8;
+        char *wX = smem + L::XH_OFF + r * L::XH_ROLL + h * 128 + j * 8;
+        char *wU = smem + L::XU_OFF + r * 16 + h * 8;
+        pipe_barrier();                                         // period -2
+        pipe_barrier();                                         // period -1: chunk 0 is in the LDS
+        PROF_DECL
+        for (int p = 0; p < NC; ++p) {
+            const unsigned raw = (unsigned)(p % L::NRAW) * L::RAW_BUF;
+            const char *pK = rK + raw, *pX = rX + raw, *pU = rU + raw, *pV = rV + raw;
+            char *oX = wX + (p & 1) * L::XH_BUF, *oU = wU + (p & 1) * L::XU_BUF;
+            double ops[2][4];
+            ops[0][0] = *(const double *)pK; ops[0][1] = *(const double *)pX; ops[0][2] = *(const double *)pU; ops[0][3] = *(const double *)pV;
+            if (PIPE_EXP != 3) static_for<0, G>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value, cu = t & 1, nx = cu ^ 1;
+                if constexpr (t + 1 < G) {
+                    ops[nx][0] = *(const double *)(pK + (t + 1) * 160); ops[nx][1] = *(const double *)(pX + (t + 1) * 80);
+                    ops[nx][2] = *(const double *)(pU + (t + 1) * 16); ops[nx][3] = *(const double *)(pV + (t + 1) * 16);
+                }
+                const double *o = ops[cu];
+                // controls (forward_pass.jl:18-19): u_h = ū_h + α k_h, then += K_i[h,:]·dx — row h of the pair of rows forms control h
+                const double dx = xh - o[1];
+                double pr = o[0] * dx;
+                double ua = fma(o[3], alpha, o[2]), ub = 0.0, a0 = 0.0, a1 = 0.0;
+                asm volatile("" : "+v"(ub), "+v"(a0), "+v"(a1));
+                *(double *)(oX + t * L::XH_STEP) = xh;
+                fmac_bc<0>(a0, xh, Arow[0]); fmac_bc<1>(a1, xh, Arow[1]);            // Σ_l A[j,l] x̂_l does not wait for the controls
+                dpp_fence(pr);
+                fmac_bc<0>(ua, pr, one); fmac_bc<2>(a0, xh, Arow[2]); fmac_bc<1>(ub, pr, one); fmac_bc<3>(a1, xh, Arow[3]);
+                fmac_bc<2>(ua, pr, one); fmac_bc<4>(a0, xh, Arow[4]); fmac_bc<3>(ub, pr, one); fmac_bc<5>(a1, xh, Arow[5]);
+                fmac_bc<4>(ua, pr, one); fmac_bc<6>(a0, xh, Arow[6]); fmac_bc<5>(ub, pr, one); fmac_bc<7>(a1, xh, Arow[7]);
+                fmac_bc<6>(ua, pr, one); fmac_bc<8>(a0, xh, Arow[8]); fmac_bc<7>(ub, pr, one); fmac_bc<9>(a1, xh, Arow[9]);
+                fmac_bc<8>(ua, pr, one); fmac_bc<9>(ub, pr, one);
+                const double uh = ua + ub;
+                *(double *)(oU + t * L::XU_STEP) = uh;
+                double u0, u1;
+                spread_pair(uh, u0, u1);
+                xh = fma(B1, u1, fma(B0, u0, a0 + a1));                                // A*x + B*u (demo_linear.jl:45)
+                dpp_fence(xh);
+            });
+            PROF(0);
+            pipe_barrier();
+            PROF(1);
+        }
+        PROF_DUMP(wave);
+        pipe_barrier();                                         // period NC: O of the last chunk
+    } else if (wave == 1) {
+        // ================================================ the DMA wave ==================================================
+        const char *src[L::RAW_INSTR];
+        unsigned stepb[L::RAW_INSTR], tau0[L::RAW_INSTR];        // bytes per step of the slot's array, the slot's step inside the chunk
+#pragma unroll
+        for (int k = 0; k < L::RAW_INSTR; ++k) {
+            int s = k * 64 + lane;
+            if (s >= R4 * L::RAW_PER_ROLL) s = R4 * L::RAW_PER_ROLL - 1;
+            const int r = s / L::RAW_PER_ROLL, w = s % L::RAW_PER_ROLL;
+            int b, ai; bool act; roll(r, b, ai, act);
+            if (w < L::RAW_X) { src[k] = (const char *)(a.K + nm * N * b) + 16 * w; stepb[k] = 160; tau0[k] = w / 10; }
+            else if (w < L::RAW_U) { src[k] = (const char *)(a.x + (size_t)n * N * b) + 16 * (w - L::RAW_X); stepb[k] = 80; tau0[k] = (w - L::RAW_X) / 5; }
+            else if (w < L::RAW_KV) { src[k] = (const char *)(a.u + (size_t)m * N * b) + 16 * (w - L::RAW_U); stepb[k] = 16; tau0[k] = w - L::RAW_U; }
+            else { src[k] = (const char *)(a.k + (size_t)m * N * b) + 16 * (w - L::RAW_KV); stepb[k] = 16; tau0[k] = w - L::RAW_KV; }
+        }
+        auto dma_chunk = [&](int c) __attribute__((always_inline)) {
+            const unsigned base = lds0 + L::RAW_OFF + (unsigned)(c % L::NRAW) * L::RAW_BUF;
+            const bool tail = (c + 1) * G > N;                   // the last chunk may reach past the horizon: such slots re-read its first step
+#pragma unroll
+            for (int k = 0; k < L::RAW_INSTR; ++k) {
+                const char *g = src[k] + (size_t)c * G * stepb[k];
+                if (tail && c * G + (int)tau0[k] >= N) g -= (size_t)tau0[k] * stepb[k];
+                if (PIPE_EXP != 4) dma16(g, base + k * 1024);
+            }
+        };
+        // period p issues chunk p+2 (its buffer was read by the chains in period p-1) and waits for chunk p+1, issued a period ago
+        // and read in period p+1: two periods of flight time per chunk
+        dma_chunk(0);
+        pipe_barrier();                                         // period -2
+        PROF_DECL
+        for (int p = -1; p <= NC; ++p) {
+            if (p + 2 < NC) {
+                dma_chunk(p + 2);
+                PROF(2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::RAW_INSTR) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PROF(0);
+            pipe_barrier();
+            PROF(1);
+        }
+        PROF_DUMP(1);
+    } else {
+        // ================================================ the output wave ===============================================
+        char *sink = (char *)(a.sink + lane);
+        // ---- xnew: item e = (r, tau, j), R4·G·10 of them; global pointer of chunk 0
+        constexpr int XI = R4 * G * n, XPASS = (XI + 63) / 64;
+        unsigned x_rd[XPASS], x_tau[XPASS];
+        char *x_dst[XPASS];
+        bool x_on[XPASS];
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            int e = 64 * q + lane;
+            const bool in = e < XI;
+            e = in ? e : XI - 1;
+            const int r = e / (G * n), tau = (e % (G * n)) / n, j = e % n;
+            int b, ai; bool act; roll(r, b, ai, act);
+            x_rd[q] = L::XH_OFF + tau * L::XH_STEP + r * L::XH_ROLL + j * 8;
+            x_tau[q] = tau;
+            x_on[q] = in && act;
+            x_dst[q] = (char *)(a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai) + (size_t)tau * n + j);
+        }
+        // ---- unew: item e = (r, tau, q), R4·G·2 of them
+        constexpr int UI = R4 * G * m, UPASS = (UI + 63) / 64;
+        unsigned u_rd[UPASS], u_tau[UPASS];
+        char *u_dst[UPASS];
+        bool u_on[UPASS];
+#pragma unroll
+        for (int q = 0; q < UPASS; ++q) {
+            int e = 64 * q + lane;
+            const bool in = e < UI;
+            e = in ? e : UI - 1;
+            const int r = e / (G * m), tau = (e % (G * m)) / m, qq = e % m;
+            int b, ai; bool act; roll(r, b, ai, act);
+            u_rd[q] = L::XU_OFF + tau * L::XU_STEP + r * 16 + qq * 8;
+            u_tau[q] = tau;
+            u_on[q] = in && act;
+            u_dst[q] = (char *)(a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai) + (size_t)tau * m + qq);
+        }
+        // ---- cost + NaN test: lane (r, tau), R4·G <= 64 of them
+        const int ce = lane < R4 * G ? lane : R4 * G - 1, cr_ = ce / G, ctau = ce % G;
+        int cb, cai; bool cact; roll(cr_, cb, cai, cact);
+        const bool c_on = lane < R4 * G && cact;
+        const unsigned c_rx = L::XH_OFF + ctau * L::XH_STEP + cr_ * L::XH_ROLL, c_ru = L::XU_OFF + ctau * L::XU_STEP + cr_ * 16;
+        char *c_dst = FUSE ? (char *)(a.cnew + (size_t)N * ((size_t)cb + (size_t)B * cai) + ctau) : nullptr;
+        double cq[n], cr0 = 0.0, cr1 = 0.0;                      // ½Q_ll, ½R_qq
+        if (FUSE) {
+#pragma unroll
+            for (int l = 0; l < n; ++l) cq[l] = 0.5 * a.Q[l + n * l];
+            cr0 = 0.5 * a.R[0]; cr1 = 0.5 * a.R[1 + m];
+        }
+        double cacc = 0.0;
+        auto output = [&](int c) __attribute__((always_inline)) {
+            const unsigned xhb = (unsigned)(c & 1) * L::XH_BUF, xub = (unsigned)(c & 1) * L::XU_BUF;
+            const bool tail = (c + 1) * G > N;
+            {   // cost of the step (demo_linear.jl:49, split per step), NaN controls
+                const d2 uv = *(const d2 *)(smem + c_ru + xub);
+                if (uv.x != uv.x || uv.y != uv.y) nanflag[cr_] = 1;      // u[isnan.(u)] .= 0 (demo_linear.jl:43): this rollout is redone below
+                if (FUSE) {
+                    double q0 = 0.0;
+#pragma unroll
+                    for (int l = 0; l < n; ++l) { const double xv = *(const double *)(smem + c_rx + xhb + l * 8); q0 += (cq[l] * xv) * xv; }
+                    const double ci = (q0 + (cr0 * uv.x) * uv.x) + (cr1 * uv.y) * uv.y;
+                    const bool on = c_on && (!tail || c * G + ctau < N);
+                    store_untracked(on ? c_dst + (size_t)c * (G * 8) : sink, ci);
+                    cacc += on ? ci : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UPASS; ++q) {                     // unew
+                const double v = *(const double *)(smem + u_rd[q] + xub);
+                const bool on = u_on[q] && (!tail || c * G + (int)u_tau[q] < N);
+                store_untracked(on ? u_dst[q] + (size_t)c * (G * m * 8) : sink, v);
+            }
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) {                     // xnew
+                const double v = *(const double *)(smem + x_rd[q] + xhb);
+                const bool on = x_on[q] && (!tail || c * G + (int)x_tau[q] < N);
+                store_untracked(on ? x_dst[q] + (size_t)c * (G * n * 8) : sink, v);
+            }
+        };
+        PROF_DECL
+        for (int p = -2; p <= NC; ++p) {                          // period p: O(p-1)
+            if (PIPE_EXP != 1 && p - 1 >= 0) output(p - 1);
+            PROF(0);
+            pipe_barrier();
+            PROF(1);
+        }
+        PROF_DUMP(0);
+        *(double *)(smem + L::CF_OFF + lane * 8) = cacc;
+    }
+    // ---- sum(cnew) per rollout, in step order
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the untracked stores have left before the redo path may rewrite them
+    __syncthreads();
+    if (FUSE && threadIdx.x < R4) {
+        const int r = threadIdx.x;
+        int b, ai; bool act; roll(r, b, ai, act);
+        double s = 0.0;
+        for (int t = 0; t < G; ++t) s += *(const double *)(smem + L::CF_OFF + (r * G + t) * 8);
+        if (act && nanflag[r] == 0) a.csum[(size_t)b + (size_t)B * ai] = s;
+    }
+    // ---- a NaN control somewhere: the rollouts concerned are recomputed step by step with the reference's statements
+    if (wave != 2) return;
+    {
+        const int row = lane / 16, j = lane % 16;
+        const bool redo = nanflag[row] != 0;
+        if (!__any(redo)) return;
+        const bool inx = j < n;
+        const int jx = inx ? j : 0;
+        int b, ai; bool act; roll(row, b, ai, act);
+        const bool wr = act && redo;
+        const double alpha = a.alpha[ai];
+        const double z = inx ? 1.0 : 0.0;
+        const double *Ab = a.A + (a.dyn_batched ? nn * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * b : 0);
+        const double *ug = a.u + (size_t)m * N * b, *xg = a.x + (size_t)n * N * b, *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b;
+        double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai), *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
+        double *co = FUSE ? a.cnew + (size_t)N * ((size_t)b + (size_t)B * ai) : nullptr;
+        double Arow[n], Brow[m];
+#pragma unroll
+        for (int l = 0; l < n; ++l) Arow[l] = z * Ab[jx + n * l];
+#pragma unroll
+        for (int q = 0; q < m; ++q) Brow[q] = z * Bb[jx + n * q];
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
+        double cw = 0.0;
+        if (FUSE) cw = inx ? 0.5 * a.Q[jx + n * jx] : (j < n + m ? 0.5 * a.R[(j - n) + m * (j - n)] : 0.0);
+        double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0, cacc = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const d2 Kc = *(const d2 *)(Kg + nm * i + m * jx), uc = *(const d2 *)(ug + (size_t)m * i), kc = *(const d2 *)(kg + (size_t)m * i);
+            const double dx = xh - xg[(size_t)n * i + jx];
+            double pr0 = Kc.x * dx, pr1 = Kc.y * dx;
+            dpp_fence(pr0, pr1);
+            double s0 = fma(kc.x, alpha, uc.x), s1 = 0.0, t0 = fma(kc.y, alpha, uc.y), t1 = 0.0;
+            RowSum<n>::run(s0, s1, pr0, one);
+            RowSum<n>::run(t0, t1, pr1, one);
+            double uu0 = s0 + s1, uu1 = t0 + t1;
+            if (uu0 != uu0) uu0 = 0.0;
+            if (uu1 != uu1) uu1 = 0.0;
+            const double v = inx ? xh : (j == n ? uu0 : (j == n + 1 ? uu1 : 0.0));
+            if (wr && inx) xo[(size_t)n * i + j] = v;
+            if (wr && j >= n && j < n + m) uo[(size_t)m * i + (j - n)] = v;
+            if (FUSE) {
+                double pc = (cw * v) * v, c0 = 0.0, c1 = 0.0;
+                dpp_fence(pc);
+                RowSum<n + m>::run(c0, c1, pc, one);
+                const double cs = c0 + c1;
+                if (wr && j == 0) co[i] = cs;
+                cacc += cs;
+            }
+            double x0a = 0.0, x1a = 0.0;
+            dpp_fence(xh);
+            RowDot<n>::run(x0a, x1a, xh, Arow);
+            xh = fma(Brow[1], uu1, fma(Brow[0], uu0, x0a + x1a));
+            dpp_fence(xh);
+        }
+        if (FUSE && wr && j == 0) a.csum[(size_t)b + (size_t)B * ai] = cacc;
+    }
+}
+
+}   // namespace
+
+// returns 1 when this launch is not for the pipeline kernel (the caller goes on to the row kernel), 0 launched, <0 error
+int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
+                            const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
+                            const int32_t *active, double *xnew, double *unew, double *cnew, double *csum)
+{
+    if (p->kind != DDP_PROBLEM_LQ || p->n != 10 || p->m != 2 || !K || lims || p->dyn_tv || !p->cost_diag || !h->sink) return 1;
+    const char *env = getenv("DDP_FORWARD_PIPE");               // 0: never, 1: whenever the shape allows (A/B timing, tests)
+    if (env && env[0] == '0') return 1;
+    const char *fuse_env = getenv("DDP_FORWARD_FUSE");
+    if (fuse_env && fuse_env[0] == '0') return 1;
+    const long total = (long)p->B * nalpha;
+    // one work-group (4 rollouts) per CU: with two the chain waves share their SIMDs and the pass is no faster than the row kernel
+    // (2 048 rollouts: 0.215 against 0.201 ms)
+    if (!(env && env[0] == '1') && total > 1024) return 1;
+    if ((((uintptr_t)K | (uintptr_t)k | (uintptr_t)u | (uintptr_t)x) & 15) != 0) return 1;   // 16-byte pieces of K_i, x_i, k_i, ū_i for the DMA
+    FPipeArgs a;
+    a.N = p->N; a.B = p->B; a.nalpha = nalpha; a.dyn_batched = p->dyn_batched;
+    a.A = p->A; a.Bm = p->Bm; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.Q = p->Q; a.R = p->R; a.active = active;
+    for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
+    a.xnew = xnew; a.unew = unew; a.cnew = cnew; a.csum = csum; a.sink = (double *)h->sink;
+    const dim3 grid((unsigned)((total + 3) / 4));
+    hipLaunchKernelGGL((forward_pipe_kernel<12, true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
