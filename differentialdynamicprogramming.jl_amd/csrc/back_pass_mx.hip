@@ -27,6 +27,10 @@
 // the kernel is therefore written to minimise the INSTRUCTION COUNT of a step (~70 vector instructions).
 #include "ddp_internal.h"
 
+#ifndef MX_EXP
+#define MX_EXP 0          // timing experiments (wrong results): 1 no transpose round trip, 2 no group write-back, 3 both
+#endif
+
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
 
     // ---- loop-invariant lane constants ---------------------------------------------------------------------------
     const double mask12 = l15 == VC ? 1.0 : 0.0;
+    const double cB = l4 >= 2 ? 1.0 : -lam;                   // regType 1: T = -λK in the 16-lane rows 0, 1
     const bool odd = (l4 & 1) != 0, hi2 = l4 >= 2;
     const int wr = l4 + TLD * l15;                           // accumulator register s -> tile element (l4+4s, l15)
     const int rdT = l15 == VC ? TZERO : l15 + TLD * l4;      // its transpose (l15, l4+4s): + 4*TLD per register
@@ -306,6 +311,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         // u-rows (Qu, below) and, linearly, by V[:,VC] = Vx (added after the value MFMA).
         const d4 c = CTV ? d4{hr[slot][0], hr[slot][1], hr[slot][2], hr[slot][3]} : Hc4;
         const double e = mode == 1 ? ecur[EREC * tau + eidx] : er[slot];
+        // LCH groups: the entry cu[parity of my 16-lane row] that column VC of the u-rows wants (Qu = cu + fu'Vx) comes by a
+        // second LDS read instead of two row broadcasts out of e (an LDS read costs ~8 issue cycles off the chain, the two
+        // v_fmac_f64_dpp + their wait states ~40 on it)
+        const double eu = mode == 1 ? ecur[EREC * tau + n + (l4 & 1)] : 0.0;
         if (FXTV) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) { F[s] = fr[slot][s]; Fh[s] = hmask * F[s]; }
@@ -320,9 +329,14 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], W[1], g, 0, 0, 0);
         g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], W[2], g, 0, 0, 0);
         // ================= gains (backward_pass.jl:30-42) =============================================================
-        double Z = g.w + 0.0;                              // G row 10 | 11 (Qux | Quu | Qu) with the parity of my 16-lane row
-        fmac_bcast<10, 0x3, true>(Z, e, mask12);                 // column VC: Qu = cu + fu'Vx   (e[10 + (l4&1)]: lane 10 of rows 0,1,
-        fmac_bcast<8, 0xc>(Z, e, mask12);                  //                               lane 8 of rows 2,3)
+        double Z;                                          // G row 10 | 11 (Qux | Quu | Qu) with the parity of my 16-lane row
+        if (mode == 1) {
+            Z = fma(eu, mask12, g.w);                      // column VC: Qu = cu + fu'Vx
+        } else {
+            Z = g.w + 0.0;
+            fmac_bcast<10, 0x3, true>(Z, e, mask12);       // (e[10 + (l4&1)]: lane 10 of rows 0,1,
+            fmac_bcast<8, 0xc>(Z, e, mask12);              //  lane 8 of rows 2,3)
+        }
         double Q0, Q1;                                     // row 10, row 11 in every lane
         double F00, F01, F11;                              // QuuF (:205-207)
         if (REG2) {                                        // u-rows of F'(W + λF) + H: Qux_reg, QuuF;  λF = 2λ·(½F)
@@ -361,12 +375,22 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         const double K1 = n1 * nidet;
         // my u-row: K_a, T_a = Qux_a + Quu[a,:]·K  (:64); a = parity of the 16-lane row
         const double Ksel = odd ? K1 : K0;
-        double Tsel = Z;
-        fmac_bcast<n, 0xf, true>(Tsel, Z, K0);
-        fmac_bcast<n + 1>(Tsel, Z, K1);
+        double Tsel, Bop;
+        if (!REG2) {
+            // regType 1: QuuF·K = -Qux with QuuF = Quu + λI, hence T = Quu·K + Qux = -λK — the residual form (as in the n = 64
+            // kernel): one multiply instead of two dependent row-broadcast multiply-adds, and the B operand of the value
+            // product (T_a in the 16-lane rows 0, 1; K_a in rows 2, 3) is K_a times a lane constant instead of a select
+            Bop = Ksel * cB;
+            Tsel = Bop;                                    // (only read where it is T: rows 0, 1)
+        } else {
+            Tsel = Z;
+            fmac_bcast<n, 0xf, true>(Tsel, Z, K0);
+            fmac_bcast<n + 1>(Tsel, Z, K1);
+            Bop = hi2 ? Ksel : Tsel;
+        }
         // ================= value update (:69-72): V = G + [K' Qux']·[T; K] ===========================================
         const double Aop = hi2 ? Z : Ksel;
-        const double Bop = hi2 ? (quu_lane ? Z : Ksel) : Tsel;   // (columns 10,11 of V are junk: their B lanes carry Quu for the store below)
+        // (columns 10, 11 of V are junk; Quu_i for the stores is taken from Z below)
         const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Bop, g, 0, 0, 0);
         // ---- while the value MFMA runs: outputs that do not depend on it, bookkeeping
         // wave-uniform branches, not selects: the common path is two multiply-adds
@@ -380,9 +404,12 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
             dVp = fma(Ksel, Tsel, dVp);
         }
         // ---- ½(V + V') through the transpose tile; registers keep V + V' (column VC: Vx)
+        if (MX_EXP & 1) { S[0] = v.x + v.x; S[1] = v.y + v.y; S[2] = v.z + v.z; }
+        else {
         lds[wr] = v.x; lds[wr + 4] = v.y; lds[wr + 8] = v.z;
         wave_sync();
         S[0] = v.x + lds[rdT]; S[1] = v.y + lds[rdT + rdS]; S[2] = v.z + lds[rdT + 2 * rdS];
+        }
         fmac_bcast<0>(S[0], e, mask12);                    // column VC: Vx += cx  (e[l4 + 4s]: lane 4s of my 16-lane row)
         fmac_bcast<4>(S[1], e, mask12);
         fmac_bcast<8>(S[2], e, mask12);
@@ -391,11 +418,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         if (mode == 1) {
             lout[w1 + REC * tau] = vscl * S[0];
             lout[w1 + 4 + REC * tau] = vscl * S[1];
-            lout[w2 + REC * tau] = hi2 ? Bop : vscl * S[2];
+            lout[w2 + REC * tau] = hi2 ? (quu_lane ? Z : Ksel) : vscl * S[2];
         } else {
             store2_masked(vst, vscl * S[0], vscl * S[1], lanes01);
             // rows 8, 9 of Vxx | Vx (16-lane rows 0,1) and K | k | Quu (:75-76) (rows 2,3) share one store
-            store_masked(kq, hi2 ? Bop : vscl * S[2], lanes2k);
+            store_masked(kq, hi2 ? (quu_lane ? Z : Ksel) : vscl * S[2], lanes2k);
             vst -= vst_stride;
             kq -= kq_stride;
         }
@@ -439,11 +466,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
             else if (FXTV) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- write the PD step records back: Vxx one step per instruction, the small arrays three steps per instruction
-            if (lane < 50) {
+            if (!(MX_EXP & 2)) if (lane < 50) {
 #pragma unroll
                 for (int t = 0; t < PD; ++t) *(d2 *)(pV + nn * 8 * t) = *(const d2 *)(lout + REC * t + 2 * lane);
             }
-            if (lane < 54) {
+            if (!(MX_EXP & 2)) if (lane < 54) {
                 *(d2 *)pM = *(const d2 *)(lout + mL);
                 *(d2 *)(pM + 3 * (size_t)mstep) = *(const d2 *)(lout + mL + 3 * REC);
                 if (lane < 36) *(d2 *)(pM + 6 * (size_t)mstep) = *(const d2 *)(lout + mL + 6 * REC);
