@@ -730,6 +730,13 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
     if (force == 'x' || (force == 0 && d->B < 5120)) {
+        // two waves per trajectory (chain + write-back, back_pass_mx2.hip) while a CU's four SIMDs hold one trajectory each;
+        // DDP_MX2=0 / 1 forces the one-wave / two-wave kernel
+        const char *mx2_env = getenv("DDP_MX2");
+        if (mx2_env ? mx2_env[0] == '1' : d->B <= 1024) {
+            const int r2 = ddp_launch_back_pass_mx2(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+            if (r2 <= 0) return r2;
+        }
         const int rc = ddp_launch_back_pass_mx(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;
     }
