@@ -42,8 +42,10 @@ struct MxLds {                                      // per trajectory
 };
 static_assert(sizeof(MxLds) % 16 == 0 && NT * sizeof(MxLds) <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ int lds_load_flag(const int *p) { return *(const volatile int *)p; }
-__device__ __forceinline__ void lds_store_flag(int *p, int v) { asm volatile("" ::: "memory"); *(volatile int *)p = v; asm volatile("" ::: "memory"); }
+// the counters are read and written as LDS words (a volatile access through a generic pointer becomes a system-scope FLAT access)
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ int lds_load_flag(const int *p) { return *(const volatile lds_int *)p; }
+__device__ __forceinline__ void lds_store_flag(int *p, int v) { asm volatile("" ::: "memory"); *(volatile lds_int *)p = v; asm volatile("" ::: "memory"); }
 
 // a group's step that the chain symmetrises itself (tau: position in the group, ascending time; the chain walks tau = PD-1 .. 0)
 __host__ __device__ constexpr bool sym_tau(int tau) { return tau % SYM_EVERY == 0; }
