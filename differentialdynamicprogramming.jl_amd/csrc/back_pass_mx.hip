@@ -363,11 +363,13 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
             if (i - PD >= PD - 1) { dma_e(enxt); pE -= (size_t)PD * estep; }       // [cx;cu] of the next group, a whole group ahead
             static_for<0, PD>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc, IC<1>{}); });
             // the direct-to-LDS load issued at the top has landed once at most the ring refills of this group are outstanding
-            // (in-order return); the stores below are issued after the wait and never waited for
-            if (FXTV && CTV) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-            else if (CTV) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (FXTV) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (loads return in order); the stores below are issued after the wait and never waited for.  The count is the number
+            // of refill loads a group issues behind dma_e — one 8-byte load per streamed operand register and step, nothing the
+            // compiler could merge (the lanes' addresses are unrelated) — and tests/test_gpu_edge_cases.py checks that this path and
+            // the step-by-step path (DDP_MX_LDS=0) agree bit for bit in every FXTV / CTV / regType combination.
+            constexpr int REFILLS = PD * ((FXTV ? 3 : 0) + (CTV ? 4 : 0));
+            static_assert(REFILLS <= 63, "vmcnt is a 6-bit counter");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REFILLS) : "memory");
             // ---- write the PD step records back: Vxx one step per instruction, the small arrays three steps per instruction
             if (!(MX_EXP & 2)) if (lane < 50) {
 #pragma unroll

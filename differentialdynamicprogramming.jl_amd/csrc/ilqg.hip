@@ -459,7 +459,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     //  * line search in groups: the reference stops at the first accepted step size (iLQG.jl:267-281); groups [0,1) [1,3) [3,n_alpha)
     //    roll the later step sizes out only for the trajectories whose search is still open.  DDP_ILQG_LSGROUPS=0 / 1: never / always.
     const char *cenv = getenv("DDP_ILQG_COMPACT");
-    const bool may_compact = !(cenv && cenv[0] == '0') && !(p->kind == DDP_PROBLEM_LQ && p->dyn_batched);
+    bool may_compact = !(cenv && cenv[0] == '0') && !(p->kind == DDP_PROBLEM_LQ && p->dyn_batched);
     // trajectories per wave of the backward kernel the dispatcher picks (back_pass.hip) -> slots that make two waves per SIMD
     const double tpw = (n == 4 && m == 1) ? 4.0 : (n == 10 && m == 2) ? (B < 5120 ? 1.0 : 4.0) : (n > DDP_MAX_N_GENERIC ? 0.25 : 1.0);
     const size_t min_slots = (cenv && atoi(cenv) > 1) ? (size_t)atoi(cenv) : (size_t)(2048.0 * tpw);
@@ -489,16 +489,22 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     bool polled = true;
     while (running > 0 && git < hard_cap) {
         if (polled && may_compact && (size_t)running * 2 <= Bw && Bw >= min_slots) {      // `running` is exact right after a poll only
-            // ---- drop the finished slots: their summary and (from a compacted set) their results go to the caller's arrays first
-            launch_stats(1);
-            if (ws.map) hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, 0, ws, user);
+            // ---- drop the finished slots.  Compaction is an optimisation: the block is allocated BEFORE anything is written to the
+            // caller's arrays, and a failed allocation (a memory-tight batch) only switches compaction off for the rest of the solve.
             const size_t R = (size_t)running;
             const size_t w_d = al(n * N * R * 8) + al(m * N * R * 8) + al(CL * R * 8) + al(m * n * N * R * 8) + al(m * N * R * 8) +
                                al(m * m * N * R * 8) + al(n * N * R * 8) + al(n * n * N * R * 8) + al(n * R * 8) + 4 * al(R * 8) + 12 * al(R * 4) +
                                al(Bw * 4) + 256;
             void *blk = nullptr;
-            DDP_HIP(hipMalloc(&blk, w_d));
+            if (getenv("DDP_TEST_COMPACT_ALLOC_FAIL") || hipMalloc(&blk, w_d) != hipSuccess) {      // (the variable: tests of this path)
+                (void)hipGetLastError();                         // clear the sticky error: the solve goes on with the current working set
+                may_compact = false;
+                continue;
+            }
             owned.push_back(blk);
+            // their summary and (from a compacted set) their results go to the caller's arrays first
+            launch_stats(1);
+            if (ws.map) hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)Bw), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)CL, 0, ws, user);
             char *q = (char *)blk;
             auto tk = [&](size_t b_) { void *r_ = q; q += al(b_); return r_; };
             WorkSet nw;
