@@ -58,3 +58,15 @@ def relerr(a, b, taxis=-1):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def par_map(fn, items, workers=None):
+    """fn over items on the host cores (the oracle's C calls run without the GIL): whole-batch oracle comparisons of the full-size
+    GPU tests.  Exceptions (failed asserts) of any item propagate."""
+    import concurrent.futures as cf
+    items = list(items)
+    workers = workers or max(1, min(32, len(os.sched_getaffinity(0))))
+    if workers == 1 or len(items) < 2:
+        return [fn(i) for i in items]
+    with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(fn, items))

@@ -71,6 +71,11 @@ def one_case(ddp, oc, rng, case):
     os.environ.pop("DDP_BACKPASS", None)
     if c["impl"]:
         os.environ["DDP_BACKPASS"] = c["impl"]
+    # the work-group pipelines of round 3 (back_pass_mx2: chain + writer wave; forward_pass_pipe) forced on / off / as dispatched
+    for var, pick in (("DDP_MX2", case % 3), ("DDP_FORWARD_PIPE", (case // 3) % 3)):
+        os.environ.pop(var, None)
+        if pick < 2:
+            os.environ[var] = str(pick)
     div, pol, Vx, Vxx, dV = ddp.back_pass(c["cx"], c["cu"], c["cxx"], c["cxu"], c["cuu"], c["fx"], c["fu"], c["lam"], c["regType"], lims, None, c["u"])
     os.environ.pop("DDP_BACKPASS", None)
     worst = 0.0
@@ -96,6 +101,7 @@ def one_case(ddp, oc, rng, case):
                 e = relerr(got, ref)
                 worst = max(worst, e)
                 assert e < RTOL, (name, e, tag, "trajectory %d" % b)
+    os.environ.pop("DDP_MX2", None); os.environ.pop("DDP_FORWARD_PIPE", None)
     return worst
 
 

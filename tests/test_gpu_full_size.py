@@ -6,18 +6,25 @@ kernel dispatch (no DDP_BACKPASS / DDP_FORWARD_LANE overrides: the size-triggere
     C4  n=64 m=8 N=256 per-trajectory LTV, B=1024                 (fp64-MFMA back pass, streaming rollout)
     C5  C3 + KL constraint, B=4096                                (back_pass_gps lane kernel, device-resident iLQGkl loop)
 
-Each: size-independent properties over the WHOLE batch + oracle comparisons (1e-8 per time step) on >= 3 trajectories."""
+Each: size-independent properties over the WHOLE batch + oracle comparisons (1e-8 per time step) — every trajectory of the C3 pass,
+64 randomly chosen ones of the others (C4 solves: 16), on all host cores."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import par_map, relerr
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-8
 SPOTS3 = lambda B: (0, B // 2 - 1, B - 1)      # noqa: E731
+
+
+def spots(B, k, seed):
+    """k trajectories of the batch: the first, the last and k - 2 random ones"""
+    r = np.random.default_rng(seed).choice(np.arange(1, B - 1), size=k - 2, replace=False)
+    return [0, B - 1] + sorted(int(i) for i in r)
 
 
 @pytest.fixture(scope="module")
@@ -104,9 +111,10 @@ def test_full_size_c3_pass(ddp):
     xn, un_, cn = ddp.forward_pass(pol, x0, u, x, al, prob, lims)                                 # 24 576 rollouts: lane kernel
     assert np.abs(un_).max() <= 5.0 and np.isfinite(xn).all()
     assert np.array_equal(xn[:, 0], np.broadcast_to(x0[:, :, None], xn[:, 0].shape))
-    # ---- oracle on spot trajectories
+    # ---- the oracle on EVERY trajectory (rollout, df, back_pass; the six line-search rollouts on every 16th)
     p = _pend_oracle(oc, prob, N)
-    for b in SPOTS3(B) + (1234,):
+
+    def check(b):
         xr, ur, cr = oc.forward_pass(p, None, x0[:, b], u0[..., b], None, 1.0, lims)
         assert relerr(x[..., b], xr) < RTOL and relerr(c[:, b], cr) < RTOL
         dr = oc.df(p, xr, ur)
@@ -116,9 +124,11 @@ def test_full_size_c3_pass(ddp):
         for got, ref, name in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (Vx[..., b], vx, "Vx"), (Vxx[..., b], vxx, "Vxx"),
                                (dV[:, b], dv, "dV"), (pol.Σi[..., b], Quu, "Quu")):
             assert relerr(got, ref) < RTOL, (name, b, relerr(got, ref))
-        for j, a in enumerate(al):
-            xr2, ur2, cr2 = oc.forward_pass(p, (K, k), x0[:, b], ur, xr, float(a), lims)
-            assert relerr(xn[..., b, j], xr2) < RTOL and relerr(un_[..., b, j], ur2) < RTOL and relerr(cn[:, b, j], cr2) < RTOL
+        if b % 16 == 0 or b == B - 1:
+            for j, a in enumerate(al):
+                xr2, ur2, cr2 = oc.forward_pass(p, (K, k), x0[:, b], ur, xr, float(a), lims)
+                assert relerr(xn[..., b, j], xr2) < RTOL and relerr(un_[..., b, j], ur2) < RTOL and relerr(cn[:, b, j], cr2) < RTOL
+    par_map(check, range(B))
 
 
 def test_full_size_c3_solves(ddp):
@@ -138,11 +148,20 @@ def test_full_size_c3_solves(ddp):
     c0 = ddp.forward_pass(None, x0, np.zeros((1, T, B)), None, 1.0, prob, lims)[2].sum(axis=0)
     assert (cost.sum(axis=0) < c0).all()                                     # every solve improved on the initial rollout
     p = _pend_oracle(oc, prob, T)
-    for b in SPOTS3(B):
+
+    def check(b):
         xr, ur, polr, vxr, vxxr, cr, info = oc.ilqg(p, x0[:, b], np.zeros((1, T)), lims=lims, regType=2, alpha=kw["α"], lam_max=1e15,
                                                     tol_fun=1e-8, tol_grad=1e-8, max_iter=1000)
         assert abs(cost[:, b].sum() - cr.sum()) < 1e-9 * cr.sum(), b
-        assert relerr(x[..., b], xr) < 1e-5 and relerr(u[..., b], ur) < 1e-5 and relerr(Vxx[..., b], vxxr) < 1e-5
+        same = int(st[1, b]) == info["iter"]
+        tol = 1e-5 if same else 1e-3
+        assert relerr(x[..., b], xr) < tol and relerr(u[..., b], ur) < tol, (b, same)
+        # one iteration more or less at the rounding floor of sum(cost) leaves x, u at the minimiser but Vxx / K one (tiny) accepted
+        # step apart where the value function is steep; with the same decisions they agree like a single pass
+        assert relerr(Vxx[..., b], vxxr) < (1e-5 if same else 0.1), (b, same)
+        return same
+    same = par_map(check, spots(B, 64, 3))
+    assert sum(same) >= 32                                                   # most solves take the oracle's decisions to the end
 
 
 # ------------------------------------------------------------------------------------------------ C4
@@ -203,9 +222,9 @@ def test_full_size_c4_pass_and_solves(ddp):
     # with λ > 0 the full step still descends
     assert (csn[:, 0] < csum0).all()
     assert torch.allclose(dcsn.reshape(na, B), dcn.reshape(na, B, N).sum(dim=2), rtol=1e-12, atol=0)       # csum = sum(cnew)
-    # ---- oracle on three trajectories
+    # ---- oracle on 64 trajectories (first, last, 62 random)
     lam = dlam.cpu().numpy()
-    for b in SPOTS3(B):
+    for b in spots(B, 64, 4):
         sl = lambda t, per: t[per * b: per * (b + 1)].cpu().numpy()          # noqa: E731
         Ab = sl(dA, n * n * N).reshape(n, n, N, order="F"); Bb = sl(dB, n * m * N).reshape(n, m, N, order="F")
         p = oc.make_problem("lq", n, m, N, A=Ab, B=Bb, Q=Q, R=R)
@@ -238,7 +257,7 @@ def test_full_size_c4_pass_and_solves(ddp):
     torch.cuda.synchronize()
     st = stats.cpu().numpy().reshape(8, B, order="F")
     assert set(st[0].astype(int)) <= {1, 2}
-    for b in SPOTS3(B):
+    for b in spots(B, 16, 5):
         sl = lambda t, per: t[per * b: per * (b + 1)].cpu().numpy()          # noqa: E731
         Ab = sl(dA, n * n * N).reshape(n, n, N, order="F"); Bb = sl(dB, n * m * N).reshape(n, m, N, order="F")
         p = oc.make_problem("lq", n, m, N, A=Ab, B=Bb, Q=Q, R=R)
@@ -275,12 +294,14 @@ def test_full_size_c5_kl_solves(ddp):
     assert sat.any()
     dvg = np.asarray(tr["divergence"], float)
     assert np.all(np.abs(dvg[sat] - 0.05) < 0.1 * 0.05 + 1e-12)              # satisfied = within 10 % of kl_step (klutils.jl:121)
-    # ---- oracle on three trajectories
+    # ---- oracle on 64 trajectories
     p = _pend_oracle(oc, prob, N)
-    for b in SPOTS3(B):
+
+    def check(b):
         pb = dict(K=np.zeros((1, 4, N)), k=u[..., b], S=eye[..., b], Si=eye[..., b])
         xr, ur, polr, vx, vxx, cr, info = oc.ilqgkl(p, x[..., b], float(cost0[b]), pb, dict(fx=fx[..., b], R1=R1), kl_step=0.05, lims=lims,
                                                     max_iter=30)
         assert (tr["status"][b], tr["iter"][b], tr["n_backpass"][b]) == (info["status"], info["iter"], info["n_backpass"]), b
         assert relerr(np.asarray(tr["η"])[:, b], info["eta"]) < 1e-7
         assert relerr(xo[..., b], xr) < 1e-7 and relerr(uo[..., b], ur) < 1e-7 and relerr(pol.K[..., b], polr["K"]) < 1e-7
+    par_map(check, spots(B, 64, 6))

@@ -3,7 +3,7 @@ committed golden fixtures.  Tolerance: 1e-8 relative (BASELINE.json north_star),
 import numpy as np
 import pytest
 
-from conftest import load_golden, relerr
+from conftest import load_golden, par_map, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -196,7 +196,7 @@ def test_ilqg_batched_independent_state_machines(ddp):
 
 
 def test_full_size_c2_properties(ddp):
-    """BASELINE config 2 (n=10, m=2, N=1000, B=1024): size-independent properties + oracle spot checks"""
+    """BASELINE config 2 (n=10, m=2, N=1000, B=1024): size-independent properties + the oracle on all 1 024 trajectories"""
     from oracle import np_restatement as npr
     from oracle import oracle_ctypes as oc
     rng = np.random.default_rng(1234)
@@ -215,13 +215,19 @@ def test_full_size_c2_properties(ddp):
     for j, a in enumerate((1.0, 0.3)):                                               # z == 1 for LQ problems
         z = (c.sum(0) - cn[..., j].sum(0)) / (-a * (dV[0] + a * dV[1]))
         assert np.max(np.abs(z - 1)) < 1e-7
+    # ---- the oracle on EVERY trajectory of the batch (all host cores)
     p = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=P["Q"], R=P["R"])
-    for b in (0, 511, 1023):
+
+    def check(b):
         d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], P["Q"], np.zeros((n, m)), P["R"], P["A"], P["B"], 0.0, 1,
                                                   None, x[..., b], u[..., b])
-        assert relerr(pol.K[..., b], K) < RTOL and relerr(Vxx[..., b], vxx) < RTOL and relerr(Vx[..., b], vx) < RTOL
+        assert d == 0
+        for got, ref, name in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (Vxx[..., b], vxx, "Vxx"), (Vx[..., b], vx, "Vx"),
+                               (pol.Σi[..., b], Quu, "Quu"), (dV[:, b], dv, "dV")):
+            assert relerr(got, ref) < RTOL, (name, b)
         xr, ur, cr = oc.forward_pass(p, (K, k), x0[:, b], u[..., b], x[..., b], 0.3, None)
-        assert relerr(xn[..., b, 1], xr) < RTOL and relerr(un[..., b, 1], ur) < RTOL
+        assert relerr(xn[..., b, 1], xr) < RTOL and relerr(un[..., b, 1], ur) < RTOL and relerr(cn[..., b, 1], cr) < RTOL, b
+    par_map(check, range(B))
 
 
 # ------------------------------------------------------------------ every kernel implementation of back_pass
