@@ -191,12 +191,16 @@ class PassBench:
         bp_bytes_launch = (bp_read + bp_write) * (N - 1) * B
         achieved = bp_bytes_launch / (bp_avg_ms * 1e-3) / 1e9
         force = os.environ.get("DDP_BACKPASS", "")[:1]
-        kern = {"x": "back_pass_mx_kernel<LTI>", "d": "back_pass_dpp_kernel<10,2,LTI>",
-                "g": "back_pass_kernel<10,2>"}.get(force, "back_pass_mx_kernel<LTI>" if B < 5120 else "back_pass_dpp_kernel<10,2,LTI>")
+        mx2 = os.environ.get("DDP_MX2")
+        mx = "back_pass_mx2_kernel<LTI>" if (mx2 == "1" if mx2 else B <= 1024) else "back_pass_mx_kernel<LTI>"      # back_pass.hip: ddp_launch_back_pass
+        kern = {"x": mx, "d": "back_pass_dpp_kernel<10,2,LTI>",
+                "g": "back_pass_kernel<10,2>"}.get(force, mx if B < 5120 else "back_pass_dpp_kernel<10,2,LTI>")
+        pipe = os.environ.get("DDP_FORWARD_PIPE")
+        fwd = "forward_pipe_kernel" if (pipe == "1" if pipe else B <= 1024) and os.environ.get("DDP_FORWARD_FUSE", "1") != "0" else "forward_dpp_kernel"
         return {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": bp_bytes_launch,
                 "avg_launch_ms": round(bp_avg_ms, 4), "avg_launch_ms_samples": "HIP events around three launches spread over the timed region",
-                "forward_kernels": {"kernels": "forward_dpp_kernel (cost fused, ddp_problem::cost_diag)" if os.environ.get("DDP_FORWARD_FUSE", "1") != "0"
+                "forward_kernels": {"kernels": fwd + " (cost fused, ddp_problem::cost_diag)" if os.environ.get("DDP_FORWARD_FUSE", "1") != "0"
                                     else "forward_dpp_kernel + cost_kernel", "avg_launch_ms": round(fp_avg_ms, 4),
                                     "bytes_per_launch": fp_bytes * N * B,
                                     "achieved_GBs": round(fp_bytes * N * B / (fp_avg_ms * 1e-3) / 1e9, 1)},
@@ -216,6 +220,8 @@ def main():
     ap.add_argument("--preheat", type=int, default=200, help="untimed passes BEFORE the warmup so that the GPU clocks have settled (a pass is "
                     "0.7 ms; a cold device ramps its clocks over the first ~50 ms); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic (two rocprofv3 --pmc child runs of a 3-step "
+                    "bench after the timed region); the committed figure of profiles/pmc_traffic.json is replayed instead")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 pass lines (profiles/bench_configs.py in a child process)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories for the CPU baseline (0 = auto ~10-20 s)")
     ap.add_argument("--fill-batch", type=int, default=32768, help="machine-filling batch reported next to the headline (0 = skip)")
@@ -276,17 +282,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     roofline = pb.roofline(bp_ms, fp_ms)
-    # HBM traffic per launch comes from the PMC passes of profiles/run_profile.sh (rocprofv3 --pmc cannot wrap a process from the
-    # inside): the committed figure for THIS kernel at THIS batch, or null — never a number measured for another batch or kernel
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    # HBM traffic per launch: measured after the timed region by two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE: separate passes)
+    # of a 3-step bench of the same workload (rank 0, single GPU); where that is not possible (rocprofv3 missing, multi-rank run,
+    # --no-traffic) the committed figure for THIS kernel at THIS batch is replayed — never a number of another batch or kernel
     roofline["traffic_source"] = None
-    if os.path.exists(tfile):
+    profiled = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))     # already under rocprofv3
+    if rank == 0 and world == 1 and not args.no_traffic and not profiled and os.environ.get("DDP_BENCH_CHILD") != "1":
+        try:
+            tr, src = measure_traffic(roofline["kernel"].split("<")[0], B, N)
+            roofline["traffic"], roofline["traffic_source"] = tr, src
+        except Exception as exc:
+            roofline["traffic_source"] = "live PMC measurement failed: %s" % str(exc)[-200:]
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if roofline["traffic"] is None and os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             key = roofline["kernel"].split("<")[0] + "_bytes_per_launch_B%d" % B
             roofline["traffic"] = tj.get(key)
-            roofline["traffic_source"] = ("profiles/pmc_traffic.json[%s]: %s — replayed from the committed profile, not measured in this run" % (key, tj.get("_source", "?"))
-                                          if key in tj else "no PMC profile committed for %s" % key)
+            note = ("profiles/pmc_traffic.json[%s]: %s — replayed from the committed profile, not measured in this run" % (key, tj.get("_source", "?"))
+                    if key in tj else "no PMC profile committed for %s" % key)
+            roofline["traffic_source"] = note if not roofline["traffic_source"] else roofline["traffic_source"] + "; " + note
         except Exception:
             pass
     roofline["note"] = ("each trajectory is a length-N dependency chain: at B=1024 (one wave per SIMD) the fraction is "
@@ -333,6 +348,43 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def measure_traffic(kernel, B, N):
+    """roofline.traffic measured for THIS run's kernel: HBM bytes per launch = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024
+    (/opt/skills/guides/MI355X_MICROARCH.md: both counters are in 1024-byte units and on gfx950 FETCH_SIZE reports half the bytes of a
+    wide read stream), each counter in its own `rocprofv3 --pmc` pass with --kernel-trace only, around a 3-step child run of this file."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="ddp_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "3", "--warmup", "1", "--preheat", "0", "--batch", str(B), "--horizon", str(N), "--no-cpu-baseline", "--no-other-configs",
+                   "--fill-batch", "0", "--no-traffic"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", DDP_BENCH_CHILD="1"), capture_output=True, text=True, timeout=180)
+            acc = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        acc.append(float(row["Counter_Value"]))
+            if not acc:
+                raise RuntimeError("no %s rows for %s" % (ctr, kernel))
+            vals[ctr] = (sum(acc) / len(acc), len(acc))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = int(vals["FETCH_SIZE"][0] * 1024 * 2 + vals["WRITE_SIZE"][0] * 1024)
+    return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) around a 3-step child "
+                   "run of bench.py at the same batch; mean over %d / %d launches of %s; FETCH_SIZE x1024 x2 + WRITE_SIZE x1024 per "
+                   "MI355X_MICROARCH.md" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1], kernel))
 
 
 def other_configs():

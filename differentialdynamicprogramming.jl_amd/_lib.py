@@ -28,6 +28,7 @@ EXPORTS = [
     "ddp_kl_terms_f64_dev", "ddp_kl_terms_f64", "ddp_back_pass_gps_f64_dev", "ddp_back_pass_gps_f64",
     "ddp_forward_covariance_f64_dev", "ddp_forward_covariance_f64", "ddp_kl_div_f64_dev", "ddp_kl_div_f64",
     "ddp_kl_dual_begin_f64_dev", "ddp_kl_dual_retry_f64_dev", "ddp_kl_dual_update_f64_dev",
+    "ddp_ilqgkl_default_opts", "ddp_ilqgkl_f64_dev", "ddp_ilqgkl_f64",
     "ddp_comm_unique_id", "ddp_comm_create", "ddp_comm_destroy", "ddp_allreduce_stats_f64_dev",
 ]
 
@@ -64,6 +65,12 @@ class ILQGOpts(C.Structure):
                 ("reduce_ratio_min", C.c_double), ("n_alpha", C.c_int), ("alpha", C.c_double * 16)]
 
 
+class ILQGKLOpts(C.Structure):
+    _fields_ = [("kl_step", C.c_double), ("max_iter", C.c_int), ("etabracket", C.c_double * 3), ("del0", C.c_double)]
+
+
+ILQGKL_NSTATS = 12
+
 _lib = None
 
 
@@ -87,6 +94,7 @@ def lib():
             if name not in ("ddp_last_error", "ddp_version", "ddp_stream"):
                 fn.restype = C.c_int
         L.ddp_ilqg_default_opts.restype = None
+        L.ddp_ilqgkl_default_opts.restype = None
         _lib = L
     return _lib
 

@@ -6,6 +6,7 @@
 // None of this is on the benchmarked path; the kernels are written for clarity and coalescing, not tuned.
 #include "arena.h"
 #include <stdlib.h>
+#include <vector>
 #include "ddp_internal.h"
 
 namespace {
@@ -257,6 +258,64 @@ __global__ void kl_dual_kernel(int op, int B, int it, double kl_step, ddp_kl_dua
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
 }
 
+
+// ---- helpers of the iLQGkl driver (ddp_ilqgkl_f64_dev below)
+// dst[e, t, b] = src[e (, b)]: gives a time-invariant operand the time axis back_pass_gps wants (demo_linear.jl:91-101 hands out 3-D arrays)
+__global__ __launch_bounds__(256) void kl_repeat_kernel(int len, int N, long total, int src_batched, const double *__restrict__ src,
+                                                        double *__restrict__ dst)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long per = (long)len * N;
+    dst[e] = src ? src[(e % len) + (src_batched ? (e / per) * len : 0)] : 0.0;
+}
+// x0c[:, b] = x0[:, 1, b]  (the start of every rollout, iLQGkl.jl:132)
+__global__ __launch_bounds__(256) void kl_first_col_kernel(int n, int N, int B, const double *__restrict__ x0, double *__restrict__ x0c)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n * B) x0c[e] = x0[(size_t)n * N * (e / n) + (e % n)];
+}
+__global__ __launch_bounds__(256) void kl_dual_init_kernel(int B, double e0, double e1, double e2, double del0, int own_etab, ddp_kl_dual s)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    if (own_etab) { s.etab[3 * (long)b] = e0; s.etab[3 * (long)b + 1] = e1; s.etab[3 * (long)b + 2] = e2; }
+    s.eta[b] = s.etab[3 * (long)b + 1];
+    s.del[b] = del0; s.divergence[b] = 0.0;
+    s.satisfied[b] = 0; s.status[b] = 0; s.live[b] = 1; s.pend[b] = 0; s.iters[b] = 0; s.nback[b] = 0;
+}
+// one wave per trajectory: g_norm = mean_t max_a |k[a,t]| / (|u[a,t]| + 1)  (iLQGkl.jl:125) and the summary row of the trajectory
+__global__ __launch_bounds__(DDP_WAVE) void kl_summary_kernel(int m, int N, ddp_kl_dual s, const double *__restrict__ k,
+                                                              const double *__restrict__ u, const double *__restrict__ csum_new,
+                                                              const double *__restrict__ cost0, const double *__restrict__ dV,
+                                                              double *__restrict__ stats)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    for (int t = lane; t < N; t += DDP_WAVE) {
+        double mx = 0.0;
+        for (int a = 0; a < m; ++a) {
+            const size_t e = (size_t)m * ((size_t)N * b + t) + a;
+            const double r = fabs(k[e]) / (fabs(u[e]) + 1.0);
+            mx = r > mx ? r : mx;
+        }
+        acc += mx;
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) {
+        double *r = stats + (size_t)DDP_ILQGKL_NSTATS * b;
+        const int st = s.status[b];
+        r[0] = st ? st : 3;                                                   // still live when the loop ran out: max_iter (iLQGkl.jl:234)
+        r[1] = s.iters[b]; r[2] = s.nback[b]; r[3] = s.satisfied[b];
+        r[4] = s.etab[3 * (long)b]; r[5] = s.etab[3 * (long)b + 1]; r[6] = s.etab[3 * (long)b + 2];
+        r[7] = s.divergence[b];
+        r[8] = csum_new[b];
+        r[9] = cost0 ? cost0[b] - csum_new[b] : NAN;                          // Δcost (:135)
+        r[10] = -(dV[2 * (long)b] + dV[2 * (long)b + 1]);                     // expected_reduction (:136)
+        r[11] = acc / N;
+    }
+}
+
 size_t fcov_lds(int n, int m) { return ((size_t)3 * n * n + 2 * (size_t)n * m) * sizeof(double); }
 
 }   // namespace
@@ -354,6 +413,182 @@ int ddp_kl_dual_update_f64_dev(ddp_handle h, int B, double kl_step, const ddp_kl
 {
     DDP_CHECK(klmean, "kl_dual_update: null argument");
     return kl_dual_launch(h, 2, B, 0, kl_step, s, nullptr, klmean, n_live);
+}
+
+
+// ---- iLQGkl (single KL constraint, src/iLQGkl.jl:25-178,234-252) as ONE call on device-resident arrays.
+// The batch advances in lock step; every pass recomputes ALL trajectories with their current η: one that has already left keeps its η
+// (kl_dual_kernel), so it is recomputed to the same result and the arrays are right for everyone at the end.  Two stream
+// synchronisations per iteration (the counts of still-diverging and of live trajectories), nothing else crosses PCIe.
+void ddp_ilqgkl_default_opts(ddp_ilqgkl_opts *o)
+{   // iLQGkl.jl:25-44
+    o->kl_step = 1.0; o->max_iter = 50; o->etabracket[0] = 1e-8; o->etabracket[1] = 1.0; o->etabracket[2] = 1e16; o->del0 = 1e-4;
+}
+
+int ddp_ilqgkl_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqgkl_opts *oo, const double *x0, const double *cost0,
+                       const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                       const double *model_fx, int model_fx_batched, const double *R1, const double *lims, double *etab,
+                       double *x, double *u, double *K, double *Sigma, double *Sigmai, double *Vx, double *Vxx, double *cost,
+                       double *dV, double *stats, int *iters_out)
+{
+    DDP_DEVICE(h);
+    DDP_CHECK(p && x0 && Kp && kp && Sp && Sip && model_fx && R1 && x && u && K && Sigma && Sigmai && Vx && Vxx && cost && dV && stats,
+              "ilqgkl: null argument");
+    ddp_ilqgkl_opts od;
+    if (!oo) { ddp_ilqgkl_default_opts(&od); oo = &od; }
+    DDP_CHECK(oo->max_iter >= 1, "ilqgkl: max_iter=%d (the reference returns undefined arrays without an iteration)", oo->max_iter);
+    DDP_CHECK(x0 != x && kp != u, "ilqgkl: x0 / traj_prev.k must not alias the outputs x / u");
+    const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p), NB = N * B, P2 = (n + m) * (n + m);
+    const bool pend = p->kind == DDP_PROBLEM_PENDCART;
+    DDP_CHECK(n <= (size_t)NMAXK && m <= (size_t)MMAXK, "ilqgkl: n=%zu m=%zu has no back_pass_gps kernel (n <= %d, m <= %d)", n, m, NMAXK, MMAXK);
+    // dynamics as back_pass_gps wants them: [n,n,N] or [n,n,N,B]
+    const bool fx_b = pend || p->dyn_batched, fx_rep = !pend && !p->dyn_tv;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t fxc = N * (fx_b ? B : 1);
+    const size_t s_fx = (pend || fx_rep) ? al(n * n * fxc * 8) : 0, s_fu = (pend || fx_rep) ? al(n * m * fxc * 8) : 0;
+    const size_t sz[] = {al(n * NB * 8), al(m * NB * 8),                                       // cx, cu
+                         al(n * n * N * 8), al(n * m * N * 8), al(m * m * N * 8),              // cxx, cxu, cuu [.,.,N]
+                         al(n * NB * 8), al(m * NB * 8), al(n * n * NB * 8), al(m * n * NB * 8), al(m * m * NB * 8),   // ∇kl
+                         al(m * NB * 8), al(m * NB * 8),                                       // k (new policy), zeros (traj_prev.k *= 0)
+                         al(P2 * NB * 8), al(NB * 8), al(B * 8), al(B * 8), al(n * B * 8),     // sigmanew, kldiv, klmean, csum, x0[:,1]
+                         al(3 * B * 8), 4 * al(B * 8), 6 * al(B * 4), al(B * 4), 256};         // dual state (+ sum(cost0)), diverge, counters
+    size_t bytes = s_fx + s_fu;
+    for (size_t v : sz) bytes += v;
+    void *base;
+    int rc = ddp_scratch(h, bytes, &base);
+    if (rc) return rc;
+    char *q = (char *)base;
+    auto take = [&](size_t b) { void *r = q; q += al(b); return r; };
+    int32_t *counter = (int32_t *)take(256);               // first: the stand-alone ddp_kl_dual_* entry points keep theirs at the scratch base
+    double *cx = (double *)take(n * NB * 8), *cu = (double *)take(m * NB * 8), *cxx = (double *)take(n * n * N * 8),
+           *cxu = (double *)take(n * m * N * 8), *cuu = (double *)take(m * m * N * 8);
+    ddp_kl_cost_terms t;
+    double *kcx = (double *)take(n * NB * 8), *kcu = (double *)take(m * NB * 8), *kcxx = (double *)take(n * n * NB * 8),
+           *kcxu = (double *)take(m * n * NB * 8), *kcuu = (double *)take(m * m * NB * 8);
+    double *k = (double *)take(m * NB * 8), *kzero = (double *)take(m * NB * 8), *sig = (double *)take(P2 * NB * 8),
+           *kld = (double *)take(NB * 8), *klm = (double *)take(B * 8), *cs = (double *)take(B * 8), *x0c = (double *)take(n * B * 8);
+    ddp_kl_dual s;
+    double *etab_own = (double *)take(3 * B * 8);
+    s.etab = etab ? etab : etab_own;
+    s.eta = (double *)take(B * 8); s.del = (double *)take(B * 8); s.divergence = (double *)take(B * 8);
+    s.satisfied = (int32_t *)take(B * 4); s.status = (int32_t *)take(B * 4); s.live = (int32_t *)take(B * 4);
+    s.pend = (int32_t *)take(B * 4); s.iters = (int32_t *)take(B * 4); s.nback = (int32_t *)take(B * 4);
+    int32_t *div = (int32_t *)take(B * 4);
+    double *c0buf = (double *)take(B * 8);
+    double *fxw = (pend || fx_rep) ? (double *)take(n * n * fxc * 8) : nullptr, *fuw = (pend || fx_rep) ? (double *)take(n * m * fxc * 8) : nullptr;
+    t.cx = kcx; t.cu = kcu; t.cxx = kcxx; t.cxu = kcxu; t.cuu = kcuu; t.eta = s.eta; t.eta_tv = 0;
+
+    hipStream_t st = h->stream;
+    const unsigned gB = (unsigned)((B + 255) / 256);
+    auto grid = [](size_t tot) { return dim3((unsigned)((tot + 255) / 256)); };
+    hipLaunchKernelGGL(kl_dual_init_kernel, dim3(gB), dim3(256), 0, st, (int)B, oo->etabracket[0], oo->etabracket[1], oo->etabracket[2],
+                       oo->del0, etab ? 0 : 1, s);
+    DDP_HIP(hipMemsetAsync(kzero, 0, m * NB * 8, st));
+    hipLaunchKernelGGL(kl_first_col_kernel, grid(n * B), dim3(256), 0, st, (int)n, (int)N, (int)B, x0, x0c);
+    // STEP 1 (:86): derivs(x, u) with u = copy(traj_prev.k) (:45)
+    if ((rc = ddp_df_f64_dev(h, p, x0, kp, nullptr, cx, cu, pend ? fxw : nullptr, pend ? fuw : nullptr))) return rc;
+    if (fx_rep) {
+        hipLaunchKernelGGL(kl_repeat_kernel, grid(n * n * fxc), dim3(256), 0, st, (int)(n * n), (int)N, (long)(n * n * fxc), (int)fx_b, p->A, fxw);
+        hipLaunchKernelGGL(kl_repeat_kernel, grid(n * m * fxc), dim3(256), 0, st, (int)(n * m), (int)N, (long)(n * m * fxc), (int)fx_b, p->Bm, fuw);
+    }
+    const double *fx = (pend || fx_rep) ? fxw : p->A, *fu = (pend || fx_rep) ? fuw : p->Bm;
+    hipLaunchKernelGGL(kl_repeat_kernel, grid(n * n * N), dim3(256), 0, st, (int)(n * n), (int)N, (long)(n * n * N), 0, p->Q, cxx);
+    hipLaunchKernelGGL(kl_repeat_kernel, grid(n * m * N), dim3(256), 0, st, (int)(n * m), (int)N, (long)(n * m * N), 0, (const double *)nullptr, cxu);
+    hipLaunchKernelGGL(kl_repeat_kernel, grid(m * m * N), dim3(256), 0, st, (int)(m * m), (int)N, (long)(m * m * N), 0, p->R, cuu);
+    if ((rc = ddp_kl_terms_f64_dev(h, (int)n, (int)m, (int)N, (int)B, Kp, kzero, Sip, kcx, kcu, kcxx, kcxu, kcuu))) return rc;   // :90
+    if (!cost0) {                                          // the reference insists on `cost` (:69); a C caller may leave it to costfun(x0, u)
+        if ((rc = ddp_costfun_f64_dev(h, p, x0, kp, nullptr, cost, c0buf))) return rc;
+        cost0 = c0buf;
+    }
+    ddp_bp_desc d;
+    d.n = (int)n; d.m = (int)m; d.N = (int)N; d.B = (int)B; d.fx_tv = 1; d.fx_batched = fx_b; d.cost_tv = 1; d.cost_batched = 0;
+    d.regType = 1; d.has_lims = lims != nullptr;
+    auto poll = [&](int *out) -> int {
+        DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4, hipMemcpyDeviceToHost, st));
+        DDP_HIP(hipStreamSynchronize(st));
+        *out = h->h_pinned[0];
+        return 0;
+    };
+    auto dual = [&](int op, int it) -> int {
+        DDP_HIP(hipMemsetAsync(counter, 0, 4, st));
+        hipLaunchKernelGGL(kl_dual_kernel, dim3(gB), dim3(256), 0, st, op, (int)B, it, oo->kl_step, s, (const int32_t *)div, (const double *)klm, counter);
+        DDP_HIP(hipGetLastError());
+        return 0;
+    };
+    const double one = 1.0;
+    int it = 0, live = (int)B;
+    for (it = 1; it <= oo->max_iter && live > 0; ++it) {                                                  // :91
+        if ((rc = dual(0, it))) return rc;
+        for (int guard = 0;; ++guard) {                    // back passes until the KL-regularised Quu is positive definite everywhere (:95-122)
+            DDP_HIP(hipMemsetAsync(Sigma, 0, m * m * NB * 8, st));
+            rc = ddp_launch_back_pass_gps_lane(h, &d, cx, cu, cxx, cxu, cuu, fx, fu, &t, lims, kp, nullptr, K, k, Sigmai, Sigma, Vx, Vxx, dV, div);
+            if (rc > 0) rc = ddp_launch_back_pass_gps(h, &d, cx, cu, cxx, cxu, cuu, fx, fu, &t, lims, kp, nullptr, K, k, Sigmai, Sigma, Vx, Vxx, dV, div);
+            if (rc) return rc;
+            int pending = 0;
+            if ((rc = dual(1, it)) || (rc = poll(&pending))) return rc;                                    // :103-105
+            if (!pending) break;
+            DDP_CHECK(guard < 200, "ilqgkl: back_pass_gps keeps diverging (the reference would loop forever)");
+        }
+        if ((rc = ddp_forward_pass_f64_dev(h, p, K, k, x0c, kp, x0, &one, 1, lims, nullptr, x, u, cost, cs))) return rc;                  // :132
+        if ((rc = ddp_forward_covariance_f64_dev(h, (int)n, (int)m, (int)N, (int)B, model_fx, model_fx_batched, R1, K, Sigma, sig))) return rc;   // :133
+        if ((rc = ddp_kl_div_f64_dev(h, (int)n, (int)m, (int)N, (int)B, x, x0, sig, K, k, Sigma, Kp, kzero, Sp, Sip, kld, klm))) return rc;
+        if ((rc = dual(2, it)) || (rc = poll(&live))) return rc;                                           // :141, :169-177
+    }
+    hipLaunchKernelGGL(kl_summary_kernel, dim3((unsigned)B), dim3(DDP_WAVE), 0, st, (int)m, (int)N, s, (const double *)k, kp, (const double *)cs,
+                       cost0, (const double *)dV, stats);
+    DDP_HIP(hipGetLastError());
+    DDP_HIP(hipStreamSynchronize(st));
+    if (iters_out) *iters_out = it - 1;
+    return 0;
+}
+
+
+// host-pointer flavour of the driver: separate device allocations (the driver owns the handle's scratch), one upload, one download
+int ddp_ilqgkl_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqgkl_opts *o, const double *x0, const double *cost0,
+                   const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                   const double *model_fx, int model_fx_batched, const double *R1, const double *lims, double *etab,
+                   double *x, double *u, double *K, double *Sigma, double *Sigmai, double *Vx, double *Vxx, double *cost,
+                   double *dV, double *stats, int *iters_out)
+{
+    DDP_DEVICE(h);
+    DDP_CHECK(p && x0 && Kp && kp && Sp && Sip && model_fx && R1, "ilqgkl: null argument");
+    const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p), NB = N * B;
+    const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? B : 1);
+    struct Buf { void *d; void *hdst; size_t bytes; };
+    std::vector<Buf> bufs;
+    bool failed = false;
+    auto dev = [&](const void *src, void *dst, size_t bytes) -> void * {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) { failed = true; return nullptr; }
+        if (src && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) failed = true;
+        bufs.push_back({d, dst, bytes});
+        return d;
+    };
+    ddp_problem pd = *p;
+    if (p->kind == DDP_PROBLEM_LQ) { pd.A = (double *)dev(p->A, nullptr, n * n * dc * 8); pd.Bm = (double *)dev(p->Bm, nullptr, n * m * dc * 8); }
+    pd.Q = (double *)dev(p->Q, nullptr, n * n * 8);
+    pd.R = (double *)dev(p->R, nullptr, m * m * 8);
+    const double *dx0 = (double *)dev(x0, nullptr, n * NB * 8), *dc0 = cost0 ? (double *)dev(cost0, nullptr, B * 8) : nullptr,
+                 *dKp = (double *)dev(Kp, nullptr, m * n * NB * 8), *dkp = (double *)dev(kp, nullptr, m * NB * 8),
+                 *dSp = (double *)dev(Sp, nullptr, m * m * NB * 8), *dSip = (double *)dev(Sip, nullptr, m * m * NB * 8),
+                 *dmf = (double *)dev(model_fx, nullptr, n * n * N * (model_fx_batched ? B : 1) * 8), *dR1 = (double *)dev(R1, nullptr, n * n * 8),
+                 *dl = lims ? (double *)dev(lims, nullptr, 2 * m * 8) : nullptr;
+    double *det = etab ? (double *)dev(etab, etab, 3 * B * 8) : nullptr;
+    double *dx = (double *)dev(nullptr, x, n * NB * 8), *du = (double *)dev(nullptr, u, m * NB * 8), *dK = (double *)dev(nullptr, K, m * n * NB * 8),
+           *dS = (double *)dev(nullptr, Sigma, m * m * NB * 8), *dSi = (double *)dev(nullptr, Sigmai, m * m * NB * 8),
+           *dVx = (double *)dev(nullptr, Vx, n * NB * 8), *dVxx = (double *)dev(nullptr, Vxx, n * n * NB * 8),
+           *dcost = (double *)dev(nullptr, cost, CL * B * 8), *ddV = (double *)dev(nullptr, dV, 2 * B * 8),
+           *dst = (double *)dev(nullptr, stats, DDP_ILQGKL_NSTATS * B * 8);
+    int rc = failed ? -2 : 0;
+    if (failed) ddp_set_error("ilqgkl: device allocation / upload failed");
+    if (!rc) rc = ddp_ilqgkl_f64_dev(h, &pd, o, dx0, dc0, dKp, dkp, dSp, dSip, dmf, model_fx_batched, dR1, dl, det, dx, du, dK, dS, dSi, dVx, dVxx,
+                                     dcost, ddV, dst, iters_out);
+    if (!rc)
+        for (auto &bf : bufs)
+            if (bf.hdst && hipMemcpyAsync(bf.hdst, bf.d, bf.bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = -2;
+    hipStreamSynchronize(h->stream);
+    for (auto &bf : bufs) hipFree(bf.d);
+    return rc;
 }
 
 // ---- host-pointer flavours (stage through the handle's scratch; PCIe-inclusive, for drop-in use with host arrays)

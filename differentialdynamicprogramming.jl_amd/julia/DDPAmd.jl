@@ -14,6 +14,7 @@
 #     DDPAmd.boxQP(H,g,lower,upper,x0)                                    ↔ src/boxQP.jl:29-188
 #     DDPAmd.forward_pass(traj_new,x0,u,x,α,problem,lims)                 ↔ src/forward_pass.jl:9-33
 #     DDPAmd.∇kl / back_pass_gps / forward_covariance / kl_div_wiki       ↔ src/klutils.jl, backward_pass.jl:259-350, forward_pass.jl:37-56
+#     DDPAmd.iLQGkl(problem, x0, traj_prev, fx_model, R1; ...)            ↔ src/iLQGkl.jl:25-178 (single KL constraint, one library call)
 #   device-resident (`DevArray`, or any array type whose `pointer` is a device pointer, e.g. AMDGPU.ROCArray)
 #     back_pass_dev!, forward_pass_dev!, df_dev!, iLQG_dev!
 module DDPAmd
@@ -88,6 +89,13 @@ struct KLCostTerms
     cuu::Ptr{Float64}
     eta::Ptr{Float64}
     eta_tv::Cint
+end
+
+struct ILQGKLOpts
+    kl_step::Cdouble
+    max_iter::Cint
+    etabracket::NTuple{3,Cdouble}
+    del0::Cdouble
 end
 
 # ddp_kl_dual (include/ddp_amd.h): device pointers
@@ -639,6 +647,54 @@ function kl_dual_update!(s::KLDualState, kl_step::Real, klmean::DevArray{Float64
     GC.@preserve s klmean check(@ccall libddp.ddp_kl_dual_update_f64_dev(s.handle.ptr::Ptr{Cvoid}, B::Cint, kl_step::Cdouble, Ref(_kldual(s))::Ptr{KLDual},
                                                                           klmean.ptr::Ptr{Float64}, c::Ptr{Cint})::Cint)
     return Int(c[])
+end
+
+"""
+    iLQGkl(problem, x0, traj_prev, fx_model, R1; kl_step=1, lims=[], max_iter=50, cost, ηbracket=[1e-8,1,1e16], del0=1e-4)
+        -> x, u, traj_new, Vx, Vxx, cost, trace
+
+The single-constraint loop of src/iLQGkl.jl:25-178,234-252 as ONE library call (`ddp_ilqgkl_f64`): `problem` stands in for the three
+closures, `fx_model[n,n,N(,B)]` / `R1[n,n]` are what `df(model,·)` / `covariance(model,·)` of the un-vendored model package return.
+`x0[n,N(,B)]` must be pre-rolled and `cost` given (:66-73); with a batch every trajectory owns its η bracket (`ηbracket` 3 or 3×B).
+`trace` is a Dict: :status (1 SUCCESS :169, 2 η > ηmax :174, 3 max_iter :234), :iter, :n_backpass, :satisfied, :η (3×B), :divergence,
+:cost, :improvement, :expected_reduction, :grad_norm, :dV.  `traj_prev.k` is left untouched (the reference zeroes and restores it, :51,247).
+"""
+function iLQGkl(problem::RegisteredProblem, x0, traj_prev, fx_model, R1; kl_step=1.0, lims=[], max_iter=50, cost=[],
+                ηbracket=[1e-8, 1.0, 1e16], del0=1e-4, constrain_per_step=false, handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
+    constrain_per_step && error("constrain_per_step (iLQGkl.jl:180-232) is not offloaded (it cannot run upstream either: klutils.jl:195)")
+    isempty(cost) && error("Initial trajectory supplied, initial cost must also be supplied")                 # :69
+    batched = ndims(x0) == 3
+    n, N = size(x0, 1), size(x0, 2)
+    u0 = _f64(traj_prev.k)
+    m = size(u0, 1)
+    size(u0, 2) == N || error("pre-rolled initial trajectory must be of correct length (size(x0,2) == N)")     # :72
+    B = batched ? size(x0, 3) : 1
+    P = cproblem(problem, N, B)
+    CL = cost_len(problem, N)
+    x0 = _f64(x0); Kp = _f64(traj_prev.K); Sp = _f64(traj_prev.Σ); Sip = _f64(traj_prev.Σi); fxm = _f64(fx_model); R1 = _f64(R1)
+    c0 = batched ? (ndims(cost) == 2 ? vec(sum(cost, dims=1)) : _f64(vec(cost))) : [Float64(sum(cost))]      # only sum(cost) enters (:74,135)
+    length(c0) == B || error("cost must hold one entry (or one column) per trajectory")
+    etab = ndims(ηbracket) == 2 ? _f64(copy(ηbracket)) : repeat(_f64(ηbracket), 1, B)                        # copy (:52)
+    size(etab) == (3, B) || error("ηbracket must be a 3-vector or 3×B")
+    limsp = _lims(lims)
+    o = ILQGKLOpts(kl_step, max_iter, (1e-8, 1.0, 1e16), del0)
+    x = zeros(n, N, B); u = zeros(m, N, B); K = zeros(m, n, N, B); S = zeros(m, m, N, B); Si = zeros(m, m, N, B)
+    Vx = zeros(n, N, B); Vxx = zeros(n, n, N, B); cnew = zeros(CL, B); dV = zeros(2, B); st = zeros(12, B)
+    its = Ref{Cint}(0)
+    GC.@preserve problem x0 c0 Kp u0 Sp Sip fxm R1 limsp etab x u K S Si Vx Vxx cnew dV st begin
+        check(@ccall libddp.ddp_ilqgkl_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGKLOpts}, x0::Ptr{Float64},
+            c0::Ptr{Float64}, Kp::Ptr{Float64}, u0::Ptr{Float64}, Sp::Ptr{Float64}, Sip::Ptr{Float64}, fxm::Ptr{Float64},
+            (ndims(fxm) == 4)::Cint, R1::Ptr{Float64}, _ptr_or_null(limsp)::Ptr{Float64}, etab::Ptr{Float64},
+            x::Ptr{Float64}, u::Ptr{Float64}, K::Ptr{Float64}, S::Ptr{Float64}, Si::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64},
+            cnew::Ptr{Float64}, dV::Ptr{Float64}, st::Ptr{Float64}, its::Ptr{Cint})::Cint)
+    end
+    trace = Dict{Symbol,Any}(:status => Int.(st[1, :]), :iter => Int.(st[2, :]), :n_backpass => Int.(st[3, :]), :satisfied => st[4, :] .!= 0,
+                             :η => etab, :divergence => st[8, :], :cost => st[9, :], :improvement => st[10, :],
+                             :expected_reduction => st[11, :], :grad_norm => st[12, :], :dV => dV, :batch_iterations => Int(its[]))
+    sel(a) = batched ? a : dropdims(a, dims=ndims(a))
+    x, u, K, S, Si, Vx, Vxx, cnew = map(sel, (x, u, K, S, Si, Vx, Vxx, cnew))
+    traj_new = policy(N, n, m, K, copy(u), S, Si)                                                             # traj_new.k = copy(u) (:239)
+    return x, u, traj_new, Vx, Vxx, cnew, trace
 end
 
 end # module

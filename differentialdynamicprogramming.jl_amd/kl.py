@@ -7,8 +7,8 @@
     calc_η(xnew,xold,sigmanew,ηbracket,traj_new,traj_prev,kl_step)   src/klutils.jl:112-133   (scalar kl_step)
     iLQGkl(problem,x0,traj_prev,model; kl_step, ...)                 src/iLQGkl.jl:25-178,234-252 (single KL constraint)
 
-All array work runs in libddp_amd.so (HIP kernels of csrc/back_pass.hip [GPS variant] and csrc/kl.hip); the η-bracket
-update and the outer loop are the scalar host logic of the reference, kept per trajectory for a batch.  A trailing
+All array work runs in libddp_amd.so (HIP kernels of csrc/back_pass.hip [GPS variant] and csrc/kl.hip), and so does the
+outer loop of iLQGkl with its per-trajectory η bracket (``ddp_ilqgkl_f64``).  A trailing
 axis is the batch of independent trajectories.  No CPU fallback.
 
 `model`: the reference calls `df(model,x,u)` and `covariance(model,x,u)` of the un-vendored LinearTimeVaryingModelsBase;
@@ -173,7 +173,8 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
     ``problem`` standing in for the three closures (single KL constraint, iLQGkl.jl:91-178).  ``x0[n,N(,B)]`` is the
     pre-rolled trajectory (the reference errors otherwise, :71-72) and ``cost`` its cost (:69).
     Returns ``(x, u, traj_new, Vx, Vxx, cost, trace)``; ``trace`` is a dict of per-trajectory arrays
-    (status 1 SUCCESS :169 / 2 η > ηmax :174 / 3 max_iter :234, iter, η bracket, divergence, n_backpass)."""
+    (status 1 SUCCESS :169 / 2 η > ηmax :174 / 3 max_iter :234, iter, η bracket, divergence, n_backpass).
+    The loop runs inside ONE library call (``ddp_ilqgkl_f64``); ``DDP_KL_HOSTLOOP=1`` selects the loop on host arrays instead."""
     if constrain_per_step:
         raise NotImplementedError("constrain_per_step (iLQGkl.jl:180-232) is not offloaded")
     if cost is None or np.size(cost) == 0:
@@ -191,6 +192,10 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
     etab = np.asarray(ηbracket, dtype=np.float64)
     etab = etab.copy() if etab.shape == (3, B) else np.repeat(etab.reshape(3)[:, None], B, 1)                    # copy (:52); [3,B]: one bracket per trajectory
     del0 = np.full(B, float(del0))
+    import os as _os
+    if _os.environ.get("DDP_KL_HOSTLOOP") != "1":
+        return _ilqgkl_call(h, problem, model, prev0, lims, kl_step, max_iter, x, u, cost, etab, float(del0[0]), batched)
+    # ---- DDP_KL_HOSTLOOP=1: the loop of the reference on host arrays, one library call per array operation (cross-check in the tests)
     # STEP 1 (:86): the KL demos hand 3-D arrays to back_pass_gps (demo_linear.jl:91-101)
     fx, fu, _, _, _, cx, cu, cxx, cxu, cuu = df(problem, x, u, handle=h)
     dynb = bool(getattr(problem, "dyn_batched", False))
@@ -201,11 +206,6 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
     divergence = np.zeros(B); satisfied = np.zeros(B, dtype=bool)
     live = np.ones(B, dtype=bool)
     out = None
-    import os as _os
-    if _os.environ.get("DDP_KL_HOSTLOOP") != "1":
-        out = _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u, (cx, cu, cxx, cxu, cuu, fx, fu), kl, dynb,
-                                  etab, del0, status, iters, nback, divergence, satisfied, live)
-        max_iter = 0                                           # the host-array loop below is the reference for tests (DDP_KL_HOSTLOOP=1)
     for it in range(1, max_iter + 1):                                                                           # :91
         idx = np.flatnonzero(live)
         if idx.size == 0:
@@ -281,105 +281,38 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
 
 
 
-def _ilqgkl_device_loop(h, problem, model, prev0, lims, kl_step, max_iter, x, u, derivs, kl, dynb, etab, del0, status, iters, nback,
-                        divergence, satisfied, live):
-    """The iteration of iLQGkl (iLQGkl.jl:91-178) with every array resident on the device, the dual variable η and its bracket
-    included (ddp_kl_dual_*): per iteration only the counts of live / still-diverging trajectories come down.  Each pass recomputes ALL trajectories with their current η — a trajectory that has
-    already met its constraint keeps its η, so it is recomputed to the same result and the final arrays are right for everyone
-    (the host-array loop, DDP_KL_HOSTLOOP=1, gathers the live ones instead and moved ~1.5 GB over PCIe per pass at B = 4096)."""
-    L_ = _lib.lib()
+def _ilqgkl_call(h, problem, model, prev0, lims, kl_step, max_iter, x, u, cost, etab, del0, batched):
+    """the whole loop of iLQGkl (iLQGkl.jl:91-178) as ONE library call: ``ddp_ilqgkl_f64`` (csrc/kl.hip)"""
     n, N, B = x.shape
     m = u.shape[0]
-    cx, cu, cxx, cxu, cuu, fx, fu = derivs
-    bufs = []
+    dp = _DevProblem(problem, N, B)
+    CL = dp.cost_len
+    c0 = np.asarray(cost, dtype=np.float64)                                                      # only sum(cost) enters (:74,135)
+    c0 = (c0.sum(axis=0) if c0.ndim == 2 else c0.reshape(-1)) if batched else np.array([c0.sum()])   # batch: [CL,B] per-step costs or [B] sums
+    c0 = np.ascontiguousarray(np.broadcast_to(c0, (B,)))
+    mfx, R1 = _lib.f64(model.fx), _lib.f64(model.R1)
+    Kp, Sp, Sip = _lib.f64(prev0.K), _lib.f64(prev0.Σ), _lib.f64(prev0.Σi)
+    Lh = _lims(lims)
+    o = _lib.ILQGKLOpts()
+    _lib.lib().ddp_ilqgkl_default_opts(_C.byref(o))
+    o.kl_step, o.max_iter, o.del0 = float(kl_step), int(max_iter), float(del0)
+    eb = np.asfortranarray(etab)
+    xo = np.zeros((n, N, B), order="F"); uo = np.zeros((m, N, B), order="F"); K = np.zeros((m, n, N, B), order="F")
+    S = np.zeros((m, m, N, B), order="F"); Si = np.zeros((m, m, N, B), order="F"); Vx = np.zeros((n, N, B), order="F")
+    Vxx = np.zeros((n, n, N, B), order="F"); co = np.zeros((CL, B), order="F"); dV = np.zeros((2, B), order="F")
+    st = np.zeros((_lib.ILQGKL_NSTATS, B), order="F")
+    _lib.check(_lib.lib().ddp_ilqgkl_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x), _lib.ptr(c0), _lib.ptr(Kp), _lib.ptr(u),
+                                         _lib.ptr(Sp), _lib.ptr(Sip), _lib.ptr(mfx), int(mfx.ndim == 4), _lib.ptr(R1), _lib.ptr(Lh), _lib.ptr(eb),
+                                         *map(_lib.ptr, (xo, uo, K, S, Si, Vx, Vxx, co, dV, st)), None))
+    trace = dict(status=st[0].astype(int), iter=st[1].astype(int), η=eb, divergence=st[7].copy(), satisfied=st[3] != 0,
+                 n_backpass=st[2].astype(int), dV=dV, cost=st[8].copy(), improvement=st[9].copy(), expected_reduction=st[10].copy(),
+                 grad_norm=st[11].copy())
+    if not batched:
+        traj_new = GaussianPolicy(N, n, m, K[..., 0], uo[..., 0].copy(), S[..., 0], Si[..., 0])                  # traj_new.k = copy(u) (:239)
+        trace = {k_: (v[..., 0] if isinstance(v, np.ndarray) else v) for k_, v in trace.items()}
+        return xo[..., 0], uo[..., 0], traj_new, Vx[..., 0], Vxx[..., 0], co[..., 0], trace
+    return xo, uo, GaussianPolicy(N, n, m, K, uo.copy(), S, Si), Vx, Vxx, co, trace
 
-    def up(a):
-        p_ = h.to_device(_lib.f64(a)); bufs.append(p_); return p_
-
-    def up_i(a):
-        p_ = h.malloc(a.nbytes); bufs.append(p_)
-        _lib.check(L_.ddp_memcpy_h2d(h.raw, p_, _lib.ptr(a), _C.c_size_t(a.nbytes)))
-        return p_
-
-    def dev(shape, dtype=np.float64):
-        p_ = h.malloc(int(np.prod(shape)) * np.dtype(dtype).itemsize); bufs.append(p_); return p_
-    try:
-        d_cx, d_cu, d_cxx, d_cxu, d_cuu, d_fx, d_fu = map(up, (cx, cu, cxx, cxu, cuu, fx, fu))
-        d_kl = [up(a) for a in kl]
-        d_x, d_u, d_x0 = up(x), up(u), up(x[:, 0, :])
-        d_pK, d_pk, d_pS, d_pSi = up(prev0.K), up(prev0.k), up(prev0.Σ), up(prev0.Σi)
-        mfx = _lib.f64(model.fx)
-        d_mfx, d_R1 = (d_fx if mfx is fx else up(mfx)), up(model.R1)
-        Lh = _lims(lims)
-        d_L = up(Lh) if Lh is not None else None
-        d_eta = dev((B,))
-        d_K, d_k, d_Quu, d_Quui = dev((m, n, N, B)), dev((m, N, B)), dev((m, m, N, B)), dev((m, m, N, B))
-        d_Vx, d_Vxx, d_dV, d_div = dev((n, N, B)), dev((n, n, N, B)), dev((2, B)), dev((B,), np.int32)
-        # registered problem with device-resident parameters
-        P = _lib.Problem()
-        P.kind, P.n, P.m, P.N, P.B = problem.kind, n, m, N, B
-        P.Q, P.R = up(problem.Q), up(np.atleast_2d(problem.R))
-        Qh, Rh = np.asarray(problem.Q, float), np.atleast_2d(np.asarray(problem.R, float))
-        P.cost_diag = int(not np.any(Qh - np.diag(np.diag(Qh))) and not np.any(Rh - np.diag(np.diag(Rh))))
-        if problem.kind == 0:
-            P.A, P.Bm = up(problem.A), up(problem.B)
-            P.dyn_tv, P.dyn_batched = int(problem.dyn_tv), int(problem.dyn_batched)
-        else:
-            P.g, P.l, P.h, P.d = problem.g, problem.l, problem.h, problem.d
-            for i in range(4):
-                P.goal[i] = float(problem.goal[i])
-        CL = N + 1 if problem.kind == 1 else N
-        d_xn, d_un, d_cn, d_cs = dev((n, N, B)), dev((m, N, B)), dev((CL, B)), dev((B,))
-        d_sig, d_kld, d_klm = dev((n + m, n + m, N, B)), dev((N, B)), dev((B,))
-        desc = _lib.BPDesc(n, m, N, B, 1, int(fx.ndim == 4), 1, int(cxx.ndim == 4), 1, int(Lh is not None))
-        terms = _lib.KLCostTerms(*d_kl, d_eta, 0)
-        one = np.array([1.0])
-        # the dual variable lives on the device (ddp_kl_dual_*, csrc/kl.hip): per iteration only three counts cross PCIe.
-        # calc_η moves ηbracket[2, b] BEFORE the `η > 0.999 ηmax` exit test (iLQGkl.jl:141,174): a trajectory that leaves that way
-        # keeps the results of the η it was computed with (the reference breaks right there), so `eta` is only rewritten for
-        # live trajectories; the finished ones are recomputed to the same result by every later pass.
-        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)                                                 # noqa: E731
-        d_etab, d_del, d_dvg = up(etab), up(del0), up(divergence)
-        d_sat, d_stat, d_live, d_pend = up_i(i32(satisfied)), up_i(i32(status)), up_i(i32(live)), dev((B,), np.int32)
-        d_it, d_nb = up_i(i32(iters)), up_i(i32(nback))
-        _lib.check(L_.ddp_memcpy_h2d(h.raw, d_eta, _lib.ptr(np.ascontiguousarray(etab[1])), _C.c_size_t(8 * B)))
-        dual = _lib.KLDual(d_etab, d_eta, d_del, d_dvg, d_sat, d_stat, d_live, d_pend, d_it, d_nb)
-        cnt = _C.c_int(0)
-        for it in range(1, max_iter + 1):                                                                       # :91
-            _lib.check(L_.ddp_kl_dual_begin_f64_dev(h.raw, B, it, _C.byref(dual), _C.byref(cnt)))
-            if cnt.value == 0:
-                break
-            guard = 0
-            while True:                                        # back passes until the regularised Quu is positive definite (:95-122)
-                _lib.check(L_.ddp_back_pass_gps_f64_dev(h.raw, _C.byref(desc), d_cx, d_cu, d_cxx, d_cxu, d_cuu, d_fx, d_fu, _C.byref(terms),
-                                                        d_L, d_u, None, d_K, d_k, d_Quu, d_Quui, d_Vx, d_Vxx, d_dV, d_div))
-                _lib.check(L_.ddp_kl_dual_retry_f64_dev(h.raw, B, _C.byref(dual), d_div, _C.byref(cnt)))        # :103-105
-                if cnt.value == 0:
-                    break
-                guard += 1
-                if guard > 200:
-                    raise RuntimeError("back_pass_gps keeps diverging (the reference would loop forever)")
-            _lib.check(L_.ddp_forward_pass_f64_dev(h.raw, _C.byref(P), d_K, d_k, d_x0, d_u, d_x, _lib.ptr(one), 1, d_L, None,
-                                                   d_xn, d_un, d_cn, d_cs))                                     # :132
-            _lib.check(L_.ddp_forward_covariance_f64_dev(h.raw, n, m, N, B, d_mfx, int(mfx.ndim == 4), d_R1, d_K, d_Quui, d_sig))   # :133
-            _lib.check(L_.ddp_kl_div_f64_dev(h.raw, n, m, N, B, d_xn, d_x, d_sig, d_K, d_k, d_Quui, d_pK, d_pk, d_pS, d_pSi, d_kld, d_klm))
-            _lib.check(L_.ddp_kl_dual_update_f64_dev(h.raw, B, _C.c_double(kl_step), _C.byref(dual), d_klm, _C.byref(cnt)))   # :141, :169-177
-        etab[...] = h.to_host(d_etab, (3, B))
-        divergence[...] = h.to_host(d_dvg, (B,))
-        satisfied[...] = h.to_host(d_sat, (B,), np.int32) != 0
-        status[...] = h.to_host(d_stat, (B,), np.int32)
-        live[...] = h.to_host(d_live, (B,), np.int32) != 0
-        iters[...] = h.to_host(d_it, (B,), np.int32)
-        nback[...] = h.to_host(d_nb, (B,), np.int32)
-        return dict(x=h.to_host(d_xn, (n, N, B)), u=h.to_host(d_un, (m, N, B)), cost=h.to_host(d_cn, (CL, B)), K=h.to_host(d_K, (m, n, N, B)),
-                    S=h.to_host(d_Quui, (m, m, N, B)), Si=h.to_host(d_Quu, (m, m, N, B)), Vx=h.to_host(d_Vx, (n, N, B)),
-                    Vxx=h.to_host(d_Vxx, (n, n, N, B)), dV=h.to_host(d_dV, (2, B)))
-    finally:
-        for p_ in bufs:
-            try:
-                h.free(p_)
-            except Exception:
-                pass
 
 def _tv(a, N, batched=False):
     """give a [r,c] (or, batched, [r,c,B]) array the time axis back_pass_gps wants: [r,c,N] / [r,c,N,B]"""

@@ -341,6 +341,37 @@ int ddp_kl_dual_begin_f64_dev(ddp_handle h, int B, int it, const ddp_kl_dual *s,
 int ddp_kl_dual_retry_f64_dev(ddp_handle h, int B, const ddp_kl_dual *s, const int32_t *diverge, int *n_pending);
 int ddp_kl_dual_update_f64_dev(ddp_handle h, int B, double kl_step, const ddp_kl_dual *s, const double *klmean, int *n_live);
 
+/* ---- iLQGkl — replaces iLQGkl(dynamics,costfun,derivs,x0,traj_prev,model; kl_step,lims,max_iter,cost,ηbracket,del0) ------------
+ * reference: src/iLQGkl.jl:25-178,234-252 (single KL constraint; the per-time-step branch :180-232 cannot run upstream), called from
+ * src/demo_linear.jl:124.  The whole loop — derivs, ∇kl, back_pass_gps until the KL-regularised Quu is positive definite (η += del;
+ * del *= 2), forward_pass(α = 1), forward_covariance, kl_div_wiki, calc_η, the exit tests — runs on device-resident arrays with one η
+ * bracket per trajectory; the registered problem `p` stands in for the three closures, the model is the arrays `df(model,·)` /
+ * `covariance(model,·)` would return.
+ * inputs : x0[n,N,B] pre-rolled trajectory (:66-73), cost0[B] = sum(cost) of it (NULL: costfun(x0,u); the reference insists on `cost`),
+ *          traj_prev = Kp[m,n,N,B], kp[m,N,B] (the previous controls u, :45), Sp / Sip[m,m,N,B]; model_fx[n,n,N] or [n,n,N,B], R1[n,n];
+ *          lims[m,2] or NULL; etab[3,B] in/out (NULL: o->etabracket for every trajectory)
+ * outputs: x[n,N,B] u[m,N,B] (traj_new.k = copy(u), :239) K[m,n,N,B] Sigma = inv(Quu) and Sigmai = Quu [m,m,N,B] Vx Vxx cost[CL,B] dV[2,B]
+ *          stats[DDP_ILQGKL_NSTATS,B] = [status (1 SUCCESS :169, 2 η > ηmax :174, 3 max_iter :234), iter, n_backpass, satisfied,
+ *          ηmin, η, ηmax, divergence, sum(cost), Δcost (:135), expected_reduction (:136), grad_norm (:125)]; *iters = batch-level iterations */
+typedef struct {
+    double kl_step;        /* 1                */
+    int    max_iter;       /* 50               */
+    double etabracket[3];  /* 1e-8, 1, 1e16    */
+    double del0;           /* 1e-4             */
+} ddp_ilqgkl_opts;
+void ddp_ilqgkl_default_opts(ddp_ilqgkl_opts *o);
+#define DDP_ILQGKL_NSTATS 12
+int ddp_ilqgkl_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqgkl_opts *o, const double *x0, const double *cost0,
+                       const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                       const double *model_fx, int model_fx_batched, const double *R1, const double *lims, double *etab,
+                       double *x, double *u, double *K, double *Sigma, double *Sigmai, double *Vx, double *Vxx, double *cost,
+                       double *dV, double *stats, int *iters);
+int ddp_ilqgkl_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqgkl_opts *o, const double *x0, const double *cost0,
+                   const double *Kp, const double *kp, const double *Sp, const double *Sip,
+                   const double *model_fx, int model_fx_batched, const double *R1, const double *lims, double *etab,
+                   double *x, double *u, double *K, double *Sigma, double *Sigmai, double *Vx, double *Vxx, double *cost,
+                   double *dV, double *stats, int *iters);
+
 #ifdef __cplusplus
 }
 #endif

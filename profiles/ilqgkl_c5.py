@@ -1,6 +1,6 @@
-"""C5 (= C3 + KL constraint): a batch of KL-constrained pendcart solves through the host mirror (kl.iLQGkl): the iteration runs on
-device-resident arrays with the dual variable η updated on the device (ddp_kl_dual_*); the time includes the upload of the
-derivative arrays and the download of the results."""
+"""C5 (= C3 + KL constraint): a batch of KL-constrained pendcart solves.  First through the host mirror (kl.iLQGkl -> ddp_ilqgkl_f64:
+the loop is one library call; the time includes the upload of the inputs and the download of the results into pageable host arrays),
+then through ddp_ilqgkl_f64_dev with every array resident on the device (what the kernels and the loop cost)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,3 +24,32 @@ for it in range(2):
     dt = time.perf_counter() - t
     print("C5 iLQGkl pendcart B=%d N=%d: %.3f s, status counts %s, mean iterations %.1f, mean back passes %.1f, mean cost %.1f -> %.1f"
           % (B, N, dt, dict(zip(*np.unique(tr["status"], return_counts=True))), tr["iter"].mean(), tr["n_backpass"].mean(), cost0.mean(), cost.sum(axis=0).mean()))
+
+# ---- device-resident: ddp_ilqgkl_f64_dev
+import ctypes as C
+from ddp_amd import _lib
+L, h = _lib.lib(), ddp_amd.default_handle()
+up = lambda a: h.to_device(_lib.f64(a))                                    # noqa: E731
+dev = lambda *sh: h.malloc(int(np.prod(sh)) * 8)                           # noqa: E731
+P = _lib.Problem()
+P.kind, P.n, P.m, P.N, P.B = 1, 4, 1, N, B
+P.Q, P.R, P.cost_diag = up(prob.Q), up(prob.R), 1
+P.g, P.l, P.h, P.d = prob.g, prob.l, prob.h, prob.d
+for i in range(4):
+    P.goal[i] = float(prob.goal[i])
+o = _lib.ILQGKLOpts()
+L.ddp_ilqgkl_default_opts(C.byref(o))
+o.kl_step, o.max_iter = 0.05, 30
+ins = [up(x), up(cost0), up(np.zeros((1, 4, N, B))), up(u), up(eye), up(eye), up(fx)]
+dR1, dl = up(R1), up(np.asfortranarray(lims))
+outs = [dev(4, N, B), dev(1, N, B), dev(1, 4, N, B), dev(1, 1, N, B), dev(1, 1, N, B), dev(4, N, B), dev(4, 4, N, B), dev(N + 1, B), dev(2, B), dev(12, B)]
+its = C.c_int(0)
+for rep in range(4):
+    h.sync()
+    t = time.perf_counter()
+    _lib.check(L.ddp_ilqgkl_f64_dev(h.raw, C.byref(P), C.byref(o), *ins[:7], 1, dR1, dl, None, *outs, C.byref(its)))
+    h.sync()
+    dt = time.perf_counter() - t
+    st = h.to_host(outs[9], (12, B))
+    print("C5 ddp_ilqgkl_f64_dev B=%d N=%d: %.4f s device-resident, %d batch iterations, mean iterations %.2f, mean back passes %.2f, same as host call: %s"
+          % (B, N, dt, its.value, st[1].mean(), st[2].mean(), bool(np.array_equal(st[0].astype(int), tr["status"]) and np.allclose(st[5], tr["η"][1], rtol=1e-12))))

@@ -11,9 +11,9 @@ mkdir -p $OUT $OUT/profiles
 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 for B in 1024 32768; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b$B -o stats -- python $REPO/bench.py --steps 50 --warmup 5 --batch $B --no-cpu-baseline --no-other-configs --fill-batch 0 > $OUT/stats_b$B.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_b$B -o fetch -- python $REPO/bench.py --steps 3 --warmup 1 --preheat 0 --batch $B --no-cpu-baseline --no-other-configs --fill-batch 0 > $OUT/pmc_fetch_b$B.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_b$B -o write -- python $REPO/bench.py --steps 3 --warmup 1 --preheat 0 --batch $B --no-cpu-baseline --no-other-configs --fill-batch 0 > $OUT/pmc_write_b$B.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b$B -o stats -- python $REPO/bench.py --steps 50 --warmup 5 --batch $B --no-cpu-baseline --no-other-configs --no-traffic --fill-batch 0 > $OUT/stats_b$B.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_b$B -o fetch -- python $REPO/bench.py --steps 3 --warmup 1 --preheat 0 --batch $B --no-cpu-baseline --no-other-configs --no-traffic --fill-batch 0 > $OUT/pmc_fetch_b$B.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_b$B -o write -- python $REPO/bench.py --steps 3 --warmup 1 --preheat 0 --batch $B --no-cpu-baseline --no-other-configs --no-traffic --fill-batch 0 > $OUT/pmc_write_b$B.log 2>&1
 done
 cd $REPO
 python profiles/summarize_profile.py $OUT $TAG > $OUT/profiles/${TAG}_summary.txt 2>&1

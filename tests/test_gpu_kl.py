@@ -168,6 +168,73 @@ def test_ilqgkl_bracket_exit_freezes_trajectory(ddp, monkeypatch):
         assert relerr(got, ref) < 1e-12
 
 
+def test_ilqgkl_dev_entry_matches_oracle(ddp):
+    """ddp_ilqgkl_f64_dev (the whole loop of iLQGkl.jl:91-178 in one call, device pointers): cost0 = NULL (costfun of the pre-rolled
+    trajectory), the caller's own η brackets, every row of stats[12, B] against the oracle's solve of each trajectory"""
+    import ctypes as C
+    import scipy.linalg as sla
+    from oracle import oracle_ctypes as oc
+    _lib = ddp._lib
+    L, h = _lib.lib(), ddp.default_handle()
+    rng = np.random.default_rng(77)
+    n, m, T, B, hh = 6, 2, 48, 6, 0.01
+    A0 = rng.standard_normal((n, n)); A = sla.expm(hh * (A0 - A0.T)); Bm = hh * rng.standard_normal((n, m))
+    Q, R = hh * np.eye(n), 0.1 * hh * np.eye(m)
+    u = 0.1 * rng.standard_normal((m, T, B)) * np.array([1.0, 2.0, 0.5, 3.0, 1.5, 0.8])
+    x = np.zeros((n, T, B)); x[:, 0, :] = 1.0 + 0.1 * rng.standard_normal((n, B))
+    for t in range(T - 1):
+        x[:, t + 1, :] = A @ x[:, t, :] + Bm @ u[:, t, :]
+    cost0 = 0.5 * np.einsum("itb,ij,jtb->b", x, Q, x) + 0.5 * np.einsum("itb,ij,jtb->b", u, R, u)
+    eye = np.repeat(np.repeat(np.eye(m)[:, :, None, None], T, 2), B, 3)
+    fx, R1 = np.repeat(A[:, :, None], T, 2), 1e-4 * np.eye(n)
+    etab = np.repeat(np.array([1e-8, 1.0, 1e16])[:, None], B, 1)
+    etab[:, 2] = [1e-8, 0.85, 0.9]                                          # leaves through the bracket test (status 2)
+    etab[1, 4] = 3.0
+    bufs = []
+
+    def up(a):
+        p_ = h.to_device(_lib.f64(a)); bufs.append(p_); return p_
+
+    def dev(*shape):
+        p_ = h.malloc(int(np.prod(shape)) * 8); bufs.append(p_); return p_
+    P = _lib.Problem()
+    P.kind, P.n, P.m, P.N, P.B = 0, n, m, T, B
+    P.A, P.Bm, P.Q, P.R, P.cost_diag = up(A), up(Bm), up(Q), up(R), 1
+    o = _lib.ILQGKLOpts()
+    L.ddp_ilqgkl_default_opts(C.byref(o))
+    assert (o.kl_step, o.max_iter, tuple(o.etabracket), o.del0) == (1.0, 50, (1e-8, 1.0, 1e16), 1e-4)           # iLQGkl.jl:25-44
+    o.kl_step, o.max_iter = 2e-4, 40
+    d_etab = up(etab)
+    d = dict(x=dev(n, T, B), u=dev(m, T, B), K=dev(m, n, T, B), S=dev(m, m, T, B), Si=dev(m, m, T, B), Vx=dev(n, T, B), Vxx=dev(n, n, T, B),
+             cost=dev(T, B), dV=dev(2, B), st=dev(12, B))
+    its = C.c_int(0)
+    try:
+        _lib.check(L.ddp_ilqgkl_f64_dev(h.raw, C.byref(P), C.byref(o), up(x), None, up(np.zeros((m, n, T, B))), up(u), up(eye), up(eye),
+                                        up(fx), 0, up(R1), None, d_etab, d["x"], d["u"], d["K"], d["S"], d["Si"], d["Vx"], d["Vxx"], d["cost"],
+                                        d["dV"], d["st"], C.byref(its)))
+        st = h.to_host(d["st"], (12, B)); eb = h.to_host(d_etab, (3, B))
+        xo, uo, Ko, So, Vxxo = (h.to_host(d[k_], sh) for k_, sh in (("x", (n, T, B)), ("u", (m, T, B)), ("K", (m, n, T, B)), ("S", (m, m, T, B)),
+                                                                      ("Vxx", (n, n, T, B))))
+        co, dV = h.to_host(d["cost"], (T, B)), h.to_host(d["dV"], (2, B))
+    finally:
+        for p_ in bufs:
+            h.free(p_)
+    p = oc.make_problem("lq", n, m, T, A=A, B=Bm, Q=Q, R=R)
+    assert {1, 2} <= set(st[0].astype(int)) and its.value == int(st[1].max())
+    for b in range(B):
+        pb = dict(K=np.zeros((m, n, T)), k=u[..., b], S=eye[..., b], Si=eye[..., b])
+        xr, ur, polr, vx, vxx, cr, info = oc.ilqgkl(p, x[..., b], float(cost0[b]), pb, dict(fx=fx, R1=R1), kl_step=2e-4, max_iter=40,
+                                                    etab=etab[:, b])
+        assert (int(st[0, b]), int(st[1, b]), int(st[2, b]), bool(st[3, b])) == (info["status"], info["iter"], info["n_backpass"], info["satisfied"]), b
+        assert relerr(st[4:7, b], info["eta"]) < RTOL and relerr(eb[:, b], info["eta"]) < RTOL
+        assert abs(st[7, b] - info["divergence"]) < 1e-7 * 2e-4
+        assert abs(st[8, b] - cr.sum()) < 1e-10 * abs(cr.sum()) and abs(st[9, b] - (cost0[b] - cr.sum())) < 1e-9 * abs(cost0[b])
+        assert abs(st[10, b] + info["dV"].sum()) < 1e-8 * np.abs(info["dV"]).max() and abs(st[11, b] - info["g_norm"]) < 1e-8 * info["g_norm"]
+        assert relerr(dV[:, b], info["dV"]) < RTOL
+        assert relerr(xo[..., b], xr) < RTOL and relerr(uo[..., b], ur) < RTOL and relerr(Ko[..., b], polr["K"]) < RTOL
+        assert relerr(So[..., b], polr["S"]) < RTOL and relerr(Vxxo[..., b], vxx) < RTOL and relerr(co[:, b], cr) < RTOL
+
+
 def test_ilqgkl_pendcart_c5_shape(ddp):
     """BASELINE config 5 = config 3 (pendcart, n=4, m=1, control limits) + the KL constraint; reduced N and B"""
     from oracle import oracle_ctypes as oc

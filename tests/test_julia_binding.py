@@ -22,11 +22,11 @@ CTYPES = {
     "int": {"Cint", "Int32"}, "size_t": {"Csize_t", "UInt"}, "double": {"Cdouble", "Float64"},
     "const ddp_bp_desc *": {"Ptr{BPDesc}"}, "const ddp_problem *": {"Ptr{CProblem}"}, "const ddp_ilqg_opts *": {"Ptr{ILQGOpts}"},
     "ddp_ilqg_opts *": {"Ptr{ILQGOpts}"}, "const ddp_qp_opts *": {"Ptr{QPOpts}"}, "const ddp_kl_cost_terms *": {"Ptr{KLCostTerms}"},
-    "const ddp_kl_dual *": {"Ptr{KLDual}"},
+    "const ddp_kl_dual *": {"Ptr{KLDual}"}, "const ddp_ilqgkl_opts *": {"Ptr{ILQGKLOpts}"}, "ddp_ilqgkl_opts *": {"Ptr{ILQGKLOpts}"},
     "const char *": {"Cstring"}, "void": {"Cvoid"},
 }
 STRUCTS = {"ddp_bp_desc": "BPDesc", "ddp_qp_opts": "QPOpts", "ddp_problem": "CProblem", "ddp_ilqg_opts": "ILQGOpts",
-           "ddp_kl_cost_terms": "KLCostTerms", "ddp_kl_dual": "KLDual"}
+           "ddp_kl_cost_terms": "KLCostTerms", "ddp_kl_dual": "KLDual", "ddp_ilqgkl_opts": "ILQGKLOpts"}
 FIELD = {"int": {"Cint"}, "double": {"Cdouble", "Float64"}, "const double *": {"Ptr{Float64}"}, "double *": {"Ptr{Float64}"},
          "int32_t *": {"Ptr{Int32}"}}
 
@@ -165,7 +165,7 @@ def test_binding_covers_the_hot_path_entry_points():
     need = {"ddp_create", "ddp_destroy", "ddp_last_error", "ddp_back_pass_f64", "ddp_back_pass_f64_dev", "ddp_boxqp_f64", "ddp_forward_pass_f64",
             "ddp_forward_pass_f64_dev", "ddp_df_f64", "ddp_df_f64_dev", "ddp_ilqg_ex_f64", "ddp_ilqg_ex_f64_dev", "ddp_ilqg_set_timing",
             "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_mpc_shift_f64_dev", "ddp_kl_terms_f64", "ddp_back_pass_gps_f64",
-            "ddp_forward_covariance_f64", "ddp_kl_div_f64"}
+            "ddp_forward_covariance_f64", "ddp_kl_div_f64", "ddp_ilqgkl_f64"}
     assert need <= called, need - called
 
 
