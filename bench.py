@@ -396,8 +396,8 @@ def other_configs():
     env.setdefault("DDP_BC_STEPS", "40")
     out = []
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c4"], env=env, capture_output=True, text=True,
-                           timeout=240)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c2tv", "c4", "c5"], env=env, capture_output=True,
+                           text=True, timeout=300)
         for line in r.stdout.splitlines():
             if line.startswith("{"):
                 out.append(json.loads(line))
@@ -410,7 +410,8 @@ def other_configs():
         try:
             tj = json.load(open(tfile))
             for o in out:
-                tag = "C3" if o["config"].startswith("C3") else "C4"
+                tag = o["config"].split()[0]
+                tag = "C2TV" if tag == "C2" else tag
                 o["back_pass_pmc_bytes_per_launch"] = tj.get("%s_back_pass_bytes_per_launch_B%d" % (tag, o["batch"]))
                 if tag == "C4":
                     o["back_pass_mfma_busy_frac"] = tj.get("C4_back_pass_mfma_busy_frac")

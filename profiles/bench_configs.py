@@ -1,6 +1,8 @@
 """Pass time (back_pass + forward_pass, one α) of the non-headline BASELINE configs with device-resident operands:
    C3  pendcart n=4 m=1 N=600, control limits (boxQP), B=4096
    C4  large-state LTV n=64 m=8 N=256, per-trajectory dynamics (a3 layout), B=1024 per GPU
+   C2TV the C2 shape (n=10, m=2, N=1000, B=1024) in the LTV / TV-cost layout (per-trajectory fx, fu, cxx, cxu, cuu; SURVEY 8d: 4.47 MB/pass)
+   C5  one pass of the KL-constrained iteration (C3 + KL): back_pass_gps + forward_pass + forward_covariance + kl_div_wiki, B=4096
 Prints one JSON line per config.  Informational; the graded line is bench.py's."""
 import ctypes as C
 import json
@@ -25,7 +27,7 @@ f64 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.flo
 empty = lambda c, dt=torch.float64: torch.empty(int(c), dtype=dt, device=dev)
 
 
-def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warmup=2, gen=None):
+def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warmup=2, gen=None, cost_desc=None):
     CL = N + 1 if prob.kind == 1 else N
     one = np.array([1.0])
     dl = f64(lims) if lims is not None else None
@@ -40,11 +42,14 @@ def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warm
     fx, fu, fx_tv, fx_b = (dfx, dfu, 1, 1) if pend else fx_desc
     dQ, dR = prob._Q, prob._R
     dcxu = torch.zeros(n * m, dtype=torch.float64, device=dev)
+    ctv = cb = 0
+    if cost_desc is not None:                                   # time-varying, per-trajectory cost Hessians (backward_pass.jl:179-215)
+        dQ, dcxu, dR, ctv, cb = cost_desc
     dlam = torch.ones(B, dtype=torch.float64, device=dev)
     dK, dk, dQuu, dVx, dVxx, ddV = empty(m * n * N * B), empty(m * N * B), empty(m * m * N * B), empty(n * N * B), empty(n * n * N * B), empty(2 * B)
     ddiv = torch.zeros(B, dtype=torch.int32, device=dev)
     dxn, dun, dcn, dcsn = empty(n * N * B), empty(m * N * B), empty(CL * B), empty(B)
-    desc = _lib.BPDesc(n, m, N, B, fx_tv, fx_b, 0, 0, regType, int(lims is not None))
+    desc = _lib.BPDesc(n, m, N, B, fx_tv, fx_b, ctv, cb, regType, int(lims is not None))
 
     def step(ev=None):
         if ev: L.ddp_event_record(h.raw, ev[0])
@@ -78,7 +83,7 @@ def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warm
         L.ddp_event_elapsed_ms(h.raw, ev[0], ev[1], C.byref(ms)); bp.append(ms.value)
         L.ddp_event_elapsed_ms(h.raw, ev[1], ev[2], C.byref(ms)); fp.append(ms.value)
     tv = fx_tv
-    bp_bytes = ((n + m) + (n * n + n * m if tv else 0) + (m if lims is not None else 0) + (m * n + m + n + n * n + m * m)) * 8 * (N - 1) * B
+    bp_bytes = ((n + m) + (n * n + n * m if tv else 0) + (n * n + n * m + m * m if ctv else 0) + (m if lims is not None else 0) + (m * n + m + n + n * n + m * m)) * 8 * (N - 1) * B
     fp_bytes = ((m * n + m + n + m) + (n * n + n * m if (tv and not pend) else 0) + (n + m + 1)) * 8 * N * B
     out = {"config": name, "n": n, "m": m, "N": N, "batch": B, "iterations_per_s": round(B * steps / el, 1), "ms_per_pass_batch": round(1e3 * el / steps, 3),
            "back_pass_ms": round(float(np.mean(bp)), 3), "forward_ms": round(float(np.mean(fp)), 3),
@@ -105,6 +110,121 @@ def c3(B=4096):
     nolims = os.environ.get("DDP_C3_NOLIMS") == "1"            # A/B: what the control limits (boxQP) cost
     run("C3 pendcart" + (" (no lims)" if nolims else " lims"), prob, n, m, N, B, f64(x0), f64(u0),
         None if nolims else float(os.environ.get("DDP_C3_LIMSCALE", "5.0")) * np.array([[-1.0, 1.0]]), 2, None)
+
+
+def c2tv(B=1024):
+    """the C2 shape (n=10, m=2, N=1000) in the LTV / TV-cost layout of backward_pass.jl:179-215 — fx, fu, cxx, cxu, cuu
+    time-varying and per trajectory, 4.47 MB per pass and trajectory: the north star's "coalesced HBM loads of fx/fu/cxx/cuu" at n = 10"""
+    import scipy.linalg as sla
+    n, m, N = 10, 2, 1000
+    rng = np.random.default_rng(1234)
+    torch.manual_seed(2)
+    h_ = 0.01
+    a0 = rng.standard_normal((n, n))
+    A = sla.expm(h_ * (a0 - a0.T))
+    Bm = h_ * rng.standard_normal((n, m))
+    NB = N * B
+    dA = (f64(A).reshape(1, -1) * (1.0 + 0.01 * torch.rand(NB, 1, dtype=torch.float64, device=dev))).reshape(-1).contiguous()
+    dB = (f64(Bm).reshape(1, -1) * (1.0 + 0.01 * torch.rand(NB, 1, dtype=torch.float64, device=dev))).reshape(-1).contiguous()
+    sc = 1.0 + 0.1 * torch.rand(NB, 1, dtype=torch.float64, device=dev)
+    dcxx = (f64(h_ * np.eye(n)).reshape(1, -1) * sc).reshape(-1).contiguous()
+    dcxu = torch.zeros(n * m * NB, dtype=torch.float64, device=dev)
+    dcuu = (f64(0.1 * h_ * np.eye(m)).reshape(1, -1) * sc).reshape(-1).contiguous()
+    prob = _lib.Problem()
+    prob.kind, prob.n, prob.m, prob.N, prob.B = 0, n, m, N, B
+    Q, R = f64(h_ * np.eye(n)), f64(0.1 * h_ * np.eye(m))
+    prob.A, prob.Bm, prob.Q, prob.R = dA.data_ptr(), dB.data_ptr(), Q.data_ptr(), R.data_ptr()
+    prob._Q, prob._R = Q, R
+    prob.dyn_tv, prob.dyn_batched, prob.cost_diag = 1, 1, 1
+    rng = np.random.default_rng(1000)
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
+    u0 = 0.1 * rng.standard_normal((m, N, B))
+    run("C2 LTV / TV-cost layout", prob, n, m, N, B, f64(x0), f64(u0), None, 1, (dA, dB, 1, 1), cost_desc=(dcxx, dcxu, dcuu, 1, 1))
+
+
+def c5(B=4096):
+    """one pass of the KL-constrained iteration at the C5 shape (pendcart n=4, m=1, N=600, limits): back_pass_gps + forward_pass +
+    forward_covariance + kl_div_wiki, each bracketed by HIP events (iLQGkl.jl:100,132,133, klutils.jl:114)"""
+    n, m, N = 4, 1, 600
+    prob = _lib.Problem()
+    prob.kind, prob.n, prob.m, prob.N, prob.B = 1, n, m, N, B
+    Q, R = f64(np.diag([10.0, 1, 2, 1])), f64(np.array([[1.0]]))
+    prob.Q, prob.R = Q.data_ptr(), R.data_ptr()
+    prob.g, prob.l, prob.h, prob.d = 9.82, 0.35, 0.01, 0.99
+    prob.cost_diag = 1
+    for i, v in enumerate([np.pi, 0, 0, 0]):
+        prob.goal[i] = v
+    rng = np.random.default_rng(0)
+    x0 = np.tile(np.array([np.pi - 0.6, 0, 0, 0])[:, None], (1, B)); x0[0] += rng.uniform(-0.1, 0.1, B)
+    u0 = 2.0 * np.sin(np.arange(N) / 37.0)[None, :, None] * np.ones((1, 1, B)) + 0.05 * rng.standard_normal((1, N, B))
+    dx0, du = f64(x0), f64(u0)
+    dl = f64(5.0 * np.array([[-1.0, 1.0]]))
+    one = np.array([1.0])
+    NB = N * B
+    dx, dun, dc, dcs = empty(n * NB), empty(m * NB), empty((N + 1) * B), empty(B)
+    _lib.check(L.ddp_forward_pass_f64_dev(h.raw, C.byref(prob), None, None, p(dx0), p(du), None, _lib.ptr(one), 1, p(dl), None, p(dx), p(dun), p(dc), p(dcs)))
+    dcx, dcu, dfx, dfu = empty(n * NB), empty(m * NB), empty(n * n * NB), empty(n * m * NB)
+    _lib.check(L.ddp_df_f64_dev(h.raw, C.byref(prob), p(dx), p(du), None, p(dcx), p(dcu), p(dfx), p(dfu)))
+    cxx = f64(np.repeat(np.diag([10.0, 1, 2, 1])[:, :, None], N, 2)); cxu = torch.zeros(n * m * N, dtype=torch.float64, device=dev)
+    cuu = torch.ones(m * m * N, dtype=torch.float64, device=dev)
+    Kp, kz, Sp = torch.zeros(m * n * NB, dtype=torch.float64, device=dev), torch.zeros(m * NB, dtype=torch.float64, device=dev), torch.ones(m * m * NB, dtype=torch.float64, device=dev)
+    kl = [empty(n * NB), empty(m * NB), empty(n * n * NB), empty(m * n * NB), empty(m * m * NB)]
+    _lib.check(L.ddp_kl_terms_f64_dev(h.raw, n, m, N, B, p(Kp), p(kz), p(Sp), *map(p, kl)))
+    eta = torch.ones(B, dtype=torch.float64, device=dev)
+    terms = _lib.KLCostTerms(*[t.data_ptr() for t in kl], eta.data_ptr(), 0)
+    desc = _lib.BPDesc(n, m, N, B, 1, 1, 1, 0, 1, 1)
+    dK, dk, dQuu, dQuui, dVx, dVxx, ddV = empty(m * n * NB), empty(m * NB), empty(m * m * NB), empty(m * m * NB), empty(n * NB), empty(n * n * NB), empty(2 * B)
+    ddiv = torch.zeros(B, dtype=torch.int32, device=dev)
+    dxn = empty(n * NB)
+    R1 = f64(1e-3 * np.eye(n))
+    sig, kld, klm = empty((n + m) ** 2 * NB), empty(NB), empty(B)
+
+    def step(ev=None):
+        if ev: L.ddp_event_record(h.raw, ev[0])
+        _lib.check(L.ddp_back_pass_gps_f64_dev(h.raw, C.byref(desc), p(dcx), p(dcu), p(cxx), p(cxu), p(cuu), p(dfx), p(dfu), C.byref(terms), p(dl), p(du),
+                                               None, p(dK), p(dk), p(dQuu), p(dQuui), p(dVx), p(dVxx), p(ddV), p(ddiv)))
+        if ev: L.ddp_event_record(h.raw, ev[1])
+        _lib.check(L.ddp_forward_pass_f64_dev(h.raw, C.byref(prob), p(dK), p(dk), p(dx0), p(du), p(dx), _lib.ptr(one), 1, p(dl), None, p(dxn), p(dun), p(dc), p(dcs)))
+        if ev: L.ddp_event_record(h.raw, ev[2])
+        _lib.check(L.ddp_forward_covariance_f64_dev(h.raw, n, m, N, B, p(dfx), 1, p(R1), p(dK), p(dQuui), p(sig)))
+        if ev: L.ddp_event_record(h.raw, ev[3])
+        _lib.check(L.ddp_kl_div_f64_dev(h.raw, n, m, N, B, p(dxn), p(dx), p(sig), p(dK), p(dk), p(dQuui), p(Kp), p(kz), p(Sp), p(Sp), p(kld), p(klm)))
+        if ev: L.ddp_event_record(h.raw, ev[4])
+
+    steps, warmup = int(os.environ.get("DDP_BC_STEPS", 10)), int(os.environ.get("DDP_BC_WARMUP", 2))
+    for _ in range(warmup):
+        step()
+    evs = []
+    for _ in range(steps):
+        ev = [C.c_void_p() for _ in range(5)]
+        for e in ev:
+            L.ddp_event_create(h.raw, C.byref(e))
+        evs.append(ev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for ev in evs:
+        step(ev)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = np.zeros((steps, 4))
+    for i, ev in enumerate(evs):
+        for j in range(4):
+            v = C.c_float()
+            L.ddp_event_elapsed_ms(h.raw, ev[j], ev[j + 1], C.byref(v)); ms[i, j] = v.value
+    mean = ms.mean(axis=0)
+    # algorithmic doubles per step and trajectory (the [.,.,N] cost Hessians are shared by the batch and stay in the caches)
+    bpb = ((n + m) + (n * n + n * m) + (n + m + n * n + m * n + m * m) + m + (m * n + m + 2 * m * m + n + n * n)) * 8 * (N - 1) * B
+    fpb = ((m * n + m + n + m) + (n + m + 1)) * 8 * N * B
+    fcb = (n * n + m * n + m * m + (n + m) ** 2) * 8 * N * B
+    klb = (2 * n + (n + m) ** 2 + 2 * (m * n + m) + 3 * m * m + 1) * 8 * N * B
+    print(json.dumps({"config": "C5 KL pass (pendcart lims + KL)", "n": n, "m": m, "N": N, "batch": B, "iterations_per_s": round(B * steps / el, 1),
+                      "ms_per_pass_batch": round(1e3 * el / steps, 3), "back_pass_ms": round(float(mean[0]), 3), "forward_ms": round(float(mean[1]), 3),
+                      "forward_covariance_ms": round(float(mean[2]), 3), "kl_div_ms": round(float(mean[3]), 3),
+                      "back_pass_ms_median": round(float(np.median(ms[:, 0])), 4), "back_pass_ms_min": round(float(ms[:, 0].min()), 4),
+                      "back_pass_alg_bytes_per_launch": int(bpb), "back_pass_alg_GBs": round(bpb / (mean[0] * 1e-3) / 1e9, 1),
+                      "back_pass_frac_of_8TBs": round(bpb / (mean[0] * 1e-3) / 8e12, 4), "forward_alg_GBs": round(fpb / (mean[1] * 1e-3) / 1e9, 1),
+                      "forward_covariance_alg_GBs": round(fcb / (mean[2] * 1e-3) / 1e9, 1), "kl_div_alg_GBs": round(klb / (mean[3] * 1e-3) / 1e9, 1),
+                      "diverged": int((ddiv != 0).sum().item())}))
 
 
 def c4(B=1024):
@@ -171,5 +291,9 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c4"]
     if "c3" in which:
         c3(int(os.environ.get("DDP_C3_B", 4096)))
+    if "c2tv" in which:
+        c2tv()
     if "c4" in which:
         c4()
+    if "c5" in which:
+        c5()
