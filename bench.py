@@ -282,6 +282,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     roofline = pb.roofline(bp_ms, fp_ms)
+    stats_vec = pb.stats.cpu().numpy() if use_dist else None
     # HBM traffic per launch: measured after the timed region by two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE: separate passes)
     # of a 3-step bench of the same workload (rank 0, single GPU); where that is not possible (rocprofv3 missing, multi-rank run,
     # --no-traffic) the committed figure for THIS kernel at THIS batch is replayed — never a number of another batch or kernel
@@ -343,6 +344,13 @@ def main():
                           "batch_per_gpu": B, "n": n, "m": m, "N": N, "sharding": "batch (independent trajectories), "
                           "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1 (issued by %s)" % ("the C ABI, ddp_allreduce_stats_f64_dev" if args.collective == "capi" else "torch.distributed")},
                "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill, "full_line_search": ls, "other_configs": other}
+        if use_dist:
+            # the vector the ranks share per step (Σ new cost, Σ dV[1], Σ dV[2], #diverged — summed over the ranks) after the last step
+            out["collective"] = {"issued_by": args.collective, "stats": [float(v) for v in stats_vec]}
+            if args.collective == "capi":
+                from ddp_amd import sharding
+                ver, pre = sharding.CApiComm.rccl_info()
+                out["collective"].update(rccl_version=ver, rccl_instance="the one already resident in the process" if pre else "loaded by libddp_amd")
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

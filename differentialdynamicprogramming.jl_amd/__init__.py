@@ -343,6 +343,8 @@ def df(problem, x, u, *, handle=None):
 # ---------------------------------------------------------------------------------------- iLQG
 def print_timing(trace):
     """The timing summary of iLQG.jl:343-366 from the trace keys ``time_derivs``, ``time_backward``, ``time_forward``."""
+    if "time_derivs" not in trace:
+        raise KeyError("print_timing needs the time_* keys: call iLQG(..., timing=True)")
     parts = [float(np.nansum(trace[k])) for k in ("time_derivs", "time_backward", "time_forward")]
     total = float(trace.get("time_total", sum(parts)))
     it = max(int(trace.get("global_iters", 1)), 1)
@@ -368,6 +370,10 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     ``x0[n,N]`` (``x0[n,N,B]`` with a batch) is a PRE-ROLLED initial trajectory (iLQG.jl:193-197: no initial rollout;
     ``cost`` as given or ``costfun(x0,u0)``) — the warm start of an MPC loop.
     ``timing=False`` drops the ``time_*`` trace keys: the driver then synchronises with the host every fourth batch iteration only.
+    ``trace_cap``: rows of the per-iteration history kept per trajectory; the default shrinks with the batch,
+    ``min(4 max_iter + 64, 4096, max(64, 256e6 / (56 B)))`` (136 rows at B = 32768), so that ``history[7, cap, B]`` stays under 256 MB.
+    ``trace["trace_cap"]`` is the cap used and ``trace["truncated"]`` says, per trajectory, whether it took more iterations than rows
+    were kept (its later rows are missing, ``stats`` / ``iter`` are complete).
     Returns ``None`` when the initial control sequence diverges (iLQG.jl:205-210) in the unbatched case."""
     h = handle or default_handle()
     u0, x0 = _lib.f64(u0), _lib.f64(x0)
@@ -427,15 +433,21 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     # the reference's trace keys (iLQG.jl:257,325-330), one row per iteration: trace["history"][key][iteration-1(, b)]
     hist = {key: tr7[c] for c, key in enumerate(("λ", "dλ", "α", "improvement", "cost", "reduce_ratio", "grad_norm"))}
     trace = dict(stats=stats, status=stats[0].astype(int), iter=stats[1].astype(int), λ=stats[5], grad_norm=stats[6],
-                 cost=tr, global_iters=git.value, history=hist)
+                 cost=tr, global_iters=git.value, history=hist, trace_cap=cap, truncated=(stats[1] - 1 > cap))
+    if trace["truncated"].any():
+        import warnings
+        warnings.warn("iLQG: %d of %d trajectories took more iterations than the %d history rows kept (trace_cap); their later rows are "
+                      "missing from trace['history'] / trace['cost']" % (int(trace["truncated"].sum()), B, cap))
     # time_derivs / time_backward / time_forward (iLQG.jl:227,241,281): GPU seconds per GLOBAL iteration of the batch
     for r, key in enumerate(("time_derivs", "time_backward", "time_forward")):
-        trace[key] = timing[r, : git.value].copy()
+        if timing_on:
+            trace[key] = timing[r, : git.value].copy()
     trace["time_total"] = total_t
     if verbosity > 0:
         for b in range(min(B, 8)):
             print("[%d] %s after %d iterations, cost %.6g" % (b, STATUS.get(int(stats[0, b]), "?"), int(stats[1, b]), stats[7, b]))
-        print_timing(trace)
+        if timing_on:
+            print_timing(trace)
     if not batched:
         if int(stats[0, 0]) == -1:
             return None

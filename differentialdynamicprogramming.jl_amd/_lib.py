@@ -29,7 +29,7 @@ EXPORTS = [
     "ddp_forward_covariance_f64_dev", "ddp_forward_covariance_f64", "ddp_kl_div_f64_dev", "ddp_kl_div_f64",
     "ddp_kl_dual_begin_f64_dev", "ddp_kl_dual_retry_f64_dev", "ddp_kl_dual_update_f64_dev",
     "ddp_ilqgkl_default_opts", "ddp_ilqgkl_f64_dev", "ddp_ilqgkl_f64",
-    "ddp_comm_unique_id", "ddp_comm_create", "ddp_comm_destroy", "ddp_allreduce_stats_f64_dev",
+    "ddp_comm_rccl_info", "ddp_comm_unique_id", "ddp_comm_create", "ddp_comm_destroy", "ddp_allreduce_stats_f64_dev",
 ]
 
 

@@ -4,7 +4,9 @@ One hipcc invocation per translation unit (run in parallel), then a link step.  
 cross-compiles for gfx950 without a GPU, so this also runs in the CPU-only build container.
 """
 import concurrent.futures as cf
+import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -37,14 +39,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+_digests = {}
+
+
+def _code_digest(path):
+    """digest of a header's CODE (comments and white space removed): an edit to a comment of include/ddp_amd.h does not recompile
+    eighteen translation units (four minutes)"""
+    if path not in _digests:
+        txt = open(path).read()
+        txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+        txt = re.sub(r"//[^\n]*", " ", txt)
+        _digests[path] = hashlib.sha1(" ".join(txt.split()).encode()).hexdigest()
+    return _digests[path]
+
+
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS + EXTRA_DEPS.get(src, [])]
-    if _stale(obj, deps):
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS + EXTRA_DEPS.get(src, [])]
+    stamp = obj + ".hdr"
+    want = "\n".join("%s %s" % (os.path.basename(h), _code_digest(h)) for h in hdrs) + "\n" + " ".join(FLAGS + EXTRA_FLAGS.get(src, []))
+    have = open(stamp).read() if os.path.exists(stamp) else None
+    if _stale(obj, [os.path.join(CSRC, src)]) or have != want:
         cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        open(stamp, "w").write(want)
         return src, True
     return src, False
 

@@ -17,5 +17,17 @@ int ddp_launch_back_pass_mfma(ddp_handle h, const ddp_bp_desc *d, const double *
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.lims = lims;
     a.u = u; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
-    return d->has_lims ? ddp_bpm_launch_lims(h, a) : ddp_bpm_launch<false>(h, a);
+    if (d->has_lims) {
+        // lims[1,1] > lims[1,2] means "no limits" upstream (backward_pass.jl:31: the Cholesky branch, not a box-QP with infinite bounds,
+        // whose projected-Newton iterations and extra exits would differ by rounding).  Two doubles come down once per call — a pass of
+        // this shape takes milliseconds.
+        DDP_CHECK(lims && u && h->h_pinned, "back_pass: has_lims needs lims and u");
+        double *lh = (double *)h->h_pinned;
+        DDP_HIP(hipMemcpyAsync(lh, lims, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        DDP_HIP(hipMemcpyAsync(lh + 1, lims + m, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        DDP_HIP(hipStreamSynchronize(h->stream));
+        if (!(lh[0] > lh[1])) return ddp_bpm_launch_lims(h, a);
+        a.has_lims = 0; a.lims = nullptr;
+    }
+    return ddp_bpm_launch<false>(h, a);
 }

@@ -21,17 +21,35 @@ struct Rccl {
     int (*CommDestroy)(rccl_comm) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, rccl_comm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    int version = 0;
+    bool preloaded = false;      // the process already held a librccl (e.g. torch's own copy): that instance is used, no second one is loaded
 };
+constexpr int RCCL_MIN_VERSION = 21800;   // NCCL_VERSION(2,18,0): the ABI declared above (ncclUniqueId by value, ncclFloat64 = 8) is that of NCCL 2.x
 
-Rccl *rccl()
+Rccl &rccl_state()
 {
     static Rccl r;
     static bool tried = false;
     if (!tried) {
         tried = true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // a host that has RCCL loaded already (PyTorch ships torch/lib/librccl.so) must not end up with two instances in one process:
+        // first ask the loader for a copy it holds (RTLD_NOLOAD), by the names above and through an already-resolved symbol
+        for (const char *name : names) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (r.lib) break;
+        }
+        if (!r.lib) {
+            if (void *sym = dlsym(RTLD_DEFAULT, "ncclGetUniqueId")) {
+                Dl_info info;
+                if (dladdr(sym, &info) && info.dli_fname) r.lib = dlopen(info.dli_fname, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            }
+        }
+        r.preloaded = r.lib != nullptr;
+        for (const char *name : names) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (r.lib) {
             r.GetUniqueId = (int (*)(rccl_unique_id *))dlsym(r.lib, "ncclGetUniqueId");
@@ -39,9 +57,18 @@ Rccl *rccl()
             r.CommDestroy = (int (*)(rccl_comm))dlsym(r.lib, "ncclCommDestroy");
             r.AllGather = (int (*)(const void *, void *, size_t, int, rccl_comm, hipStream_t))dlsym(r.lib, "ncclAllGather");
             r.GetErrorString = (const char *(*)(int))dlsym(r.lib, "ncclGetErrorString");
+            r.GetVersion = (int (*)(int *))dlsym(r.lib, "ncclGetVersion");
+            if (r.GetVersion && r.GetVersion(&r.version) != 0) r.version = 0;
         }
     }
-    return (r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather) ? &r : nullptr;
+    return r;
+}
+
+Rccl *rccl()
+{
+    Rccl &r = rccl_state();
+    // older than the declared ABI (or no ncclGetVersion at all): refuse rather than call through mismatched prototypes
+    return (r.lib && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.version >= RCCL_MIN_VERSION) ? &r : nullptr;
 }
 
 #define DDP_RCCL(call)                                                                                             \
@@ -76,10 +103,25 @@ struct ddp_comm_s {
 
 extern "C" {
 
+// RCCL as this library sees it: version code (NCCL_VERSION_CODE of the loaded librccl, 0 = not loadable / too old) and whether the
+// instance was already resident in the process (1) or loaded here (0)
+int ddp_comm_rccl_info(int *version, int *preloaded)
+{
+    Rccl &R = rccl_state();
+    if (version) *version = R.version;
+    if (preloaded) *preloaded = R.preloaded ? 1 : 0;
+    if (!rccl()) {
+        ddp_set_error(R.lib ? "RCCL %d is older than the ABI this library declares (>= %d)" : "RCCL (librccl.so) could not be loaded", R.version,
+                      RCCL_MIN_VERSION);
+        return -3;
+    }
+    return 0;
+}
+
 int ddp_comm_unique_id(char id[DDP_COMM_ID_BYTES])
 {
     Rccl *R = rccl();
-    DDP_CHECK(R, "ddp_comm_unique_id: RCCL (librccl.so) could not be loaded");
+    DDP_CHECK(R, "ddp_comm_unique_id: RCCL (librccl.so) could not be loaded, or is older than 2.18");
     DDP_CHECK(id, "ddp_comm_unique_id: id is NULL");
     rccl_unique_id u;
     DDP_RCCL(R->GetUniqueId(&u));
@@ -91,7 +133,7 @@ int ddp_comm_create(ddp_handle h, int nranks, int rank, const char id[DDP_COMM_I
 {
     DDP_DEVICE(h);
     Rccl *R = rccl();
-    DDP_CHECK(R, "ddp_comm_create: RCCL (librccl.so) could not be loaded");
+    DDP_CHECK(R, "ddp_comm_create: RCCL (librccl.so) could not be loaded, or is older than 2.18");
     DDP_CHECK(out && id && nranks >= 1 && rank >= 0 && rank < nranks, "ddp_comm_create: bad argument (nranks=%d rank=%d)", nranks, rank);
     rccl_unique_id u;
     memcpy(u.internal, id, DDP_COMM_ID_BYTES);

@@ -241,6 +241,9 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     DDP_CHECK((K == nullptr) == (k == nullptr), "forward_pass: K and k must both be given or both NULL");
     DDP_CHECK(!K || x, "forward_pass: a non-empty policy needs the nominal trajectory x");
     DDP_CHECK(p->m <= DDP_MAX_M && p->n <= 64, "forward_pass: n=%d m=%d unsupported (n<=64, m<=%d)", p->n, p->m, DDP_MAX_M);
+    // the trailing field of ddp_problem (library 0.2.0): a caller built against the older layout, or one that does not zero the struct,
+    // hands over garbage here — anything but 0 / 1 is refused instead of silently selecting the diagonal-cost rollout
+    DDP_CHECK(p->cost_diag == 0 || p->cost_diag == 1, "forward_pass: ddp_problem.cost_diag = %d (0 or 1; zero-initialise the struct)", p->cost_diag);
     if (p->n > DDP_MAX_N_GENERIC || (getenv("DDP_FORWARD") && getenv("DDP_FORWARD")[0] == 'b')) {   // large states
         const int rc = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rc <= 0) return rc;

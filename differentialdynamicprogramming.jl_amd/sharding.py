@@ -57,6 +57,34 @@ def allreduce_stats(v, device=None):
     return torch.cat([g[:, :N_SUM].sum(dim=0), g[:, N_SUM:].max(dim=0).values]).cpu().numpy()
 
 
+def file_exchange(path, rank, timeout=120.0):
+    """an `exchange` for CApiComm on hosts without torch.distributed (or MPI): rank 0 writes the 128-byte RCCL id to `path`
+    (atomically, via rename), the other ranks wait for the file.  `path` must be visible to every rank and fresh per job."""
+    import os
+    import time
+
+    def exchange(b):
+        if rank == 0:
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "wb") as f:
+                f.write(b)
+            os.replace(tmp, path)
+            return b
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    raw = f.read()
+                if len(raw) == 128:
+                    return raw
+            except FileNotFoundError:
+                pass
+            if time.time() - t0 > timeout:
+                raise TimeoutError("no RCCL id at %s after %.0f s" % (path, timeout))
+            time.sleep(0.01)
+    return exchange
+
+
 class CApiComm:
     """The RCCL communicator owned by the C ABI (ddp_comm_create / ddp_allreduce_stats_f64_dev, include/ddp_amd.h) — what a Julia
     or C host without torch uses for the one collective of the path.  `exchange(id_bytes_or_None) -> id_bytes` ships the
@@ -88,6 +116,26 @@ class CApiComm:
         self._lib.check(self._lib.lib().ddp_allreduce_stats_f64_dev(self.handle.raw, self._c, C.c_void_p(getattr(dptr, "value", dptr)),
                                                                     int(nsum), int(nmax)))
 
+    def allreduce_host(self, v, nsum):
+        """a host vector through the device collective: SUM of the first nsum entries, MAX of the rest; returns a new array"""
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        d = self.handle.to_device(v)
+        try:
+            self.allreduce(d, nsum, v.size - nsum)
+            self.handle.sync()
+            return self.handle.to_host(d, v.shape)
+        finally:
+            self.handle.free(d)
+
+    @staticmethod
+    def rccl_info():
+        """(NCCL version code of the librccl the library uses, whether that instance was already resident in the process)"""
+        import ctypes as C
+        from . import _lib
+        ver, pre = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().ddp_comm_rccl_info(C.byref(ver), C.byref(pre)))
+        return ver.value, bool(pre.value)
+
     def close(self):
         if self._c:
             self._lib.lib().ddp_comm_destroy(self._c)
@@ -100,17 +148,43 @@ class CApiComm:
             pass
 
 
-def solve_sharded(problem, x0, u0, *, solver=None, device=None, **kw):
+def _torch_dist():
+    """torch.distributed when it is importable AND initialised, else None"""
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def solve_sharded(problem, x0, u0, *, solver=None, device=None, comm=None, handle=None, **kw):
     """Every rank solves its contiguous shard of the batch (x0[n,B], u0[m,N,B]) and the ranks all-reduce the
     statistics vector.  `solver(problem, x0_shard, u0_shard, **kw)` must return the tuple of ``iLQG``; it defaults
-    to the GPU solver of this package.  Returns ``(local_result, global_stats_dict, (lo, hi))``."""
-    import torch.distributed as dist
-    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    to the GPU solver of this package.  Returns ``(local_result, global_stats_dict, (lo, hi))``.
+
+    The collective: torch.distributed when a process group is initialised (backend nccl = RCCL, gloo in the CPU tests); otherwise —
+    torch absent or not initialised, as under a Julia / C launcher — rank and world size come from RANK / WORLD_SIZE and the vector
+    goes through the C ABI's own RCCL communicator (`comm`: a CApiComm, or one is created with the id exchanged through the file
+    named by DDP_COMM_ID_FILE)."""
+    import os
+    dist = _torch_dist()
+    if dist is not None:
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     B = u0.shape[2]
     lo, hi = shard_range(B, rank, world)
     if solver is None:
         from . import iLQG as solver        # GPU path (raises without a GPU: no CPU fallback)
     res = solver(problem, np.ascontiguousarray(x0[:, lo:hi]), np.ascontiguousarray(u0[:, :, lo:hi]), **kw)
     x, u, pol, Vx, Vxx, cost, trace = res
-    g = allreduce_stats(stats_from_solve(trace["stats"], cost), device=device)
+    v = stats_from_solve(trace["stats"], cost)
+    if comm is None and dist is None and world > 1:
+        path = os.environ.get("DDP_COMM_ID_FILE")
+        if not path:
+            raise RuntimeError("solve_sharded without torch.distributed: pass comm=CApiComm(...) or name a shared file in DDP_COMM_ID_FILE")
+        from . import default_handle
+        handle = handle or default_handle(int(os.environ.get("LOCAL_RANK", rank)))
+        comm = CApiComm(handle, rank, world, exchange=file_exchange(path, rank))
+    g = comm.allreduce_host(v, N_SUM) if comm is not None else allreduce_stats(v, device=device)
     return res, dict(zip(STAT_NAMES, g)), (lo, hi)

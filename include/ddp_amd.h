@@ -136,7 +136,9 @@ typedef struct {
     double goal[4];
     /* 1: the caller declares Q and R DIAGONAL (true for the reference's demos: Q = h·I, R = 0.1h·I, Q = diag(10,1,2,1)); the rollout
      * kernels of the n = 10 / m = 2 and pendcart shapes then evaluate the cost themselves from the values they hold instead of a
-     * second kernel re-reading xnew, unew (only the diagonals are read).  0: general Q, R.                                       */
+     * second kernel re-reading xnew, unew (only the diagonals are read).  0: general Q, R.  The declaration is NOT verified (Q, R are
+     * device memory in the _dev entry points): a wrong 1 gives the cost of diag(Q), diag(R).  Any other value is refused, so a struct that
+     * was not zero-initialised — or a caller built against the 0.1.0 layout, which ended at goal[] — fails loudly.               */
     int cost_diag;
 } ddp_problem;
 
@@ -252,6 +254,10 @@ int ddp_batch_stats_f64_dev(ddp_handle h, int B, const double *csum, const doubl
 #define DDP_COMM_ID_BYTES 128
 #define DDP_COMM_MAX_STATS 64
 typedef struct ddp_comm_s *ddp_comm;
+/* RCCL as the library sees it: *version = NCCL_VERSION_CODE of the librccl in use (the hand-declared ABI needs >= 2.18: return < 0 below
+ * that or when no librccl can be loaded), *preloaded = 1 when the process already held a librccl (e.g. PyTorch's torch/lib/librccl.so) and
+ * that instance is used — a second copy is never loaded beside it.                                                            */
+int ddp_comm_rccl_info(int *version, int *preloaded);
 int ddp_comm_unique_id(char id[DDP_COMM_ID_BYTES]);
 int ddp_comm_create(ddp_handle h, int nranks, int rank, const char id[DDP_COMM_ID_BYTES], ddp_comm *out);
 int ddp_comm_destroy(ddp_comm c);

@@ -31,3 +31,36 @@ def test_bench_line_has_the_contract_fields():
     assert abs(rf["achieved"] - rf["bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1.0       # algorithmic bytes / HIP-event time
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    # roofline.traffic is measured by this run (two rocprofv3 --pmc child runs), not replayed: within 5 % of the algorithmic bytes or above
+    assert rf["traffic"] is not None and "measured in this run" in rf["traffic_source"], rf["traffic_source"]
+    assert 0.95 * rf["bytes_per_launch"] < rf["traffic"] < 1.5 * rf["bytes_per_launch"]
+
+
+def _torchrun_bench(collective, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--preheat", "0", "--no-cpu-baseline", "--no-other-configs",
+           "--fill-batch", "0", "--no-traffic", "--collective", collective]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, DDP_BENCH_REHEARSALS="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_one_rank_collective_torch_and_capi_agree():
+    """The N > 1 code path as far as ONE GPU can run it (RCCL refuses two ranks on one device): under torch.distributed.run with one rank
+    the per-step statistics vector goes through an RCCL communicator — torch's, or the C ABI's own (ddp_comm_*).  Both must deliver the
+    same vector; the C ABI must use the librccl instance torch already loaded (never a second copy) and see a version >= its declared ABI."""
+    import socket
+    ports = []
+    for _ in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            ports.append(s.getsockname()[1])
+    a, b = _torchrun_bench("torch", ports[0]), _torchrun_bench("capi", ports[1])
+    sa, sb = a["collective"]["stats"], b["collective"]["stats"]
+    assert a["collective"]["issued_by"] == "torch" and b["collective"]["issued_by"] == "capi"
+    assert len(sa) == 4 and sa[3] == 0.0 and sa[0] > 0.0
+    assert all(abs(x - y) <= 1e-12 * max(1.0, abs(x)) for x, y in zip(sa, sb)), (sa, sb)
+    assert b["collective"]["rccl_version"] >= 21800 and b["collective"]["rccl_instance"].startswith("the one already resident")

@@ -457,3 +457,25 @@ def test_results_are_reproducible_bit_for_bit(ddp):
     for k_ in (0, 1, 3, 4, 5):
         assert np.array_equal(r0[k_], r1[k_], equal_nan=True), k_
     assert np.array_equal(r0[2].K, r1[2].K) and np.array_equal(r0[6]["stats"], r1[6]["stats"])
+
+
+def test_trace_cap_is_reported_and_truncation_flagged(ddp):
+    """the history keeps `trace_cap` rows per trajectory (the default shrinks with the batch); a trajectory that iterates
+    longer is flagged in trace['truncated'] (with a warning), and timing=False really drops the time_* keys"""
+    import warnings
+    from oracle import np_restatement as npr
+    rng = np.random.default_rng(4)
+    P = npr.make_lq_problem(rng, T=60)
+    prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+    B = 3
+    x0 = np.ones((10, B)) + 0.1 * rng.standard_normal((10, B))
+    u0 = 0.1 * rng.standard_normal((2, 60, B))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        r = ddp.iLQG(prob, x0, u0, trace_cap=2, timing=False)
+    tr = r[6]
+    assert tr["trace_cap"] == 2 and tr["history"]["cost"].shape[0] == 2
+    assert np.array_equal(tr["truncated"], tr["iter"] - 1 > 2) and tr["truncated"].any() and any("trace_cap" in str(x.message) for x in w)
+    assert not any(k.startswith("time_d") or k.startswith("time_b") or k.startswith("time_f") for k in tr)
+    full = ddp.iLQG(prob, x0, u0)[6]
+    assert not full["truncated"].any() and "time_derivs" in full and full["trace_cap"] >= int(full["iter"].max())

@@ -122,3 +122,18 @@ def test_ilqg_large_state_batched(ddp):
         assert (int(st[0]), int(st[1])) == (info["status"], info["iter"])
         assert relerr(x[..., b], xr) < RTOL and relerr(uu[..., b], ur) < RTOL and relerr(Vxx[..., b], vxxr) < RTOL
         assert abs(cost[:, b].sum() - cr.sum()) < 1e-9 * abs(cr.sum())
+
+
+def test_inverted_bounds_take_the_cholesky_branch(ddp):
+    """lims[1,1] > lims[1,2] means "no limits" upstream (backward_pass.jl:31): the n = 64 / m = 8 launcher then runs the instantiation
+    without the box-QP — the same bits as `lims = []`, not a QP with infinite bounds"""
+    rng = np.random.default_rng(17)
+    n, m, N, B = 64, 8, 10, 3
+    cx, cu, cxx, cxu, cuu, fx, fu, u = _problem(rng, n, m, N, B, False)
+    L = np.stack([0.4 * np.ones(m), -0.25 * np.ones(m)], 1)               # lower > upper
+    lam = np.array([1e-3, 0.1, 2.0])
+    a = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 1, L, None, u)
+    b = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 1, None, None, u)
+    assert np.array_equal(a[0], b[0])
+    for got, ref in ((a[1].K, b[1].K), (a[1].k, b[1].k), (a[1].Σi, b[1].Σi), (a[2], b[2]), (a[3], b[3]), (a[4], b[4])):
+        assert np.array_equal(got, ref)

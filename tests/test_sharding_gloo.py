@@ -81,3 +81,42 @@ def test_two_rank_gloo_allreduce_matches_unsharded():
         got = np.array([g[k] for k in sharding.STAT_NAMES])
         assert np.allclose(got, ref, rtol=1e-12, atol=0)
     assert out[0][3]["n_traj"] == 5 and out[0][3]["n_converged"] == 5
+
+
+
+def test_file_exchange_ships_the_id(tmp_path):
+    """the rendezvous of CApiComm without torch.distributed: rank 0 writes the 128-byte id, the others wait for it"""
+    import threading
+    path = str(tmp_path / "rccl_id")
+    blob = bytes(range(128))
+    got = {}
+
+    def other():
+        got[1] = sharding.file_exchange(path, 1, timeout=30.0)(None)
+    t = threading.Thread(target=other)
+    t.start()
+    assert sharding.file_exchange(path, 0)(blob) == blob
+    t.join(timeout=30)
+    assert got[1] == blob
+    with pytest.raises(TimeoutError):
+        sharding.file_exchange(str(tmp_path / "missing"), 1, timeout=0.05)(None)
+
+
+def test_solve_sharded_without_torch_distributed_uses_the_capi_comm(monkeypatch):
+    """torch.distributed not initialised (a Julia / C launcher): rank and world size from the environment, the statistics vector through
+    the communicator object (CApiComm on a GPU box; a stand-in with its interface here) — one call with the SUM / MAX split"""
+    P, x0, u0 = _make_batch()
+    calls = []
+
+    class FakeComm:
+        def allreduce_host(self, v, nsum):
+            calls.append((np.array(v), nsum))
+            return np.concatenate([2.0 * v[:nsum], v[nsum:]])        # "two ranks with the same shard"
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    res, g, (lo, hi) = sharding.solve_sharded(P, x0, u0, solver=_oracle_solver, comm=FakeComm())
+    assert (lo, hi) == (3, 5) and len(calls) == 1 and calls[0][1] == sharding.N_SUM
+    assert g["n_traj"] == 4.0 and g["max_iters"] == calls[0][0][10]
+    monkeypatch.delenv("DDP_COMM_ID_FILE", raising=False)
+    with pytest.raises(RuntimeError, match="DDP_COMM_ID_FILE"):
+        sharding.solve_sharded(P, x0, u0, solver=_oracle_solver)
