@@ -29,7 +29,8 @@ EXTRA_FLAGS = {"back_pass_mx.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 
 
 EXTRA_DEPS = {"back_pass_mfma.hip": ["back_pass_mfma_kernel.h"], "back_pass_mfma_lims.hip": ["back_pass_mfma_kernel.h"],
-              "back_pass_mx.hip": ["back_pass_mx_common.h"], "back_pass_mx2.hip": ["back_pass_mx_common.h"]}
+              "back_pass_mx.hip": ["back_pass_mx_common.h"], "back_pass_mx2.hip": ["back_pass_mx_common.h"],
+              "forward_pass_dpp.hip": ["pend_math.h"]}
 
 
 def _stale(target, deps):

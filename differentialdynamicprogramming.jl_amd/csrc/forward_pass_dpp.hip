@@ -32,6 +32,8 @@ struct FDArgs {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+#include "pend_math.h"
+
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 // acc += src0[lane L of this 16-lane row] * src1
@@ -360,7 +362,9 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
     const double *kg = POLICY ? a.k + (size_t)N * b : nullptr;
     double *xo = a.xnew + (size_t)n * N * rho, *uo = a.unew + (size_t)N * rho;
     const double lo = LIMS ? a.lims[0] : 0.0, hi = LIMS ? a.lims[1] : 0.0;
-    const double gl = a.g / a.l, h = a.h;
+    const double gl = a.g / a.l, il = 1.0 / a.l, h = a.h;
+    PendTrig trig;
+    trig.init();
     struct Ops { double u, k; d2 K0, K1, x0, x1; };
     auto fetch = [&](int i, Ops &o) {
         o.u = ug[i];
@@ -405,8 +409,10 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
         }
         if (advance) {                                                   // system_pendcart.jl:83-89
             double sn, cs;
-            sincos(x0v, &sn, &cs);
-            const double f1 = x1v + h * (-gl * sn + uu / a.l * cs - a.d * x1v);
+            pend_sincos(trig, x0v, sn, cs);
+            double ul = uu * il;
+            ul = __builtin_fma(__builtin_fma(-ul, a.l, uu), il, ul);     // u / l: one Newton correction of u · (1/l)
+            const double f1 = x1v + h * (-gl * sn + ul * cs - a.d * x1v);
             const double n0 = x0v + h * x1v, n2 = x2v + h * x3v, n3 = x3v + h * uu;
             x0v = n0; x1v = f1; x2v = n2; x3v = n3;
         }
@@ -435,6 +441,174 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
     if (FUSE && act) {
         co[N] = 0.5 * qxl;
         a.csum[rho] = cacc + 0.5 * qxl;
+    }
+}
+
+
+// ---- pendcart, one 16-lane row per rollout, written for the step count of a LONE wave (B = 4 096 single-α rollouts are one wave per
+// SIMD: the pass takes as long as one wave needs for its N steps, ~6.5 cycles per vector instruction and ~60 per vector-memory
+// instruction).  Against the generic row kernel above (132 vector + 5 vector-memory instructions per step):
+//   * ONE load per step: lanes 0-3 fetch K_i[j], lanes 4-7 x_i[j-4], lane 8 ū_i, lane 9 k_i — every lane walks its own array with its
+//     own stride; x_i moves to the state lanes by a row shift, ū_i and k_i enter the multiply-adds as row broadcasts;
+//   * sin, cos by pend_sincos (pend_math.h, ~42 instructions instead of ~70), u / l as u · (1/l) with one Newton correction (3
+//     instructions; a division is ~10);
+//   * the four components of x̂⁺ = x̂ + h·(x̂_1, a, x̂_3, u) as ONE multiply-add on a lane-selected increment instead of a branch tree;
+//   * the clamp by v_max / v_min when the bounds are ordered (the loop exists twice; the other copy keeps the reference's compares),
+//     the NaN test on the unclamped control.
+// Lanes 0-3 hold x̂, lane 4 the control of the step (store, cost).  Same statements as forward_pass.jl:17-24 and
+// system_pendcart.jl:83-89; cost tile as in the kernel above.
+template <bool V> struct BoolC { static constexpr bool value = V; };
+// every lane of a 16-lane row <- lane L of the row (no `old` operand: all lanes are written, so no zero has to be moved in first)
+template <int L>
+__device__ __forceinline__ double row_bcast_all(double x)
+{
+    double d;
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(x), "n"(L));
+    return d;
+}
+template <bool POLICY, bool LIMS, bool FUSE>
+__global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
+{
+    constexpr int n = 4, G = 16, GPW = DDP_WAVE / G, TS = 17, D = 8;
+    __shared__ double ctile[FUSE ? GPW * 16 * TS : 1];
+    const int N = a.N, B = a.B;
+    const int lane = threadIdx.x, grp = lane / G, j = lane % G;
+    const long total = (long)B * a.nalpha;
+    long lin = (long)blockIdx.x * GPW + grp;
+    const bool valid = lin < total;
+    if (!valid) lin = total - 1;
+    const int b = (int)(lin / a.nalpha), ai = (int)(lin % a.nalpha);
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;
+    const double alpha = a.alpha[ai];
+    const bool inx = j < n;
+    const int jx = inx ? j : 0;
+    // this lane's operand stream: (pointer to its entry of step 0, bytes per step)
+    const double *ug = a.u + (size_t)N * b;
+    const char *ldb = (const char *)ug;
+    unsigned lds = 0;                                            // lanes without an operand re-read ū_0
+    if (POLICY) {
+        if (j < 4) { ldb = (const char *)(a.K + (size_t)n * N * b + j); lds = n * 8; }
+        else if (j < 8) { ldb = (const char *)(a.x + (size_t)n * N * b + (j - 4)); lds = n * 8; }
+        else if (j == 9) { ldb = (const char *)(a.k + (size_t)N * b); lds = 8; }
+    }
+    if (j == 8) lds = 8;
+    auto fetch = [&](int i) -> double { return *(const double *)(ldb + (size_t)lds * (unsigned)i); };
+    // this lane's result stream: x̂_i[j] (lanes 0-3), u_i (lane 4); the others write to the sink
+    const size_t rho = (size_t)b + (size_t)B * ai;
+    const bool st_on = act && j <= n;
+    char *stb = !st_on ? (char *)(a.sink + lane) : (j < n ? (char *)(a.xnew + (size_t)n * N * rho + j) : (char *)(a.unew + (size_t)N * rho));
+    const unsigned sts = !st_on ? 0u : (j < n ? n * 8u : 8u);
+    const double lo = LIMS ? a.lims[0] : 0.0, hi = LIMS ? a.lims[1] : 0.0;
+    const double gl = a.g / a.l, il = 1.0 / a.l, h = a.h, dd = a.d;
+    double one = 1.0;
+    asm volatile("" : "+v"(one));
+    double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0;
+    // fused cost
+    double cw = 0.0, cg = 0.0, cacc = 0.0, xlast = 0.0;
+    double *co = nullptr;
+    if (FUSE) {
+        if (inx) { cw = 0.5 * a.Q[jx + n * jx]; cg = a.goal[jx]; }
+        else if (j == n) cw = 0.5 * a.R[0];
+        co = a.cnew + (size_t)(N + 1) * rho;
+    }
+    double *ct = &ctile[FUSE ? grp * 16 * TS : 0];
+    double *ctw = ct + j;
+    auto flush_cost = [&](int i0c, int cnt) {
+        wave_sync();
+        double c = 0.0;
+#pragma unroll
+        for (int l = 0; l < n + 1; ++l) c += ct[j * TS + l];
+        if (j < cnt) {
+            if (act) co[i0c + j] = c;
+            cacc += c;
+        }
+        wave_sync();
+    };
+    const bool is1 = j == 1, is3 = j == 3, isu = j == n;
+    PendTrig trig;
+    trig.init();
+    dpp_fence(xh);
+    auto run = [&](auto minmax_c) __attribute__((always_inline)) {
+    constexpr bool MINMAX = decltype(minmax_c)::value;
+    auto step = [&](int i, double ld, bool advance) {
+        // ---- control (forward_pass.jl:17-24): u = ū + α k + K (x̂ - x), clamp, NaN -> 0 (inside f, system_pendcart.jl:120)
+        double uu = row_bcast_all<8>(ld);                                // ū_i  (ld comes from memory: no VALU -> DPP hazard)
+        if (POLICY) {
+            const double xi = __builtin_amdgcn_update_dpp(0.0, ld, 0x104, 0xf, 0xf, true);      // row_shl:4: x_i[j] from lane j + 4
+            double pr = ld * (xh - xi);                                  // K_i[j] (x̂_j - x_j) in lanes 0-3
+            fmac_bc<9>(uu, ld, alpha);                                   // unew .+= k*α
+            dpp_fence(pr);
+            double s1 = 0.0;
+            RowSum<n>::run(uu, s1, pr, one);                             // unew .+= K*dx, two interleaved partial sums
+            uu += s1;
+        }
+        const bool nan = uu != uu;
+        if (LIMS) uu = MINMAX ? fmin(fmax(uu, lo), hi) : clampd(uu, lo, hi);
+        uu = nan ? 0.0 : uu;
+        const double v = isu ? uu : xh;
+        *(double *)(stb + (size_t)sts * (unsigned)i) = v;
+        if (FUSE) {
+            const double dv = v - cg;
+            const double pc = (cw * dv) * dv;
+            ctw[(i & 7) * TS] = pc;
+            if (i == N - 1) xlast = inx ? pc : 0.0;                      // c[N+1] re-counts x[:,N] without a control (system_pendcart.jl:105)
+        }
+        if (advance) {                                                   // system_pendcart.jl:83-89
+            const double x0v = row_bcast_all<0>(xh), x1v = row_bcast_all<1>(xh);
+            double sn, cs;
+            pend_sincos(trig, x0v, sn, cs);
+            double ul = uu * il;                                         // u / l, correctly rounded but for rare cases, in three instructions
+            ul = __builtin_fma(__builtin_fma(-ul, a.l, uu), il, ul);     // (a division is ~10): one Newton correction of u · (1/l)
+            double acc = -gl * sn + ul * cs - dd * x1v;
+            asm("" : "+v"(acc));                                         // in every lane: selects below, not an exec-mask branch around three instructions
+            const double nxt = __builtin_amdgcn_update_dpp(0.0, xh, 0xf9, 0xf, 0xf, true);      // quad_perm [1,2,3,3]: x̂_{j+1} in lanes 0 and 2
+            const double inc = is1 ? acc : (is3 ? uu : nxt);             // lanes >= 4: their right-hand neighbour's 0
+            xh = xh + h * inc;
+            dpp_fence(xh);
+        }
+    };
+    double ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring[d] = fetch(d < N ? d : N - 1);
+    int i0 = 0;
+    for (; i0 + 2 * D <= N; i0 += D) {
+        if (FUSE) ctw = ct + j + (i0 & 8) * TS;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            step(i0 + d, ring[d], true);
+            ring[d] = fetch(i0 + d + D);
+        }
+        if (FUSE && (i0 & 8)) flush_cost(i0 - 8, 16);
+    }
+    for (; i0 < N; i0 += D) {
+        if (FUSE) ctw = ct + j + (i0 & 8) * TS;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = i0 + d;
+            if (i < N) {
+                step(i, ring[d], i < N - 1);
+                ring[d] = fetch(i + D < N ? i + D : N - 1);
+            }
+        }
+        if (FUSE && ((i0 & 8) || i0 + D >= N)) {
+            const int c0 = i0 & ~15;
+            flush_cost(c0, (N - c0) < 16 ? N - c0 : 16);
+        }
+    }
+    };
+    if (!LIMS || lo <= hi) run(BoolC<true>{}); else run(BoolC<false>{});
+    if (FUSE) {
+        double s0 = 0.0, s1 = 0.0;
+        dpp_fence(xlast);
+        RowSum<n>::run(s0, s1, xlast, one);
+        const double cN = s0 + s1;
+        if (act && j == 0) co[N] = cN;
+        cacc += (j == 0) ? cN : 0.0;
+        s0 = 0.0; s1 = 0.0;
+        dpp_fence(cacc);
+        RowSum<16>::run(s0, s1, cacc, one);
+        if (act && j == 0) a.csum[rho] = s0 + s1;
     }
 }
 
@@ -527,6 +701,22 @@ int launch_dpp(ddp_handle h, const FDArgs &a)
     return 0;
 }
 
+template <bool FUSE>
+int launch_pend_row(ddp_handle h, const FDArgs &a)
+{
+    const long total = (long)a.B * a.nalpha;
+    const dim3 grid((unsigned)((total + 3) / 4)), block(DDP_WAVE);
+    const int key = (a.has_policy ? 2 : 0) | (a.has_lims ? 1 : 0);
+    switch (key) {
+    case 0: hipLaunchKernelGGL((forward_pend_row_kernel<false, false, FUSE>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((forward_pend_row_kernel<false, true, FUSE>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((forward_pend_row_kernel<true, false, FUSE>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((forward_pend_row_kernel<true, true, FUSE>), grid, block, 0, h->stream, a); break;
+    }
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
 }   // namespace
 
 // returns 1 when the shape has no DPP kernel (caller falls back to the group kernel), 0 launched, <0 error
@@ -568,6 +758,9 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
 #undef DDP_LANE
         DDP_HIP(hipGetLastError());
         rc = 0;
+    } else if (!lq && a.sink && !(getenv("DDP_FORWARD_PEND") && getenv("DDP_FORWARD_PEND")[0] == '0')) {
+        // the pendulum's own row kernel (DDP_FORWARD_PEND=0: the generic row kernel, for A/B timing and the tests of both)
+        rc = fuse ? launch_pend_row<true>(h, a) : launch_pend_row<false>(h, a);
     } else {
         if (fuse) rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2, true>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1, true>(h, a);
         else rc = lq ? launch_dpp<DDP_PROBLEM_LQ, 10, 2, false>(h, a) : launch_dpp<DDP_PROBLEM_PENDCART, 4, 1, false>(h, a);
