@@ -51,6 +51,7 @@ struct Q4Args {
     const int32_t *active;
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
     int32_t *diverge;
+    const double *eta;          // back_pass_gps only: η per trajectory
     double *sink;               // >= 64 x 16 B that lanes without an output may write (paired kernel: stores carry no exec-mask branch)
 };
 
@@ -115,13 +116,15 @@ __device__ __forceinline__ void boxqp1_two_iterations(double H, double g, double
 struct Q4In { double fx, fu, cx, cu, u, cxx, cxxT, cxuc, cxur, cuu; };    // operands of one step (layout L / column / row forms)
 struct Q4State { double V, VT, vxc, kprev, dV0, dV1; int diverge; };        // Vxx_{i+1} (and transposed), Vx_{i+1} column form
 struct Q4Out { double Vn, Kc, vx, kk, Quu; };
-struct Q4Par { double lam, limlo, limhi; bool nolims; };
+struct Q4Par { double lam, limlo, limhi; bool nolims; double ieta; };
 
 struct Q4NoMid { __device__ __forceinline__ void operator()() const {} };
 
 // `mid` runs once the matrix instructions of the step have been issued (the LDS-chunk kernel puts the LDS writes of the PREVIOUS
 // step there: behind the products their latency costs nothing, in front of them it delays the first product)
-template <bool LIMS, bool REG2, int EXP, class Mid = Q4NoMid>
+// GPS (back_pass_gps, backward_pass.jl:290-307): Q• = (c• + f'V f)/η + c•kl.  The caller hands in c̃• = c•/η + c•kl (a prepass), so what is
+// left is the factor 1/η on the products with V: on Vx and on W = Vxx fx, W2 = Vxx'fu — three multiplications per step.
+template <bool LIMS, bool REG2, int EXP, class Mid = Q4NoMid, bool GPS = false>
 __device__ __forceinline__ void q4_step(int i, const Q4In &o, Q4State &s, Q4Out &out, const Q4Par &p, Mid mid = Mid())
 {
     const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};                                   // boxQP.jl:30-35
@@ -133,10 +136,12 @@ __device__ __forceinline__ void q4_step(int i, const Q4In &o, Q4State &s, Q4Out 
         ff = mm(o.fu, o.fu, 0.0);                               // fu'fu
     }
     // ---- Q-function expansion (:165-169 / :203-210 / :240-244)
-    const double Qu = mm(o.fu, s.vxc, o.cu);
-    const double Qxc = mm(o.fx, s.vxc, o.cx);
-    const double W2 = mm(s.V, o.fu, 0.0);                       // Vxx'·fu: (fu'Vxx)' in column form
-    const double W = mm(s.VT, o.fx, 0.0);                       // Vxx·fx
+    const double vxs = GPS ? s.vxc * p.ieta : s.vxc;
+    const double Qu = mm(o.fu, vxs, o.cu);
+    const double Qxc = mm(o.fx, vxs, o.cx);
+    double W2 = mm(s.V, o.fu, 0.0);                             // Vxx'·fu: (fu'Vxx)' in column form
+    double W = mm(s.VT, o.fx, 0.0);                             // Vxx·fx
+    if (GPS) { W2 *= p.ieta; W *= p.ieta; }
     const double Quu = mm(o.fu, W2, o.cuu);
     const double Quxc = mm(o.fx, W2, o.cxuc);
     const double Quxr = mm(W2, o.fx, o.cxur);
@@ -198,7 +203,7 @@ __device__ __forceinline__ void q4_zero_fill(const Q4Args &a, int b, int q16, in
 }
 
 // ---- one time step at a time: any N, time-varying cost (CTV) or not
-template <bool LIMS, bool CTV, bool REG2, int EXP = 0>
+template <bool LIMS, bool CTV, bool REG2, int EXP = 0, bool GPS = false>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4_kernel(Q4Args a)
 {
     constexpr int n = 4, D = 8;
@@ -224,7 +229,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4_kernel(Q4Args a)
     const unsigned st_stride = (st_K || st_Vx) ? n * 8u : 8u;
 
     Q4Par par;
-    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;
+    par.lam = GPS ? 0.0 : a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;     // back_pass_gps: η is the only regularisation
+    par.ieta = GPS ? 1.0 / a.eta[b] : 1.0;
     if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }     // backward_pass.jl:31
 
     // ---- terminal step (backward_pass.jl:21-23 / :197-199 / :234-236).  Vxx_i is exactly symmetric for i < N-1; the terminal cxx
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4_kernel(Q4Args a)
     auto step = [&](int i, Q4In &o) __attribute__((always_inline)) {
         if (!CTV) { o.cxx = cst.cxx; o.cxxT = cst.cxxT; o.cxuc = cst.cxuc; o.cxur = cst.cxur; o.cuu = cst.cuu; }
         Q4Out out;
-        q4_step<LIMS, REG2, EXP>(i, o, s, out, par);
+        q4_step<LIMS, REG2, EXP, Q4NoMid, GPS>(i, o, s, out, par);
         // ---- stores (a diverged trajectory keeps writing; its range is zero-filled after the loop)
         if (act && !(EXP & 1)) Vxxg[(size_t)(unsigned)(16 * i)] = out.Vn;
         const double v0 = st_K ? out.Kc : st_Vx ? out.vx : st_k ? out.kk : out.Quu;       // :75-76
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
     const unsigned st_stride = !st_on ? 0u : (st_K || st_Vx) ? 2u * n * 8u : 16u;      // bytes per pair
 
     Q4Par par;
-    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;
+    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true; par.ieta = 1.0;
     if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }
 
     Q4In cst;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
     };
 
     Q4Par par;
-    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;
+    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true; par.ieta = 1.0;
     if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }
     const double *cxx = a.cxx + a.cxx_b * b, *cuu = a.cuu + a.cuu_b * b, *cxu = a.cxu + a.cxu_b * b;
     Q4In cst;
@@ -548,6 +554,49 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
     if (act && q16 == 0) { a.dV[2 * b] = s.dV0; a.dV[2 * b + 1] = s.dV1; a.diverge[b] = s.diverge; }
 }
 
+
+// ---- back_pass_gps for n = 4, m = 1 on the same kernel (backward_pass.jl:259-350).  c̃• = c•/η + c•kl for every step but the last,
+// where the reference takes Vx[:,N] = cx[:,N], Vxx[:,:,N] = cxx[:,:,N] as they are and Quu[:,:,N] = cuu/η + cuukl (:281-283).
+struct GpsCombine {
+    int N, B;
+    int cxx_t, cxu_t, cuu_t;                                    // element strides of the cost Hessians per time step / trajectory
+    long cxx_b, cxu_b, cuu_b;
+    const double *cx, *cu, *cxx, *cxu, *cuu, *kcx, *kcu, *kcxx, *kcxu, *kcuu, *eta;
+    double *ox, *ou, *oxx, *oxu, *ouu;
+};
+__global__ __launch_bounds__(256) void gps_combine_kernel(GpsCombine a)
+{
+    const long NB = (long)a.N * a.B;
+    const int which = blockIdx.y;                               // 0 cx (4), 1 cu (1), 2 cxx (16), 3 cxu (4), 4 cuu (1)
+    const int len = which == 0 ? 4 : which == 2 ? 16 : which == 3 ? 4 : 1;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= NB * len) return;
+    const long tb = g / len;
+    const int e = (int)(g % len), t = (int)(tb % a.N);
+    const long b = tb / a.N;
+    const bool last = t == a.N - 1;
+    const double ie = 1.0 / a.eta[b];
+    switch (which) {
+    case 0: a.ox[g] = last ? a.cx[g] : a.cx[g] * ie + a.kcx[g]; break;
+    case 1: a.ou[g] = a.cu[g] * ie + a.kcu[g]; break;
+    case 2: { const double c = a.cxx[a.cxx_b * b + (long)a.cxx_t * t + e]; a.oxx[g] = last ? c : c * ie + a.kcxx[g]; } break;
+    case 3: a.oxu[g] = a.cxu[a.cxu_b * b + (long)a.cxu_t * t + e] * ie + a.kcxu[g]; break;          // m = 1: cxukl[1,4] and cxu[4,1] share their order
+    default: a.ouu[g] = a.cuu[a.cuu_b * b + (long)a.cuu_t * t] * ie + a.kcuu[g]; break;
+    }
+}
+// Quui[:,:,i] = inv(Quu[:,:,i]) (:283,344) for the steps the pass completed: every step without a failure, the steps after the failing
+// one otherwise (it returns before :344 at the failing step; the caller's array is zero-filled)
+__global__ __launch_bounds__(256) void gps_quui_kernel(int N, long NB, const double *__restrict__ Quu, const int32_t *__restrict__ diverge,
+                                                       const int32_t *__restrict__ active, double *__restrict__ Quui)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= NB) return;
+    const long b = g / N;
+    if (active && active[b] == 0) return;
+    const int t = (int)(g % N), dv = diverge[b];                // dv = 1-based failing step, 0: none
+    Quui[g] = (dv == 0 || t > dv - 1) ? 1.0 / Quu[g] : 0.0;
+}
+
 }   // namespace
 
 // returns 1 if this shape has no such kernel (caller falls back), 0 launched, <0 error
@@ -609,6 +658,55 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
     }
 #undef Q4S
 #undef Q4P
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+// back_pass_gps for n = 4, m = 1 with one η per trajectory: prepass (c̃• = c•/η + c•kl into the handle's pad buffer), the matrix-core
+// kernel above with the 1/η factors on the products with V, Quui = 1/Quu.  Returns 1 when the shape is not handled here.
+int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                                const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                                const double *fu, const ddp_kl_cost_terms *kl, const double *lims, const double *u,
+                                const int32_t *active, double *K, double *k, double *Quu, double *Quui, double *Vx,
+                                double *Vxx, double *dV, int32_t *diverge)
+{
+    if (!(d->n == 4 && d->m == 1) || d->N < 2 || !d->fx_tv || !d->cost_tv || kl->eta_tv) return 1;
+    const char *q4e = getenv("DDP_GPS_Q4");                      // 0: never (the lane-per-trajectory kernel instead; A/B timing, tests)
+    if (q4e && q4e[0] == '0') return 1;
+    const long N = d->N, B = d->B, NB = N * B;
+    auto al = [](size_t b_) { return (b_ + 255) & ~(size_t)255; };
+    const size_t s4 = al((size_t)4 * NB * 8), s1 = al((size_t)NB * 8), s16 = al((size_t)16 * NB * 8), bytes = 2 * s4 + 2 * s1 + s16;
+    if (bytes > h->pad_bytes) {
+        DDP_HIP(hipStreamSynchronize(h->stream));
+        if (h->pad) DDP_HIP(hipFree(h->pad));
+        h->pad = nullptr; h->pad_bytes = 0;
+        DDP_HIP(hipMalloc(&h->pad, bytes));
+        h->pad_bytes = bytes;
+    }
+    char *q = (char *)h->pad;
+    auto tk = [&](size_t b_) { double *r_ = (double *)q; q += b_; return r_; };
+    GpsCombine c;
+    c.N = d->N; c.B = d->B;
+    c.cxx_t = 16; c.cxu_t = 4; c.cuu_t = 1;
+    c.cxx_b = d->cost_batched ? 16 * N : 0; c.cxu_b = d->cost_batched ? 4 * N : 0; c.cuu_b = d->cost_batched ? N : 0;
+    c.cx = cx; c.cu = cu; c.cxx = cxx; c.cxu = cxu; c.cuu = cuu;
+    c.kcx = kl->cx; c.kcu = kl->cu; c.kcxx = kl->cxx; c.kcxu = kl->cxu; c.kcuu = kl->cuu; c.eta = kl->eta;
+    c.ox = tk(s4); c.ou = tk(s1); c.oxx = tk(s16); c.oxu = tk(s4); c.ouu = tk(s1);
+    hipLaunchKernelGGL(gps_combine_kernel, dim3((unsigned)((16 * NB + 255) / 256), 5), dim3(256), 0, h->stream, c);
+    Q4Args a;
+    a.N = d->N; a.B = d->B; a.regType = 1;
+    a.fx_t = 16; a.fx_b = d->fx_batched ? 16 * N : 0;
+    a.fu_t = 4; a.fu_b = d->fx_batched ? 4 * N : 0;
+    a.cxx_t = 16; a.cxx_b = 16 * N; a.cxu_t = 4; a.cxu_b = 4 * N; a.cuu_t = 1; a.cuu_b = N;
+    a.cx = c.ox; a.cu = c.ou; a.cxx = c.oxx; a.cxu = c.oxu; a.cuu = c.ouu; a.fx = fx; a.fu = fu; a.lambda = nullptr; a.lims = lims;
+    a.u = u; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    a.eta = kl->eta; a.sink = (double *)h->sink;
+    const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
+    if (d->has_lims) hipLaunchKernelGGL((back_pass_q4_kernel<true, true, false, 0, true>), grid, block, 0, h->stream, a);
+    else hipLaunchKernelGGL((back_pass_q4_kernel<false, true, false, 0, true>), grid, block, 0, h->stream, a);
+    hipLaunchKernelGGL(gps_quui_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, h->stream, d->N, NB, (const double *)Quu,
+                       (const int32_t *)diverge, active, Quui);
     DDP_HIP(hipGetLastError());
     return 0;
 }

@@ -9,6 +9,13 @@
 #include <vector>
 #include "ddp_internal.h"
 
+// back_pass_gps on the matrix-core kernel of back_pass_q4.hip (n = 4, m = 1, one η per trajectory); 1 = shape not handled there
+int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                                const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                                const double *fu, const ddp_kl_cost_terms *kl, const double *lims, const double *u,
+                                const int32_t *active, double *K, double *k, double *Quu, double *Quui, double *Vx,
+                                double *Vxx, double *dV, int32_t *diverge);
+
 namespace {
 
 constexpr int NMAXK = DDP_MAX_N_GENERIC, MMAXK = DDP_MAX_M;
@@ -113,9 +120,98 @@ __global__ __launch_bounds__(DDP_WAVE) void fcov_kernel(int n, int m, int N, con
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ forward_covariance, n = 4
+// The C5 shape on the fp64 matrix cores, as the backward pass of back_pass_q4.hip: ONE TRAJECTORY PER BLOCK of v_mfma_f64_4x4x4_4b, four
+// per wave, every 4x4 matrix one element per lane ([r][c] in lane 16 r + 4 blk + c), mm(X, Y, C) = X'Y + C per block.  The chain
+// Σ -> Σ⁺ = (fx Σ) fx' + R1 (forward_pass.jl:49, the reference's association) is three dependent products per step — T = X1'Σ with
+// X1 = fx' (the load picks the lanes), T' = T'·I, Σ⁺ = (T')'X1 + R1 — against ~2 500 cycles per step of the run-time-sized kernel above
+// (one wave per trajectory, operands through the LDS, three hand-offs).  Off the chain: KΣ = Kt'Σ, ΣK' = (Σ')'Kt, (KΣ)K' + Σ_policy
+// with the transposes again by products with (shifted) identities; Kt holds K' in its columns 0..m-1 AND m..2m-1, so the last product
+// lands in lanes [m+a][m+b], which no other result uses: three stores per step (Σ | KΣ and KΣK' | ΣK').
+__device__ const double fcov_zeros[2] = {0.0, 0.0};
+
+template <int M>
+__global__ __launch_bounds__(DDP_WAVE) void fcov_q4_kernel(int N, int B, const double *__restrict__ fx, int fx_batched,
+                                                           const double *__restrict__ R1, const double *__restrict__ K,
+                                                           const double *__restrict__ Sigma, double *__restrict__ out, double *__restrict__ sink)
+{
+    constexpr int n = 4, p = n + M, pp = p * p, D = 6;
+    const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3;
+    long tb = (long)blockIdx.x * 4 + blk;
+    const bool valid = tb < B;
+    if (!valid) tb = B - 1;                                     // idle blocks repeat the last trajectory (their stores go to the sink)
+    const size_t b = (size_t)tb;
+    auto mm = [](double a_, double b_, double c_) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0); };
+    // ---- per-lane operand streams (pointer to this lane's entry of step 0, bytes per step); lanes without an entry read a zero
+    const char *pX = (const char *)(fx + (fx_batched ? (size_t)n * n * N * b : 0) + (c + n * r));      // X1[r][c] = fx[c, r]
+    const bool hasK = c < 2 * M;                                                                        // Kt[r][c] = K[c mod M, r]
+    const char *pK = hasK ? (const char *)(K + (size_t)M * n * N * b + (c % M) + M * r) : (const char *)fcov_zeros;
+    const unsigned sK = hasK ? M * n * 8u : 0u;
+    const bool hasS = r >= M && r < 2 * M && c >= M && c < 2 * M;                                       // Σ_policy[a, b] in lane [M+a][M+b]
+    const char *pS = hasS ? (const char *)(Sigma + (size_t)M * M * N * b + (r - M) + M * (c - M)) : (const char *)fcov_zeros;
+    const unsigned sS = hasS ? M * M * 8u : 0u;
+    // ---- per-lane result streams: sigmanew[ix,ix] = Σ | [iu,ix] = KΣ and [iu,iu] | [ix,iu] = ΣK'
+    double *ob = out + (size_t)pp * N * b;
+    const bool st2 = r < M || hasS, st3 = c < M;
+    char *q1 = valid ? (char *)(ob + r + p * c) : (char *)(sink + lane);
+    char *q2 = (valid && st2) ? (char *)(ob + (r < M ? (n + r) + p * c : (n + r - M) + p * (n + c - M))) : (char *)(sink + lane);
+    char *q3 = (valid && st3) ? (char *)(ob + r + p * (n + c)) : (char *)(sink + lane);
+    const unsigned s1 = valid ? pp * 8u : 0u, s2 = (valid && st2) ? pp * 8u : 0u, s3 = (valid && st3) ? pp * 8u : 0u;
+    const bool isU1 = r < M;
+    const double I = r == c ? 1.0 : 0.0, Ish = c == r + M ? 1.0 : 0.0;
+    const double R1L = R1[r + n * c];
+    double S = R1L;                                                                                    // Σ0 = R1 (forward_pass.jl:43)
+    struct Ops { double X1, Kt, Sp; };
+    auto fetch = [&](int i, Ops &o) {
+        o.X1 = *(const double *)(pX + (size_t)(n * n * 8u) * (unsigned)i);
+        o.Kt = *(const double *)(pK + (size_t)sK * (unsigned)i);
+        o.Sp = *(const double *)(pS + (size_t)sS * (unsigned)i);
+    };
+    auto step = [&](int i, const Ops &o) __attribute__((always_inline)) {
+        *(double *)(q1 + (size_t)s1 * (unsigned)i) = S;                                                // sigmanew[ix,ix,i] (:45)
+        const double T = mm(o.X1, S, 0.0);                                                             // fx Σ
+        const double U1 = mm(o.Kt, S, 0.0);                                                            // K Σ          (:50)
+        const double St = mm(S, I, 0.0);                                                               // Σ'
+        const double Tt = mm(T, I, 0.0);                                                               // (fx Σ)'
+        const double U1s = mm(U1, Ish, 0.0);                                                           // (K Σ)' shifted by M columns
+        const double U2 = mm(St, o.Kt, 0.0);                                                           // Σ K'         (:51)
+        const double Sn = mm(Tt, o.X1, R1L);                                                           // (fx Σ) fx' + R1 (:49)
+        const double U3 = mm(U1s, o.Kt, o.Sp);                                                         // K Σ K' + Σ_policy (:52)
+        *(double *)(q2 + (size_t)s2 * (unsigned)i) = isU1 ? U1 : U3;
+        *(double *)(q3 + (size_t)s3 * (unsigned)i) = U2;
+        S = Sn;
+    };
+    Ops ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d < N ? d : N - 1, ring[d]);
+    int i0 = 0;
+    for (; i0 + 2 * D <= N - 1; i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            step(i0 + d, ring[d]);
+            fetch(i0 + d + D, ring[d]);
+        }
+    }
+    for (; i0 < N - 1; i0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int i = i0 + d;
+            if (i < N - 1) {
+                step(i, ring[d]);
+                fetch(i + D < N ? i + D : N - 1, ring[d]);
+            }
+        }
+    }
+    // the last step has no policy block (the loop of forward_pass.jl:44-53 ends before it): Σ, zeros elsewhere
+    *(double *)(q1 + (size_t)s1 * (unsigned)(N - 1)) = S;
+    *(double *)(q2 + (size_t)s2 * (unsigned)(N - 1)) = 0.0;
+    *(double *)(q3 + (size_t)s3 * (unsigned)(N - 1)) = 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------ kl_div_wiki
 // log|det A| and the sign of det A for the leading m x m block (LU with partial pivoting, like logdet of a Matrix)
-__device__ double logabsdet_small(int m, const double *Ain, int &sgn)
+__device__ __forceinline__ double logabsdet_small(int m, const double *Ain, int &sgn)
 {
     double A[MMAXK * MMAXK];
     for (int e = 0; e < m * m; ++e) A[e] = Ain[e];
@@ -140,6 +236,57 @@ __device__ double logabsdet_small(int m, const double *Ain, int &sgn)
     return s;
 }
 
+// one time step of kl_div_wiki (klutils.jl:84-101) from the step's own slices of the ten arrays (global memory or an LDS image)
+template <int NC = 0, int MC = 0>
+__device__ __forceinline__ double kl_div_step(int n_, int m_, const double *xn, const double *xo, const double *St, const double *Knt,
+                                              const double *knt, const double *Snt, const double *Kpt, const double *kpt,
+                                              const double *Spt, const double *Si, int &threw)
+{
+    const int n = NC ? NC : n_, m = MC ? MC : m_;                        // compile-time sizes unroll every loop below
+    const int p = n + m;
+    double kd[MMAXK], mu[NMAXK], SKmu[MMAXK], Kmu[MMAXK];
+    for (int a = 0; a < m; ++a) kd[a] = kpt[a] - knt[a];
+    for (int j = 0; j < n; ++j) mu[j] = xn[j] - xo[j];
+    double tr1 = 0.0, q1 = 0.0;
+    for (int a = 0; a < m; ++a)
+        for (int c = 0; c < m; ++c) {
+            tr1 += Si[a + m * c] * Snt[c + m * a];                       // tr(Σip Σn)
+            q1 += kd[a] * Si[a + m * c] * kd[c];                         // k_diff'Σip k_diff
+        }
+    int sp, sn;
+    const double ldp = logabsdet_small(m, Spt, sp), ldn = logabsdet_small(m, Snt, sn);
+    if (sp < 0 || sn < 0) threw = 1;                                     // logdet throws a DomainError (:95-99)
+    double v = 0.5 * (tr1 + q1 - m + ldp - ldn);                         // :92
+    for (int a = 0; a < m; ++a) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += (Kpt[a + m * j] - Knt[a + m * j]) * mu[j];
+        Kmu[a] = s;
+    }
+    double q2 = 0.0, q3 = 0.0, tr2 = 0.0;
+    for (int a = 0; a < m; ++a) {                                        // Σip K_diff μ
+        double s = 0.0;
+        for (int c = 0; c < m; ++c) s += Si[a + m * c] * Kmu[c];
+        SKmu[a] = s;
+        q2 += Kmu[a] * s;
+        q3 += kd[a] * s;
+    }
+    for (int c = 0; c < n; ++c) {                                        // tr(K_diff'Σip K_diff Σt), Σt = sigmanew[1:n,1:n,t]
+        double SK[MMAXK];
+        for (int a = 0; a < m; ++a) {
+            double s = 0.0;
+            for (int a2 = 0; a2 < m; ++a2) s += Si[a + m * a2] * (Kpt[a2 + m * c] - Knt[a2 + m * c]);
+            SK[a] = s;
+        }
+        for (int r = 0; r < n; ++r) {
+            double s = 0.0;
+            for (int a = 0; a < m; ++a) s += (Kpt[a + m * r] - Knt[a + m * r]) * SK[a];
+            tr2 += s * St[c + p * r];
+        }
+    }
+    v += 0.5 * (q2 + tr2) + q3;                                          // :93-94
+    return v > 0.0 ? v : 0.0;                                            // :101
+}
+
 __global__ __launch_bounds__(DDP_WAVE) void kl_div_kernel(int n, int m, int N, const double *__restrict__ xnew,
                                                           const double *__restrict__ xold, const double *__restrict__ sig,
                                                           const double *__restrict__ Kn, const double *__restrict__ kn,
@@ -154,53 +301,66 @@ __global__ __launch_bounds__(DDP_WAVE) void kl_div_kernel(int n, int m, int N, c
     int threw = 0;
     for (int t = lane; t < N; t += DDP_WAVE) {
         const size_t tb = (size_t)N * b + t;
-        const double *St = sig + pp * tb, *Si = Sip + mm * tb, *Snt = Sn + mm * tb, *Spt = Sp + mm * tb;
-        const double *Knt = Kn + nm * tb, *Kpt = Kp + nm * tb;
-        double kd[MMAXK], mu[NMAXK], SKmu[MMAXK], Kmu[MMAXK];
-        for (int a = 0; a < m; ++a) kd[a] = kp[(size_t)m * tb + a] - kn[(size_t)m * tb + a];
-        for (int j = 0; j < n; ++j) mu[j] = xnew[(size_t)n * tb + j] - xold[(size_t)n * tb + j];
-        double tr1 = 0.0, q1 = 0.0;
-        for (int a = 0; a < m; ++a)
-            for (int c = 0; c < m; ++c) {
-                tr1 += Si[a + m * c] * Snt[c + m * a];                       // tr(Σip Σn)
-                q1 += kd[a] * Si[a + m * c] * kd[c];                         // k_diff'Σip k_diff
-            }
-        int sp, sn;
-        const double ldp = logabsdet_small(m, Spt, sp), ldn = logabsdet_small(m, Snt, sn);
-        if (sp < 0 || sn < 0) threw = 1;                                     // logdet throws a DomainError (:95-99)
-        double v = 0.5 * (tr1 + q1 - m + ldp - ldn);                         // :92
-        for (int a = 0; a < m; ++a) {
-            double s = 0.0;
-            for (int j = 0; j < n; ++j) s += (Kpt[a + m * j] - Knt[a + m * j]) * mu[j];
-            Kmu[a] = s;
-        }
-        double q2 = 0.0, q3 = 0.0, tr2 = 0.0;
-        for (int a = 0; a < m; ++a) {                                        // Σip K_diff μ
-            double s = 0.0;
-            for (int c = 0; c < m; ++c) s += Si[a + m * c] * Kmu[c];
-            SKmu[a] = s;
-            q2 += Kmu[a] * s;
-            q3 += kd[a] * s;
-        }
-        for (int c = 0; c < n; ++c) {                                        // tr(K_diff'Σip K_diff Σt), Σt = sigmanew[1:n,1:n,t]
-            double SK[MMAXK];
-            for (int a = 0; a < m; ++a) {
-                double s = 0.0;
-                for (int a2 = 0; a2 < m; ++a2) s += Si[a + m * a2] * (Kpt[a2 + m * c] - Knt[a2 + m * c]);
-                SK[a] = s;
-            }
-            for (int r = 0; r < n; ++r) {
-                double s = 0.0;
-                for (int a = 0; a < m; ++a) s += (Kpt[a + m * r] - Knt[a + m * r]) * SK[a];
-                tr2 += s * St[c + p * r];
-            }
-        }
-        v += 0.5 * (q2 + tr2) + q3;                                          // :93-94
-        v = v > 0.0 ? v : 0.0;                                               // :101  (NaN -> 0 like max.(0, NaN)? no: see below)
+        const double v = kl_div_step(n, m, xnew + (size_t)n * tb, xold + (size_t)n * tb, sig + pp * tb, Kn + nm * tb, kn + (size_t)m * tb,
+                                     Sn + mm * tb, Kp + nm * tb, kp + (size_t)m * tb, Sp + mm * tb, Sip + mm * tb, threw);
         kldiv[tb] = v;
         acc += v;
     }
     for (int off = 32; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off, 64); threw |= __shfl_xor(threw, off, 64); }
+    if (lane == 0) klmean[b] = threw ? INFINITY : acc / N;
+}
+
+// The same with the operands of 64 time steps brought in by COALESCED loads into an LDS image first (small n, m: the C5 shape keeps 46
+// doubles per step).  With lanes over time every lane's own slice is contiguous but the lanes' slices are 8 .. 200 bytes apart: the
+// 25 loads of a step's sigmanew each touch 64 different lines, and the kernel above moved 7.0 GB for 0.93 GB of operands
+// (profiles/r03_c5_pmc.txt).  Per-step strides in the image are odd numbers of doubles (no bank conflicts).
+struct KlSrc { const double *g; int len; };
+template <int NC, int MC>
+__global__ __launch_bounds__(DDP_WAVE) void kl_div_lds_kernel(int n, int m, int N, KlSrc s0, KlSrc s1, KlSrc s2, KlSrc s3, KlSrc s4, KlSrc s5,
+                                                              KlSrc s6, KlSrc s7, KlSrc s8, KlSrc s9, double *__restrict__ kldiv,
+                                                              double *__restrict__ klmean)
+{
+    extern __shared__ double klds[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const KlSrc src[10] = {s0, s1, s2, s3, s4, s5, s6, s7, s8, s9};
+    int off[10], stride[10], q0[10], r0[10];
+    {
+        int o = 0;
+#pragma unroll
+        for (int a = 0; a < 10; ++a) {
+            stride[a] = src[a].len | 1;
+            off[a] = o;
+            o += stride[a] * DDP_WAVE;
+            q0[a] = lane / src[a].len; r0[a] = lane % src[a].len;        // (step, entry) of this lane's first element of a chunk
+        }
+    }
+    double acc = 0.0;
+    int threw = 0;
+    for (int t0 = 0; t0 < N; t0 += DDP_WAVE) {
+        const int cnt = N - t0 < DDP_WAVE ? N - t0 : DDP_WAVE;
+#pragma unroll
+        for (int a = 0; a < 10; ++a) {
+            const int len = src[a].len, total = cnt * len, dq = DDP_WAVE / len, dr = DDP_WAVE % len;
+            const double *gp = src[a].g + (size_t)len * ((size_t)N * b + t0);
+            int t = q0[a], e = r0[a];
+            for (int g = lane; g < total; g += DDP_WAVE) {
+                klds[off[a] + t * stride[a] + e] = gp[g];
+                t += dq; e += dr;
+                if (e >= len) { e -= len; ++t; }
+            }
+        }
+        wave_sync();
+        if (lane < cnt) {
+            const double *L[10];
+#pragma unroll
+            for (int a = 0; a < 10; ++a) L[a] = klds + off[a] + lane * stride[a];
+            const double v = kl_div_step<NC, MC>(n, m, L[0], L[1], L[2], L[3], L[4], L[5], L[6], L[7], L[8], L[9], threw);
+            kldiv[(size_t)N * b + t0 + lane] = v;
+            acc += v;
+        }
+        wave_sync();
+    }
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) { acc += __shfl_xor(acc, o2, 64); threw |= __shfl_xor(threw, o2, 64); }
     if (lane == 0) klmean[b] = threw ? INFINITY : acc / N;
 }
 
@@ -347,6 +507,8 @@ int ddp_back_pass_gps_f64_dev(ddp_handle h, const ddp_bp_desc *d,
     DDP_HIP(hipMemsetAsync(Quui, 0, sizeof(double) * (size_t)d->m * d->m * d->N * d->B, h->stream));
     const char *env = getenv("DDP_GPS_LANE");                     // 0: always the run-time-sized kernel (cross-check in the tests)
     if (!(env && env[0] == '0') && kl && kl->cx && kl->cu && kl->cxx && kl->cxu && kl->cuu && kl->eta && (!d->has_lims || (lims && u))) {
+        const int r4 = ddp_launch_back_pass_gps_q4(h, d, cx, cu, cxx, cxu, cuu, fx, fu, kl, lims, u, active, K, k, Quu, Quui, Vx, Vxx, dV, diverge);
+        if (r4 <= 0) return r4;                                   // n = 4, m = 1, one η per trajectory: the matrix-core kernel (DDP_GPS_Q4=0: not)
         const int rc = ddp_launch_back_pass_gps_lane(h, d, cx, cu, cxx, cxu, cuu, fx, fu, kl, lims, u, active, K, k, Quu, Quui, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;
     }
@@ -359,6 +521,14 @@ int ddp_forward_covariance_f64_dev(ddp_handle h, int n, int m, int N, int B, con
     DDP_DEVICE(h);
     DDP_CHECK(h && fx && R1 && K && Sigma && sigmanew, "forward_covariance: null argument");
     DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "forward_covariance: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
+    const char *q4env = getenv("DDP_FCOV_Q4");                     // 0: the run-time-sized kernel for every shape (cross-check in the tests)
+    if (n == 4 && (m == 1 || m == 2) && h->sink && !(q4env && q4env[0] == '0')) {
+        const dim3 grid((unsigned)((B + 3) / 4)), block(DDP_WAVE);
+        if (m == 1) hipLaunchKernelGGL(fcov_q4_kernel<1>, grid, block, 0, h->stream, N, B, fx, fx_batched, R1, K, Sigma, sigmanew, (double *)h->sink);
+        else hipLaunchKernelGGL(fcov_q4_kernel<2>, grid, block, 0, h->stream, N, B, fx, fx_batched, R1, K, Sigma, sigmanew, (double *)h->sink);
+        DDP_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(fcov_kernel, dim3(B), dim3(DDP_WAVE), fcov_lds(n, m), h->stream, n, m, N, fx, fx_batched, R1, K, Sigma, sigmanew);
     DDP_HIP(hipGetLastError());
     return 0;
@@ -372,8 +542,25 @@ int ddp_kl_div_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *x
     DDP_DEVICE(h);
     DDP_CHECK(h && xnew && xold && sigmanew && Kn && kn && Sn && Kp && kp && Sp && Sip && kldiv && klmean, "kl_div: null argument");
     DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "kl_div: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
-    hipLaunchKernelGGL(kl_div_kernel, dim3(B), dim3(DDP_WAVE), 0, h->stream, n, m, N, xnew, xold, sigmanew, Kn, kn, Sn, Kp, kp, Sp, Sip,
-                       kldiv, klmean);
+    // operands through an LDS image of 64 steps when that fits (DDP_KL_LDS=0: the direct kernel, cross-check in the tests)
+    const int lens[10] = {n, n, (n + m) * (n + m), n * m, m, m * m, n * m, m, m * m, m * m};
+    size_t image = 0;
+    for (int l : lens) image += (size_t)(l | 1) * DDP_WAVE * sizeof(double);
+    const char *lenv = getenv("DDP_KL_LDS");
+    if (image <= 48 * 1024 && !(lenv && lenv[0] == '0')) {
+        const double *ptr[10] = {xnew, xold, sigmanew, Kn, kn, Sn, Kp, kp, Sp, Sip};
+        KlSrc a[10];
+        for (int i = 0; i < 10; ++i) a[i] = KlSrc{ptr[i], lens[i]};
+#define DDP_KLL(NC_, MC_) hipLaunchKernelGGL((kl_div_lds_kernel<NC_, MC_>), dim3(B), dim3(DDP_WAVE), image, h->stream, n, m, N, a[0], a[1], a[2], \
+                                             a[3], a[4], a[5], a[6], a[7], a[8], a[9], kldiv, klmean)
+        if (n == 4 && m == 1) DDP_KLL(4, 1);
+        else if (n == 4 && m == 2) DDP_KLL(4, 2);
+        else DDP_KLL(0, 0);
+#undef DDP_KLL
+    } else {
+        hipLaunchKernelGGL(kl_div_kernel, dim3(B), dim3(DDP_WAVE), 0, h->stream, n, m, N, xnew, xold, sigmanew, Kn, kn, Sn, Kp, kp, Sp, Sip,
+                           kldiv, klmean);
+    }
     DDP_HIP(hipGetLastError());
     return 0;
 }
@@ -521,7 +708,8 @@ int ddp_ilqgkl_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqgkl_opts
         if ((rc = dual(0, it))) return rc;
         for (int guard = 0;; ++guard) {                    // back passes until the KL-regularised Quu is positive definite everywhere (:95-122)
             DDP_HIP(hipMemsetAsync(Sigma, 0, m * m * NB * 8, st));
-            rc = ddp_launch_back_pass_gps_lane(h, &d, cx, cu, cxx, cxu, cuu, fx, fu, &t, lims, kp, nullptr, K, k, Sigmai, Sigma, Vx, Vxx, dV, div);
+            rc = ddp_launch_back_pass_gps_q4(h, &d, cx, cu, cxx, cxu, cuu, fx, fu, &t, lims, kp, nullptr, K, k, Sigmai, Sigma, Vx, Vxx, dV, div);
+            if (rc > 0) rc = ddp_launch_back_pass_gps_lane(h, &d, cx, cu, cxx, cxu, cuu, fx, fu, &t, lims, kp, nullptr, K, k, Sigmai, Sigma, Vx, Vxx, dV, div);
             if (rc > 0) rc = ddp_launch_back_pass_gps(h, &d, cx, cu, cxx, cxu, cuu, fx, fu, &t, lims, kp, nullptr, K, k, Sigmai, Sigma, Vx, Vxx, dV, div);
             if (rc) return rc;
             int pending = 0;

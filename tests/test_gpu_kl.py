@@ -23,10 +23,14 @@ def _lims(g):
     return None if g["lims"].size == 0 else g["lims"]
 
 
-@pytest.mark.parametrize("lane", ["1", "0"])         # n=4: one lane per trajectory | the run-time-sized kernel for every shape
-@pytest.mark.parametrize("name", GPS)
-def test_gps_chain_golden(ddp, monkeypatch, name, lane):
+@pytest.mark.parametrize("mode", ["q4", "lane", "generic"])   # back_pass_gps: matrix-core kernel (n=4, m=1) | one lane per trajectory (n=4) |
+@pytest.mark.parametrize("name", GPS)                          # the run-time-sized kernel for every shape
+def test_gps_chain_golden(ddp, monkeypatch, name, mode):
+    lane = "0" if mode == "generic" else "1"
     monkeypatch.setenv("DDP_GPS_LANE", lane)
+    monkeypatch.setenv("DDP_GPS_Q4", "1" if mode == "q4" else "0")
+    monkeypatch.setenv("DDP_FCOV_Q4", lane)          # the same split for forward_covariance (n = 4: matrix-core kernel | run-time-sized kernel)
+    monkeypatch.setenv("DDP_KL_LDS", lane)           # and kl_div_wiki (operands through an LDS image | straight from global memory)
     kl = ddp.kl
     g = load_golden(name)
     N = g["u"].shape[1]
@@ -45,6 +49,94 @@ def test_gps_chain_golden(ddp, monkeypatch, name, lane):
     kld = kl.kl_div_wiki(g["xnew"], g["x"], sig, pol, prev)
     fin = np.isfinite(g["kldiv"])
     assert np.array_equal(np.isfinite(kld), fin) and relerr(kld[fin], g["kldiv"][fin]) < RTOL
+
+
+@pytest.mark.parametrize("m", [1, 2])
+def test_fcov_and_kl_div_fast_kernels_match_generic(ddp, monkeypatch, m):
+    """forward_covariance on the matrix cores (n = 4) and kl_div_wiki through the LDS image against the run-time-sized kernels (which the
+    goldens and the oracle pin): a ragged batch (B not a multiple of 4, N not a multiple of 64), per-trajectory model, and the oracle on
+    every trajectory"""
+    from oracle import oracle_ctypes as oc
+    kl = ddp.kl
+    rng = np.random.default_rng(40 + m)
+    n, N, B = 4, 70, 7
+
+    def spd(d, s=1.0):
+        a = rng.standard_normal((d, d)); return s * (a @ a.T / d + 0.5 * np.eye(d))
+    fx = np.stack([np.stack([np.eye(n) + 0.05 * rng.standard_normal((n, n)) for _ in range(N)], -1) for _ in range(B)], -1)
+    R1 = spd(n, 1e-2)
+    K = 0.3 * rng.standard_normal((m, n, N, B)); k = 0.1 * rng.standard_normal((m, N, B))
+    S = np.stack([np.stack([spd(m, 0.5) for _ in range(N)], -1) for _ in range(B)], -1)
+    Si = np.stack([np.stack([np.linalg.inv(S[:, :, t, b]) for t in range(N)], -1) for b in range(B)], -1)
+    Kp = 0.2 * rng.standard_normal((m, n, N, B)); kp = 0.1 * rng.standard_normal((m, N, B))
+    Sip = np.stack([np.stack([spd(m, 2.0) for _ in range(N)], -1) for _ in range(B)], -1)
+    Sp = np.stack([np.stack([np.linalg.inv(Sip[:, :, t, b]) for t in range(N)], -1) for b in range(B)], -1)
+    x = rng.standard_normal((n, N, B)); xnew = x + 0.1 * rng.standard_normal((n, N, B)); u = np.zeros((m, N, B))
+    pol = ddp.GaussianPolicy(N, n, m, K, k, S, Si); prev = ddp.GaussianPolicy(N, n, m, Kp, kp, Sp, Sip)
+    out = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("DDP_FCOV_Q4", fast); monkeypatch.setenv("DDP_KL_LDS", fast)
+        for fxm, tag in ((fx, "batched"), (fx[..., 2], "shared")):
+            sig = kl.forward_covariance(kl.Model(fxm, None, R1), x, u, pol)
+            out[fast, tag] = (sig, kl.kl_div_wiki(xnew, x, sig, pol, prev))
+    for tag in ("batched", "shared"):
+        assert relerr(out["1", tag][0], out["0", tag][0]) < 1e-12 and relerr(out["1", tag][1], out["0", tag][1]) < 1e-11
+        assert not out["1", tag][0][n:, n:, N - 1].any() and not out["1", tag][0][n:, :n, N - 1].any()       # last step: no policy block
+    sig, kld = out["1", "batched"]
+    for b in range(B):
+        sr = oc.forward_covariance(fx[..., b], R1, K[..., b], S[..., b])
+        assert relerr(sig[..., b], sr) < RTOL, b
+        kr = oc.kl_div_wiki(xnew[..., b], x[..., b], sr, dict(K=K[..., b], k=k[..., b], S=S[..., b]), dict(K=Kp[..., b], k=kp[..., b], S=Sp[..., b], Si=Sip[..., b]))
+        assert relerr(kld[:, b], kr) < RTOL, b
+
+
+@pytest.mark.parametrize("lims", [False, True])
+def test_gps_q4_batch_matches_lane_kernel_and_oracle(ddp, monkeypatch, lims):
+    """back_pass_gps for n = 4, m = 1 on the matrix-core kernel (prepass c̃ = c/η + c_kl, 1/η on the products with V): a ragged batch with
+    per-trajectory η, per-trajectory and shared cost Hessians, one trajectory failing — against the lane-per-trajectory kernel and the oracle"""
+    from oracle import oracle_ctypes as oc
+    kl = ddp.kl
+    rng = np.random.default_rng(19)
+    n, m, N, B = 4, 1, 37, 6
+
+    def spd(d, s=1.0):
+        a = rng.standard_normal((d, d)); return s * (a @ a.T / d + 0.5 * np.eye(d))
+    fx = np.stack([np.stack([0.9 * np.eye(n) + 0.02 * rng.standard_normal((n, n)) for _ in range(N)], -1) for _ in range(B)], -1)   # (stable: with unstable random
+    # dynamics and clamped controls Vxx reaches 1e10 .. 1e18, |grad| at the Newton point is rounding noise above minGrad = 1e-8, and
+    # whether the QP ends with result 5 or breaks on sdotg >= 0 (result 0, boxQP.jl:133) is decided by the last bit)
+    fu = 0.3 * rng.standard_normal((n, m, N, B))
+    cx, cu, u, x = rng.standard_normal((n, N, B)), rng.standard_normal((m, N, B)), 0.3 * rng.standard_normal((m, N, B)), rng.standard_normal((n, N, B))
+    Kp, kp = 0.2 * rng.standard_normal((m, n, N, B)), 0.1 * rng.standard_normal((m, N, B))
+    Sip = 0.5 + rng.uniform(0, 2, (m, m, N, B)); Sp = 1.0 / Sip
+    etab = np.stack([1e-8 * np.ones(B), np.array([1.0, 0.5, 2.0, 1.0, 4.0, 0.25]), 1e16 * np.ones(B)])
+    terms = kl.grad_kl(ddp.GaussianPolicy(N, n, m, Kp, kp, Sp, Sip))
+    L = np.array([[-0.3, 0.25]]) if lims else None
+    for batched_cost in (True, False):
+        if batched_cost:
+            cxx = np.stack([np.stack([spd(n) for _ in range(N)], -1) for _ in range(B)], -1)
+            cuu = 0.5 + rng.uniform(0, 1, (m, m, N, B)); cxu = 0.05 * rng.standard_normal((n, m, N, B))
+            cuu[:, :, 9, 3] = -30.0                                             # Quu < 0 there: trajectory 3 fails at step 10
+        else:
+            cxx = np.stack([spd(n) for _ in range(N)], -1); cuu = 0.5 + rng.uniform(0, 1, (m, m, N)); cxu = 0.05 * rng.standard_normal((n, m, N))
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("DDP_GPS_Q4", mode)
+            res[mode] = kl.back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, L, x, u, (terms, etab))
+        (d1, p1, vx1, vxx1, dv1), (d0, p0, vx0, vxx0, dv0) = res["1"], res["0"]
+        assert np.array_equal(d1, d0) and (not batched_cost or lims or d1[3] == 10)      # (with limits a clamped control skips the factorisation)
+        for got, ref, nm in ((p1.K, p0.K, "K"), (p1.k, p0.k, "k"), (p1.Σ, p0.Σ, "Quui"), (p1.Σi, p0.Σi, "Quu"), (vx1, vx0, "Vx"), (vxx1, vxx0, "Vxx"),
+                             (dv1, dv0, "dV")):
+            assert relerr(got, ref) < 1e-10, (nm, batched_cost, relerr(got, ref))
+        assert np.array_equal(vxx1, np.transpose(vxx1, (1, 0, 2, 3)))
+        for b in range(B):
+            sl = lambda a_: a_[..., b] if batched_cost else a_                   # noqa: E731
+            tb = oc.kl_terms(Kp[..., b], kp[..., b], Sip[..., b])
+            d, (K, k, Quui, Quu), vx, vxx, dv = oc.back_pass_gps(cx[..., b], cu[..., b], sl(cxx), sl(cxu), sl(cuu), fx[..., b], fu[..., b], L,
+                                                                x[..., b], u[..., b], (tb, etab[:, b]))
+            assert d1[b] == d
+            for got, ref, nm in ((p1.K[..., b], K, "K"), (p1.k[..., b], k, "k"), (p1.Σ[..., b], Quui, "Quui"), (p1.Σi[..., b], Quu, "Quu"),
+                                 (vx1[..., b], vx, "Vx"), (vxx1[..., b], vxx, "Vxx"), (dv1[:, b], dv, "dV")):
+                assert relerr(got, ref) < RTOL, (nm, b, relerr(got, ref))
 
 
 def test_gps_batch_matches_oracle(ddp):
