@@ -165,9 +165,9 @@ def back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u, *, fx_batc
     d = _lib.BPDesc(n, m, N, B, int(fx_tv), int(fx_batched), int(cost_tv), int(cost_batched), int(regType),
                     int(L is not None))
     lam = np.ascontiguousarray(np.broadcast_to(np.asarray(λ, dtype=np.float64), (B,)))
-    K = np.zeros((m, n, N, B), order="F"); k = np.zeros((m, N, B), order="F")
-    Quu = np.zeros((m, m, N, B), order="F"); Vx = np.zeros((n, N, B), order="F")
-    Vxx = np.zeros((n, n, N, B), order="F"); dV = np.zeros((2, B), order="F")
+    K = _lib.result_array((m, n, N, B)); k = _lib.result_array((m, N, B))
+    Quu = _lib.result_array((m, m, N, B)); Vx = _lib.result_array((n, N, B))
+    Vxx = _lib.result_array((n, n, N, B)); dV = np.zeros((2, B), order="F")
     div = np.zeros(B, dtype=np.int32)
     _lib.check(_lib.lib().ddp_back_pass_f64(h.raw, _C.byref(d), *map(_lib.ptr, (cx, cu, cxx, cxu, cuu, fx, fu, lam, L, u,
                                                                               K, k, Quu, Vx, Vxx, dV)),
@@ -301,8 +301,8 @@ def forward_pass(traj_new, x0, u, x, α, problem, lims, *, handle=None):
             raise ValueError("traj_new.K, traj_new.k, x should be (m,n,N), (m,N), (n,N) [+ batch axis]")
     L = _lims(lims)
     CL = dp.cost_len
-    xnew = np.zeros((n, N, B, na), order="F"); unew = np.zeros((m, N, B, na), order="F")
-    cnew = np.zeros((CL, B, na), order="F"); csum = np.zeros((B, na), order="F")
+    xnew = _lib.result_array((n, N, B, na)); unew = _lib.result_array((m, N, B, na))
+    cnew = _lib.result_array((CL, B, na)); csum = np.zeros((B, na), order="F")
     _lib.check(_lib.lib().ddp_forward_pass_f64(h.raw, _C.byref(dp.struct), _lib.ptr(K), _lib.ptr(k), _lib.ptr(x0),
                                                _lib.ptr(u), _lib.ptr(xx), _lib.ptr(alphas), na, _lib.ptr(L),
                                                _lib.ptr(xnew), _lib.ptr(unew), _lib.ptr(cnew), _lib.ptr(csum)))
@@ -324,10 +324,10 @@ def df(problem, x, u, *, handle=None):
     n = x.shape[0]
     B = u.shape[2] if batched else 1
     dp = _DevProblem(problem, N, B)
-    cx = np.zeros((n, N, B), order="F"); cu = np.zeros((m, N, B), order="F")
+    cx = _lib.result_array((n, N, B)); cu = _lib.result_array((m, N, B))
     pend = problem.kind == 1
-    fx = np.zeros((n, n, N, B), order="F") if pend else None
-    fu = np.zeros((n, m, N, B), order="F") if pend else None
+    fx = _lib.result_array((n, n, N, B)) if pend else None
+    fu = _lib.result_array((n, m, N, B)) if pend else None
     _lib.check(_lib.lib().ddp_df_f64(h.raw, _C.byref(dp.struct), _lib.ptr(x), _lib.ptr(u), _lib.ptr(cx), _lib.ptr(cu),
                                      _lib.ptr(fx), _lib.ptr(fu)))
     if not pend:
@@ -405,9 +405,9 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
         o.alpha[i] = a
     L = _lims(lims)
     CL = dp.cost_len
-    x = np.zeros((n, N, B), order="F"); u = np.zeros((m, N, B), order="F")
-    K = np.zeros((m, n, N, B), order="F"); k = np.zeros((m, N, B), order="F"); Quu = np.zeros((m, m, N, B), order="F")
-    Vx = np.zeros((n, N, B), order="F"); Vxx = np.zeros((n, n, N, B), order="F")
+    x = _lib.result_array((n, N, B)); u = _lib.result_array((m, N, B))
+    K = _lib.result_array((m, n, N, B)); k = _lib.result_array((m, N, B)); Quu = _lib.result_array((m, m, N, B))
+    Vx = _lib.result_array((n, N, B)); Vxx = _lib.result_array((n, n, N, B))
     stats = np.zeros((8, B), order="F")
     # rows of the per-iteration trace kept per trajectory; by default bounded so that trace7[7, cap, B] stays under 256 MB
     # (a batch of 4096 pendcart solves with cap = 4 max_iter + 64 moved 0.93 GB of mostly zeros)
@@ -415,8 +415,8 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     cap = min(cap, 4096)
     git = _C.c_int(0)
     c0 = None if (not prerolled or cost is None or np.size(cost) == 0) else _lib.f64(np.reshape(cost, (CL, B), order="F"))
-    cost = np.zeros((CL, B), order="F")
-    tr7 = np.zeros((7, cap, B), order="F")
+    cost = _lib.result_array((CL, B))
+    tr7 = _lib.result_array((7, cap, B))
     tcap = 4 * max_iter + 1000                                 # the driver's bound on global iterations
     timing_on = bool(timing)
     timing = np.full((3, tcap), np.nan)

@@ -20,7 +20,7 @@ vp = C.c_void_p
 
 EXPORTS = [
     "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_stream",
-    "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_memset",
+    "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_memset", "ddp_host_alloc", "ddp_host_free", "ddp_host_trim",
     "ddp_event_create", "ddp_event_destroy", "ddp_event_record", "ddp_event_elapsed_ms",
     "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
     "ddp_cost_len", "ddp_forward_pass_f64_dev", "ddp_forward_pass_f64", "ddp_df_f64_dev", "ddp_df_f64",
@@ -162,6 +162,42 @@ def default_handle(device=0):
     if device not in _default:
         _default[device] = Handle(device)
     return _default[device]
+
+
+class _Pinned:
+    """a block of page-locked host memory from the library's cache (ddp_host_alloc); arrays made from it keep it alive"""
+    __slots__ = ("ptr", "nbytes", "__weakref__")
+
+    def __init__(self, nbytes):
+        p = vp()
+        check(lib().ddp_host_alloc(C.c_size_t(max(int(nbytes), 1)), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().ddp_host_free(vp(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (max(self.nbytes, 1),), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+
+def result_array(shape, dtype=np.float64):
+    """Fortran-ordered array for a RESULT of a host-pointer call.  Page-locked memory from the library's cache when the array is large
+    (>= 1 MB; DDP_PINNED_RESULTS=0: never): the device writes straight into it at link speed, and the block comes back from the cache on
+    the next call of the same size instead of fresh pageable pages that fault on first touch.  Contents are unspecified until the call
+    has filled the array (every result array is written in full)."""
+    shape = tuple(int(s) for s in np.atleast_1d(shape))
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    if nbytes < (1 << 20) or os.environ.get("DDP_PINNED_RESULTS") == "0":
+        return np.zeros(shape, dtype=dt, order="F")
+    blk = _Pinned(nbytes)
+    return np.asarray(blk)[:nbytes].view(dt).reshape(shape, order="F")
 
 
 def f64(a):

@@ -1,7 +1,10 @@
 // capi.hip — handle, memory/event helpers, host-pointer flavours and the standalone batched boxQP
 // of the C ABI declared in include/ddp_amd.h.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "ddp_internal.h"
 #include "boxqp_dev.h"
@@ -100,6 +103,93 @@ int ddp_free(ddp_handle h, void *dptr)
     if (dptr) { DDP_HIP(hipStreamSynchronize(h->stream)); DDP_HIP(hipFree(dptr)); }
     return 0;
 }
+// ---- page-locked host memory for results (ddp_amd.h).  Process-wide cache of freed blocks, keyed by their (2 MB-rounded) size: a host
+// that calls the same entry point again and again gets the same blocks back, so neither the pinning nor the first touch of fresh pages
+// is paid per call.  DDP_PINNED_CACHE_MB bounds the bytes kept in the cache (default 8192).
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;      // size -> block
+    std::map<void *, size_t> live;                  // block -> size
+    size_t cached = 0;
+    size_t cap()
+    {
+        const char *e = getenv("DDP_PINNED_CACHE_MB");
+        return (size_t)(e ? atol(e) : 8192) << 20;
+    }
+};
+PinnedPool &pinned_pool() { static PinnedPool p; return p; }
+}   // namespace
+
+int ddp_host_alloc(size_t bytes, void **hptr)
+{
+    DDP_CHECK(hptr, "ddp_host_alloc: null argument");
+    const size_t sz = ((bytes ? bytes : 1) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    PinnedPool &P = pinned_pool();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.free_blocks.find(sz);
+        if (it != P.free_blocks.end()) {
+            *hptr = it->second;
+            P.free_blocks.erase(it);
+            P.cached -= sz;
+            P.live[*hptr] = sz;
+            return 0;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, sz, hipHostMallocPortable);
+    if (e != hipSuccess) {                                      // make room: drop the cache and try once more
+        (void)hipGetLastError();
+        ddp_host_trim();
+        e = hipHostMalloc(&p, sz, hipHostMallocPortable);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ddp_set_error("ddp_host_alloc: hipHostMalloc(%zu) failed: %s", sz, hipGetErrorString(e));
+        return -2;
+    }
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live[p] = sz;
+    *hptr = p;
+    return 0;
+}
+
+int ddp_host_free(void *hptr)
+{
+    if (!hptr) return 0;
+    PinnedPool &P = pinned_pool();
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.live.find(hptr);
+        DDP_CHECK(it != P.live.end(), "ddp_host_free: %p was not allocated by ddp_host_alloc", hptr);
+        sz = it->second;
+        P.live.erase(it);
+        if (P.cached + sz <= P.cap()) {
+            P.free_blocks.insert({sz, hptr});
+            P.cached += sz;
+            return 0;
+        }
+    }
+    DDP_HIP(hipHostFree(hptr));
+    return 0;
+}
+
+int ddp_host_trim(void)
+{
+    PinnedPool &P = pinned_pool();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        for (auto &kv : P.free_blocks) drop.push_back(kv.second);
+        P.free_blocks.clear();
+        P.cached = 0;
+    }
+    for (void *p : drop) (void)hipHostFree(p);
+    return 0;
+}
+
 int ddp_memcpy_h2d(ddp_handle h, void *dst, const void *src, size_t bytes)
 {
     DDP_DEVICE(h);

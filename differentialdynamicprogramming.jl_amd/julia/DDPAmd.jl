@@ -135,6 +135,24 @@ default_handle() = (_default[] === nothing && (_default[] = Handle(0)); _default
 sync(h::Handle=default_handle()) = check(@ccall libddp.ddp_sync(h.ptr::Ptr{Cvoid})::Cint)
 device_count() = Int(@ccall libddp.ddp_device_count()::Cint)
 
+"""
+    result_array(dims...) -> Array{Float64}
+
+Array for a RESULT of a host-pointer call, in page-locked memory from the library's cache (`ddp_host_alloc`) when it is large (>= 1 MB;
+`ENV["DDP_PINNED_RESULTS"] = "0"`: plain `zeros`).  The device writes straight into it at link speed; a finalizer hands the block back to
+the cache, so the next call of the same size pays neither pinning nor first-touch page faults (1.2 GB of results per C2 pass).
+"""
+function result_array(dims::Integer...)
+    d = map(Int, dims)
+    nbytes = prod(d) * sizeof(Float64)
+    (nbytes < (1 << 20) || get(ENV, "DDP_PINNED_RESULTS", "1") == "0") && return zeros(d...)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(@ccall libddp.ddp_host_alloc(nbytes::Csize_t, r::Ptr{Ptr{Cvoid}})::Cint)
+    a = unsafe_wrap(Array, Ptr{Float64}(r[]), d; own=false)
+    finalizer(x -> (@ccall libddp.ddp_host_free(pointer(x)::Ptr{Cvoid})::Cint), a)
+    return a
+end
+
 # ---- output container (src/iLQG.jl:39-53); with a batch the arrays carry a trailing axis ------------
 mutable struct GaussianPolicy{P}
     T::Int
@@ -220,8 +238,8 @@ function back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u; handl
     has_lims = !isempty(limsp)
     d = BPDesc(n, m, N, B, fx_tv, fx_batched, cost_tv, cost_batched, regType, has_lims)
     bt = batched ? (B,) : ()
-    K = zeros(m, n, N, bt...); k = zeros(m, N, bt...); Quu = zeros(m, m, N, bt...)
-    Vx = zeros(n, N, bt...); Vxx = zeros(n, n, N, bt...); dV = zeros(2, bt...)
+    K = result_array(m, n, N, bt...); k = result_array(m, N, bt...); Quu = result_array(m, m, N, bt...)
+    Vx = result_array(n, N, bt...); Vxx = result_array(n, n, N, bt...); dV = zeros(2, bt...)
     diverge = zeros(Int32, B)
     lam = λ isa Number ? fill(Float64(λ), B) : _f64(λ)
     GC.@preserve cx cu cxx cxu cuu fx fu u lam limsp K k Quu Vx Vxx dV diverge begin
@@ -278,7 +296,7 @@ function forward_pass(traj_new, x0, u, x, α, problem::RegisteredProblem, lims; 
     empty = _isempty_policy(traj_new)
     al = α isa Number ? [Float64(α)] : _f64(α)
     na = length(al)
-    xnew = zeros(n, N, B, na); unew = zeros(m, N, B, na); cnew = zeros(CL, B, na); csum = zeros(B, na)
+    xnew = result_array(n, N, B, na); unew = result_array(m, N, B, na); cnew = result_array(CL, B, na); csum = zeros(B, na)
     x0 = _f64(x0); u = _f64(u)
     Kh = empty ? Float64[] : _f64(traj_new.K); kh = empty ? Float64[] : _f64(traj_new.k); xh = empty ? Float64[] : _f64(x)
     limsp = _lims(lims)
@@ -352,8 +370,9 @@ function iLQG(problem::RegisteredProblem, x0, u0; lims=[], α=DEFAULT_ALPHA, tol
     CL = cost_len(problem, N)
     o = _opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
     bt = batched ? (B,) : ()
-    x = zeros(n, N, bt...); u = zeros(m, N, bt...); K = zeros(m, n, N, bt...); k = zeros(m, N, bt...); Quu = zeros(m, m, N, bt...)
-    Vx = zeros(n, N, bt...); Vxx = zeros(n, n, N, bt...); costo = zeros(CL, bt...); stats = zeros(8, B)
+    x = result_array(n, N, bt...); u = result_array(m, N, bt...); K = result_array(m, n, N, bt...); k = result_array(m, N, bt...)
+    Quu = result_array(m, m, N, bt...); Vx = result_array(n, N, bt...); Vxx = result_array(n, n, N, bt...); costo = result_array(CL, bt...)
+    stats = zeros(8, B)
     cap = min(4max_iter + 64, 4096); tr7 = zeros(7, cap, B); git = Ref{Cint}(0)
     x0h = prerolled ? _f64(x0) : _f64(reshape(x0, n, B)); u0h = _f64(u0)
     c0 = (prerolled && !isempty(cost)) ? _f64(cost) : Float64[]
@@ -678,8 +697,8 @@ function iLQGkl(problem::RegisteredProblem, x0, traj_prev, fx_model, R1; kl_step
     size(etab) == (3, B) || error("ηbracket must be a 3-vector or 3×B")
     limsp = _lims(lims)
     o = ILQGKLOpts(kl_step, max_iter, (1e-8, 1.0, 1e16), del0)
-    x = zeros(n, N, B); u = zeros(m, N, B); K = zeros(m, n, N, B); S = zeros(m, m, N, B); Si = zeros(m, m, N, B)
-    Vx = zeros(n, N, B); Vxx = zeros(n, n, N, B); cnew = zeros(CL, B); dV = zeros(2, B); st = zeros(12, B)
+    x = result_array(n, N, B); u = result_array(m, N, B); K = result_array(m, n, N, B); S = result_array(m, m, N, B); Si = result_array(m, m, N, B)
+    Vx = result_array(n, N, B); Vxx = result_array(n, n, N, B); cnew = result_array(CL, B); dV = zeros(2, B); st = zeros(12, B)
     its = Ref{Cint}(0)
     GC.@preserve problem x0 c0 Kp u0 Sp Sip fxm R1 limsp etab x u K S Si Vx Vxx cnew dV st begin
         check(@ccall libddp.ddp_ilqgkl_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGKLOpts}, x0::Ptr{Float64},

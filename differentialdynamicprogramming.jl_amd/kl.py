@@ -53,8 +53,8 @@ def grad_kl(traj_prev, *, handle=None):
     batched = np.ndim(traj_prev.K) == 4
     K, k, Si = _b(traj_prev.K, 3), _b(traj_prev.k, 2), _b(traj_prev.Σi, 3)
     m, n, T, B = K.shape
-    cx = np.zeros((n, T, B), order="F"); cu = np.zeros((m, T, B), order="F"); cxx = np.zeros((n, n, T, B), order="F")
-    cxu = np.zeros((m, n, T, B), order="F"); cuu = np.zeros((m, m, T, B), order="F")
+    cx = _lib.result_array((n, T, B)); cu = _lib.result_array((m, T, B)); cxx = _lib.result_array((n, n, T, B))
+    cxu = _lib.result_array((m, n, T, B)); cuu = _lib.result_array((m, m, T, B))
     _lib.check(_lib.lib().ddp_kl_terms_f64(h.raw, n, m, T, B, *map(_lib.ptr, (K, k, Si, cx, cu, cxx, cxu, cuu))))
     out = (cx, cu, cxx, cxu, cuu)
     return out if batched else tuple(a[..., 0] for a in out)
@@ -93,8 +93,8 @@ def back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, kl_cost_terms, *, h
     L = _lims(lims)
     d = _lib.BPDesc(n, m, N, B, 1, int(fx.ndim == 4), 1, int(cxx.ndim == 4), 1, int(L is not None))
     t = _lib.KLCostTerms(*[_lib.ptr(a) for a in kl], _lib.ptr(eta), int(eta_tv))
-    K = np.zeros((m, n, N, B), order="F"); k = np.zeros((m, N, B), order="F"); Quu = np.zeros((m, m, N, B), order="F")
-    Quui = np.zeros((m, m, N, B), order="F"); Vx = np.zeros((n, N, B), order="F"); Vxx = np.zeros((n, n, N, B), order="F")
+    K = _lib.result_array((m, n, N, B)); k = _lib.result_array((m, N, B)); Quu = _lib.result_array((m, m, N, B))
+    Quui = _lib.result_array((m, m, N, B)); Vx = _lib.result_array((n, N, B)); Vxx = _lib.result_array((n, n, N, B))
     dV = np.zeros((2, B), order="F"); div = np.zeros(B, dtype=np.int32)
     _lib.check(_lib.lib().ddp_back_pass_gps_f64(h.raw, _C.byref(d), *map(_lib.ptr, (cx, cu, cxx, cxu, cuu, fx, fu)), _C.byref(t),
                                                 _lib.ptr(L), _lib.ptr(u), *map(_lib.ptr, (K, k, Quu, Quui, Vx, Vxx, dV)),
@@ -112,7 +112,7 @@ def forward_covariance(model, x, u, traj, *, handle=None):
     K, Sg = _b(traj.K, 3), _b(traj.Σ, 3)
     m, n, N, B = K.shape
     fx, R1 = _lib.f64(model.fx), _lib.f64(model.R1)
-    S = np.zeros((n + m, n + m, N, B), order="F")
+    S = _lib.result_array((n + m, n + m, N, B))
     _lib.check(_lib.lib().ddp_forward_covariance_f64(h.raw, n, m, N, B, _lib.ptr(fx), int(fx.ndim == 4), _lib.ptr(R1), _lib.ptr(K),
                                                      _lib.ptr(Sg), _lib.ptr(S)))
     return S if batched else S[..., 0]
@@ -297,9 +297,9 @@ def _ilqgkl_call(h, problem, model, prev0, lims, kl_step, max_iter, x, u, cost, 
     _lib.lib().ddp_ilqgkl_default_opts(_C.byref(o))
     o.kl_step, o.max_iter, o.del0 = float(kl_step), int(max_iter), float(del0)
     eb = np.asfortranarray(etab)
-    xo = np.zeros((n, N, B), order="F"); uo = np.zeros((m, N, B), order="F"); K = np.zeros((m, n, N, B), order="F")
-    S = np.zeros((m, m, N, B), order="F"); Si = np.zeros((m, m, N, B), order="F"); Vx = np.zeros((n, N, B), order="F")
-    Vxx = np.zeros((n, n, N, B), order="F"); co = np.zeros((CL, B), order="F"); dV = np.zeros((2, B), order="F")
+    xo = _lib.result_array((n, N, B)); uo = _lib.result_array((m, N, B)); K = _lib.result_array((m, n, N, B))
+    S = _lib.result_array((m, m, N, B)); Si = _lib.result_array((m, m, N, B)); Vx = _lib.result_array((n, N, B))
+    Vxx = _lib.result_array((n, n, N, B)); co = _lib.result_array((CL, B)); dV = np.zeros((2, B), order="F")
     st = np.zeros((_lib.ILQGKL_NSTATS, B), order="F")
     _lib.check(_lib.lib().ddp_ilqgkl_f64(h.raw, _C.byref(dp.struct), _C.byref(o), _lib.ptr(x), _lib.ptr(c0), _lib.ptr(Kp), _lib.ptr(u),
                                          _lib.ptr(Sp), _lib.ptr(Sip), _lib.ptr(mfx), int(mfx.ndim == 4), _lib.ptr(R1), _lib.ptr(Lh), _lib.ptr(eb),

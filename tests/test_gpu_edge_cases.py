@@ -479,3 +479,44 @@ def test_trace_cap_is_reported_and_truncation_flagged(ddp):
     assert not any(k.startswith("time_d") or k.startswith("time_b") or k.startswith("time_f") for k in tr)
     full = ddp.iLQG(prob, x0, u0)[6]
     assert not full["truncated"].any() and "time_derivs" in full and full["trace_cap"] >= int(full["iter"].max())
+
+
+def test_pinned_result_arrays(ddp, monkeypatch):
+    """ddp_host_alloc / ddp_host_free / ddp_host_trim: results of the host-pointer calls live in page-locked blocks from the library's
+    cache; a freed block of the same size comes back, the results equal those in plain numpy arrays (DDP_PINNED_RESULTS=0), and views keep
+    their block alive"""
+    import ctypes as C
+    import gc
+    from oracle import np_restatement as npr
+    _lib = ddp._lib
+    L = _lib.lib()
+    p1, p2 = C.c_void_p(), C.c_void_p()
+    _lib.check(L.ddp_host_alloc(C.c_size_t(3 << 20), C.byref(p1)))
+    _lib.check(L.ddp_host_free(p1))
+    _lib.check(L.ddp_host_alloc(C.c_size_t((3 << 20) + 5), C.byref(p2)))              # same 2 MB-rounded size: the cached block
+    assert p2.value == p1.value
+    _lib.check(L.ddp_host_free(p2))
+    assert L.ddp_host_free(C.c_void_p(12345)) != 0 and b"not allocated" in L.ddp_last_error()
+    _lib.check(L.ddp_host_trim())
+    rng = np.random.default_rng(8)
+    N, B = 300, 64
+    P = npr.make_lq_problem(rng, T=N)
+    prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+    x0 = np.ones((10, B)) + 0.1 * rng.standard_normal((10, B)); u0 = 0.1 * rng.standard_normal((2, N, B))
+    x, u, c = ddp.forward_pass(ddp.GaussianPolicy(), x0, u0, None, 1.0, prob, None)
+    cx = np.einsum("ij,jtb->itb", P["Q"], x); cu = np.einsum("ij,jtb->itb", P["R"], u)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DDP_PINNED_RESULTS", mode)
+        div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], 1.0, 1, None, x, u)
+        outs[mode] = (pol.K, pol.k, Vx, Vxx)
+    assert type(outs["1"][3].base).__name__ != "NoneType"                               # Vxx (1.5 MB here) sits in a library block
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a, b)
+    view = outs["1"][3][:, :, 5, 7]
+    ref = view.copy()
+    del outs, pol, Vx, Vxx
+    gc.collect()
+    monkeypatch.setenv("DDP_PINNED_RESULTS", "1")
+    other = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), 2.0 * P["R"], P["A"], P["B"], 1.0, 1, None, x, u)      # would reuse a freed block
+    assert np.array_equal(view, ref) and not np.array_equal(other[3][:, :, 5, 7], ref)
