@@ -15,8 +15,8 @@ n, m, N, B = 10, 2, 1000, 1024
 A, Bm, Q, R, x0, u0 = make_workload(1000, n, m, N, B)
 prob = ddp_amd.LQProblem(A, Bm, Q, R)
 x, u, c = ddp_amd.forward_pass(ddp_amd.GaussianPolicy(), x0, u0, None, 1.0, prob, None)
-cx = np.einsum("ij,jtb->itb", Q, x); cu = np.einsum("ij,jtb->itb", R, u)
-for it in range(3):
+cx = np.asfortranarray(np.einsum("ij,jtb->itb", Q, x)); cu = np.asfortranarray(np.einsum("ij,jtb->itb", R, u))     # Julia's layout, as a caller has it
+for it in range(6):
     t0 = time.perf_counter()
     div, pol, Vx, Vxx, dV = ddp_amd.back_pass(cx, cu, Q, np.zeros((n, m)), R, A, Bm, 1.0, 1, None, x, u)
     t1 = time.perf_counter()

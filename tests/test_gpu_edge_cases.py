@@ -491,6 +491,7 @@ def test_pinned_result_arrays(ddp, monkeypatch):
     _lib = ddp._lib
     L = _lib.lib()
     p1, p2 = C.c_void_p(), C.c_void_p()
+    _lib.check(L.ddp_host_trim())                                                        # (blocks earlier tests left in the cache)
     _lib.check(L.ddp_host_alloc(C.c_size_t(3 << 20), C.byref(p1)))
     _lib.check(L.ddp_host_free(p1))
     _lib.check(L.ddp_host_alloc(C.c_size_t((3 << 20) + 5), C.byref(p2)))              # same 2 MB-rounded size: the cached block
