@@ -1,5 +1,5 @@
-// forward_pass_pipe.hip — closed-loop rollout of the linear-quadratic family (n = 10, m = 2, a policy, no control limits,
-// time-invariant dynamics) as a PRODUCER / CONSUMER PIPELINE inside one work-group.  src/forward_pass.jl:9-33 with
+// forward_pass_pipe.hip — closed-loop rollout of the linear-quadratic family (n = 10, m = 2, a policy, no control limits;
+// time-invariant dynamics, or time-varying ones streamed through the same LDS image) as a PRODUCER / CONSUMER PIPELINE inside one work-group.  src/forward_pass.jl:9-33 with
 // f, costfun of src/demo_linear.jl:42-49.
 //
 // Why: the rollout is a strict chain x̂_i -> x̂_{i+1}.  At the BASELINE batch (1 024 rollouts, 4 per wave) the row kernel of
@@ -126,11 +126,12 @@ __device__ __forceinline__ void spread_pair(double v, double &q0, double &q1)
     q1 = __hiloint2double((int)f.y, (int)e.y);
 }
 
-// LDS map (bytes).  Raw image of a chunk, per rollout, in 16-byte slots: K (10 per step) | x (5 per step) | ū (1) | k (1)
-template <int G>
+// LDS map (bytes).  Raw image of a chunk, per rollout, in 16-byte slots: K (10 per step) | x (5 per step) | ū (1) | k (1) and, for
+// time-varying dynamics (TV), A_i (50 per step) | B_i (10 per step): 1 232 bytes per step and rollout instead of 272
+template <int G, bool TV = false>
 struct Lds {
-    static constexpr int RAW_PER_ROLL = G * (10 + 5 + 1 + 1);
-    static constexpr int RAW_K = 0, RAW_X = G * 10, RAW_U = G * 15, RAW_KV = G * 16;
+    static constexpr int RAW_PER_ROLL = G * (10 + 5 + 1 + 1 + (TV ? 60 : 0));
+    static constexpr int RAW_K = 0, RAW_X = G * 10, RAW_U = G * 15, RAW_KV = G * 16, RAW_A = G * 17, RAW_B = G * 67;
     static constexpr int RAW_SLOTS = (R4 * RAW_PER_ROLL + 63) / 64 * 64;       // whole wave instructions
     static constexpr int RAW_INSTR = RAW_SLOTS / 64;
     static constexpr int RAW_BUF = RAW_SLOTS * 16, NRAW = 3;
@@ -148,12 +149,12 @@ struct Lds {
 
 // G: steps per chunk.  Wave 0: output, wave 1: DMA, waves 2, 3: the chains of rollouts {0, 1} and {2, 3} (a work-group's waves go
 // to the SIMDs in cyclic order, one each).
-template <int G, bool FUSE>
+template <int G, bool FUSE, bool TV = false>
 __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
 {
     constexpr int n = PN, m = PM;
-    using L = Lds<G>;
-    static_assert(R4 * G <= 64 && L::TOTAL <= 80 * 1024, "chunk size");
+    using L = Lds<G, TV>;
+    static_assert(R4 * G <= 64 && L::TOTAL <= (TV ? 160 : 80) * 1024, "chunk size");
     __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
@@ -187,12 +188,14 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
         const int jx = inx ? j : 0, jj = inx ? j : n - 1;       // idle lanes repeat lane n-1's reads (their values are never broadcast)
         int b, ai; bool act; roll(r, b, ai, act);
         const double alpha = a.alpha[ai];
-        const double *Ab = a.A + (a.dyn_batched ? nn * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * b : 0);
+        const double *Ab = a.A + (a.dyn_batched ? nn * (TV ? N : 1) * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * (TV ? N : 1) * b : 0);
         const double z = inx ? 1.0 : 0.0;
-        double Arow[n];
+        double Arow[n], B0 = 0.0, B1 = 0.0;                     // time-invariant dynamics: row j of A and B in registers (zero rows for idle lanes)
+        if (!TV) {
 #pragma unroll
-        for (int l = 0; l < n; ++l) Arow[l] = z * Ab[jx + n * l];
-        const double B0 = z * Bb[jx], B1 = z * Bb[jx + n];
+            for (int l = 0; l < n; ++l) Arow[l] = z * Ab[jx + n * l];
+            B0 = z * Bb[jx]; B1 = z * Bb[jx + n];
+        }
         double one = 1.0;
         asm volatile("" : "+v"(one));
         double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0;
@@ -202,6 +205,9 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
         const char *rX = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + jj * 8;
         const char *rU = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_U) * 16 + h * 8;
         const char *rV = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_KV) * 16 + h * 8;
+        // TV: row jj of A_i (entries 80 bytes apart) and of B_i from the image; idle lanes read row n-1 (their x̂ is never broadcast)
+        const char *rA = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_A) * 16 + jj * 8;
+        const char *rB = smem + L::RAW_OFF + (r * L::RAW_PER_ROLL + L::RAW_B) * 16 + jj * 8;
         char *wX = smem + L::XH_OFF + r * L::XH_ROLL + h * 128 + j * 8;
         char *wU = smem + L::XU_OFF + r * 16 + h * 8;
         pipe_barrier();                                         // period -2
@@ -209,15 +215,30 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
         PROF_DECL
         for (int p = 0; p < NC; ++p) {
             const unsigned raw = (unsigned)(p % L::NRAW) * L::RAW_BUF;
-            const char *pK = rK + raw, *pX = rX + raw, *pU = rU + raw, *pV = rV + raw;
+            const char *pK = rK + raw, *pX = rX + raw, *pU = rU + raw, *pV = rV + raw, *pA = rA + raw, *pB = rB + raw;
             char *oX = wX + (p & 1) * L::XH_BUF, *oU = wU + (p & 1) * L::XU_BUF;
-            double ops[2][4];
+            double ops[2][4], dyn[2][TV ? n + m : 1];
             ops[0][0] = *(const double *)pK; ops[0][1] = *(const double *)pX; ops[0][2] = *(const double *)pU; ops[0][3] = *(const double *)pV;
+            if (TV) {
+#pragma unroll
+                for (int l = 0; l < n; ++l) dyn[0][l] = *(const double *)(pA + l * 80);
+                dyn[0][n] = *(const double *)pB; dyn[0][n + 1] = *(const double *)(pB + 80);
+            }
             if (PIPE_EXP != 3) static_for<0, G>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value, cu = t & 1, nx = cu ^ 1;
                 if constexpr (t + 1 < G) {
                     ops[nx][0] = *(const double *)(pK + (t + 1) * 160); ops[nx][1] = *(const double *)(pX + (t + 1) * 80);
                     ops[nx][2] = *(const double *)(pU + (t + 1) * 16); ops[nx][3] = *(const double *)(pV + (t + 1) * 16);
+                    if (TV) {
+#pragma unroll
+                        for (int l = 0; l < n; ++l) dyn[nx][l] = *(const double *)(pA + (t + 1) * 800 + l * 80);
+                        dyn[nx][n] = *(const double *)(pB + (t + 1) * 160); dyn[nx][n + 1] = *(const double *)(pB + (t + 1) * 160 + 80);
+                    }
+                }
+                if (TV) {
+#pragma unroll
+                    for (int l = 0; l < n; ++l) Arow[l] = dyn[cu][l];
+                    B0 = dyn[cu][n]; B1 = dyn[cu][n + 1];
                 }
                 const double *o = ops[cu];
                 // controls (forward_pass.jl:18-19): u_h = ū_h + α k_h, then += K_i[h,:]·dx — row h of the pair of rows forms control h
@@ -259,7 +280,9 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
             if (w < L::RAW_X) { src[k] = (const char *)(a.K + nm * N * b) + 16 * w; stepb[k] = 160; tau0[k] = w / 10; }
             else if (w < L::RAW_U) { src[k] = (const char *)(a.x + (size_t)n * N * b) + 16 * (w - L::RAW_X); stepb[k] = 80; tau0[k] = (w - L::RAW_X) / 5; }
             else if (w < L::RAW_KV) { src[k] = (const char *)(a.u + (size_t)m * N * b) + 16 * (w - L::RAW_U); stepb[k] = 16; tau0[k] = w - L::RAW_U; }
-            else { src[k] = (const char *)(a.k + (size_t)m * N * b) + 16 * (w - L::RAW_KV); stepb[k] = 16; tau0[k] = w - L::RAW_KV; }
+            else if (!TV || w < L::RAW_A) { src[k] = (const char *)(a.k + (size_t)m * N * b) + 16 * (w - L::RAW_KV); stepb[k] = 16; tau0[k] = w - L::RAW_KV; }
+            else if (w < L::RAW_B) { src[k] = (const char *)(a.A + (a.dyn_batched ? nn * N * b : 0)) + 16 * (w - L::RAW_A); stepb[k] = 800; tau0[k] = (w - L::RAW_A) / 50; }
+            else { src[k] = (const char *)(a.Bm + (a.dyn_batched ? nm * N * b : 0)) + 16 * (w - L::RAW_B); stepb[k] = 160; tau0[k] = (w - L::RAW_B) / 10; }
         }
         auto dma_chunk = [&](int c) __attribute__((always_inline)) {
             const unsigned base = lds0 + L::RAW_OFF + (unsigned)(c % L::NRAW) * L::RAW_BUF;
@@ -400,7 +423,7 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
         const bool wr = act && redo;
         const double alpha = a.alpha[ai];
         const double z = inx ? 1.0 : 0.0;
-        const double *Ab = a.A + (a.dyn_batched ? nn * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * b : 0);
+        const double *Ab = a.A + (a.dyn_batched ? nn * (TV ? N : 1) * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * (TV ? N : 1) * b : 0);
         const double *ug = a.u + (size_t)m * N * b, *xg = a.x + (size_t)n * N * b, *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b;
         double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai), *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
         double *co = FUSE ? a.cnew + (size_t)N * ((size_t)b + (size_t)B * ai) : nullptr;
@@ -415,6 +438,12 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
         if (FUSE) cw = inx ? 0.5 * a.Q[jx + n * jx] : (j < n + m ? 0.5 * a.R[(j - n) + m * (j - n)] : 0.0);
         double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0, cacc = 0.0;
         for (int i = 0; i < N; ++i) {
+            if (TV) {
+#pragma unroll
+                for (int l = 0; l < n; ++l) Arow[l] = z * Ab[nn * i + jx + n * l];
+#pragma unroll
+                for (int q = 0; q < m; ++q) Brow[q] = z * Bb[nm * i + jx + n * q];
+            }
             const d2 Kc = *(const d2 *)(Kg + nm * i + m * jx), uc = *(const d2 *)(ug + (size_t)m * i), kc = *(const d2 *)(kg + (size_t)m * i);
             const double dx = xh - xg[(size_t)n * i + jx];
             double pr0 = Kc.x * dx, pr1 = Kc.y * dx;
@@ -453,7 +482,7 @@ int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K,
                             const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
                             const int32_t *active, double *xnew, double *unew, double *cnew, double *csum)
 {
-    if (p->kind != DDP_PROBLEM_LQ || p->n != 10 || p->m != 2 || !K || lims || p->dyn_tv || !p->cost_diag || !h->sink) return 1;
+    if (p->kind != DDP_PROBLEM_LQ || p->n != 10 || p->m != 2 || !K || lims || !p->cost_diag || !h->sink) return 1;
     const char *env = getenv("DDP_FORWARD_PIPE");               // 0: never, 1: whenever the shape allows (A/B timing, tests)
     if (env && env[0] == '0') return 1;
     const char *fuse_env = getenv("DDP_FORWARD_FUSE");
@@ -463,13 +492,17 @@ int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K,
     // (2 048 rollouts: 0.215 against 0.201 ms)
     if (!(env && env[0] == '1') && total > 1024) return 1;
     if ((((uintptr_t)K | (uintptr_t)k | (uintptr_t)u | (uintptr_t)x) & 15) != 0) return 1;   // 16-byte pieces of K_i, x_i, k_i, ū_i for the DMA
+    if (p->dyn_tv && (((uintptr_t)p->A | (uintptr_t)p->Bm) & 15) != 0) return 1;
     FPipeArgs a;
     a.N = p->N; a.B = p->B; a.nalpha = nalpha; a.dyn_batched = p->dyn_batched;
     a.A = p->A; a.Bm = p->Bm; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.Q = p->Q; a.R = p->R; a.active = active;
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.xnew = xnew; a.unew = unew; a.cnew = cnew; a.csum = csum; a.sink = (double *)h->sink;
     const dim3 grid((unsigned)((total + 3) / 4));
-    hipLaunchKernelGGL((forward_pipe_kernel<12, true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
+    // time-varying dynamics: A_i, B_i (960 of the 1 232 bytes per step and rollout) come through the same image; chunks of 8 steps keep
+    // three images (120 KB) in the LDS
+    if (p->dyn_tv) hipLaunchKernelGGL((forward_pipe_kernel<8, true, true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
+    else hipLaunchKernelGGL((forward_pipe_kernel<12, true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
     DDP_HIP(hipGetLastError());
     return 0;
 }

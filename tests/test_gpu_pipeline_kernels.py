@@ -77,6 +77,45 @@ def test_forward_pipe_per_trajectory_dynamics(ddp, monkeypatch):
         assert relerr(xn[..., b], xr) < RTOL and relerr(un[..., b], ur) < RTOL and relerr(cn[..., b], cr) < RTOL
 
 
+@pytest.mark.parametrize("B,N,na,batched", [(1, 2, 1, True), (3, 7, 1, True), (4, 8, 1, False), (5, 9, 2, True), (9, 17, 3, False), (6, 100, 11, True),
+                                            (17, 37, 1, True)])
+def test_forward_pipe_time_varying_dynamics(ddp, monkeypatch, B, N, na, batched):
+    """LTV rollout (A_i, B_i through the LDS image, chunks of 8 steps): the row kernel's results to rounding, oracle 1e-8; shared
+    [n,n,N] and per-trajectory [n,n,N,B] dynamics, ragged batches, horizons around the chunk size, a NaN control on the redo path"""
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(77 * B + N)
+    P, A0, B0, x0, u, K, k = _rollout_case(rng, N, B)
+    sh = (10, 10, N, B) if batched else (10, 10, N)
+    A = A0.reshape(10, 10, *([1] * (len(sh) - 2))) * (1.0 + 0.02 * rng.standard_normal(sh))
+    Bm = B0.reshape(10, 2, *([1] * (len(sh) - 2))) * (1.0 + 0.1 * rng.standard_normal((10, 2) + sh[2:]))
+    prob = ddp.LQProblem(A, Bm, P["Q"], P["R"], dyn_batched=batched)
+    pol = ddp.GaussianPolicy(N, 10, 2, K, k)
+    monkeypatch.setenv("DDP_FORWARD_PIPE", "0")
+    xnom, _, _ = ddp.forward_pass(ddp.GaussianPolicy(), x0, u, None, 1.0, prob, None)
+    xnom = xnom.reshape(10, N, B)
+    alphas = 10.0 ** np.linspace(0, -3, na) if na > 1 else 1.0
+    row = ddp.forward_pass(pol, x0, u, xnom, alphas, prob, None)
+    monkeypatch.setenv("DDP_FORWARD_PIPE", "1")
+    pipe = ddp.forward_pass(pol, x0, u, xnom, alphas, prob, None)
+    # (the row kernel forms A x̂ + (B u) for time-varying dynamics, the pipeline B_1 u_1 + (B_0 u_0 + A x̂) as for time-invariant ones: rounding)
+    assert relerr(pipe[0], row[0]) < 1e-13 and relerr(pipe[1], row[1]) < 1e-13 and relerr(pipe[2], row[2]) < 1e-13
+    al = np.atleast_1d(alphas)
+    for b in range(B):
+        p = oc.make_problem("lq", 10, 2, N, A=A[..., b] if batched else A, B=Bm[..., b] if batched else Bm, Q=P["Q"], R=P["R"])
+        for j in sorted({0, na - 1}):
+            xr, ur, cr = oc.forward_pass(p, (K[..., b], k[..., b]), x0[:, b], u[..., b], xnom[..., b], float(al[j]), None)
+            g = (lambda a: a[..., b, j]) if na > 1 else (lambda a: a[..., b])
+            assert relerr(g(pipe[0]), xr) < RTOL and relerr(g(pipe[1]), ur) < RTOL and relerr(g(pipe[2]), cr) < RTOL
+    if N >= 9:                                                              # u[isnan.(u)] .= 0 inside f: the step-by-step redo path of the pipeline
+        k2 = k.copy(); k2[0, N // 2, 0] = np.nan
+        pol2 = ddp.GaussianPolicy(N, 10, 2, K, k2)
+        monkeypatch.setenv("DDP_FORWARD_PIPE", "0")
+        row2 = ddp.forward_pass(pol2, x0, u, xnom, 1.0, prob, None)
+        monkeypatch.setenv("DDP_FORWARD_PIPE", "1")
+        pipe2 = ddp.forward_pass(pol2, x0, u, xnom, 1.0, prob, None)
+        assert np.isfinite(pipe2[0]).all() and relerr(pipe2[0], row2[0]) < 1e-13 and relerr(pipe2[1], row2[1]) < 1e-13 and relerr(pipe2[2], row2[2]) < 1e-12
+
+
 def test_forward_pipe_nan_control_is_redone_with_the_reference_statements(ddp, monkeypatch):
     """`u[isnan.(u)] .= 0` inside f (demo_linear.jl:43): the pipeline detects the NaN control in its output stage and recomputes that
     rollout step by step; the other rollouts of the work-group keep their pipeline results"""
