@@ -566,7 +566,8 @@ end
     back_pass_gps(cx,cu,cxx,cxu,cuu,fx,fu,lims,x,u,kl_cost_terms) -> diverge, GaussianPolicy(N,n,m,K,k,Quui,Quu), Vx, Vxx, dV
 
 Same signature and return values as backward_pass.jl:259; `kl_cost_terms = (∇kl(traj_prev), ηbracket)` with `ηbracket` a 3-vector
-or a 3×N matrix.  One trajectory (the batched form is driven through the C ABI by the host mirror's iLQGkl).
+or a 3×N matrix.  One trajectory (a batch goes through `iLQGkl` below / `ddp_back_pass_gps_f64_dev`).  Shapes: n ≤ 32, m ≤ 8 (the library
+returns an error beyond; the plain `back_pass` reaches n ≤ 64).
 """
 function back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, lims, x, u, kl_cost_terms; handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
     n, N = size(cx); m = size(cu, 1)
