@@ -26,7 +26,7 @@ def fz():
 
 @pytest.fixture(autouse=True)
 def _clean_env():
-    keys = ("DDP_BACKPASS", "DDP_MX2", "DDP_FORWARD_PIPE", "DDP_FORWARD", "DDP_FORWARD_LANE")
+    keys = ("DDP_BACKPASS", "DDP_MX2", "DDP_FORWARD_PIPE", "DDP_FORWARD", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND")
     old = {k: os.environ.get(k) for k in keys}
     yield
     for k, v in old.items():
