@@ -193,8 +193,9 @@ class PassBench:
         force = os.environ.get("DDP_BACKPASS", "")[:1]
         mx2 = os.environ.get("DDP_MX2")
         mx = "back_pass_mx2_kernel<LTI>" if (mx2 == "1" if mx2 else B <= 1024) else "back_pass_mx_kernel<LTI>"      # back_pass.hip: ddp_launch_back_pass
-        kern = {"x": mx, "d": "back_pass_dpp_kernel<10,2,LTI>",
-                "g": "back_pass_kernel<10,2>"}.get(force, mx if B < 5120 else "back_pass_dpp_kernel<10,2,LTI>")
+        dppw = os.environ.get("DDP_DPPW")                      # back_pass_dppw.hip: ddp_launch_back_pass_dppw
+        rows = "back_pass_dppw_kernel<10,2>" if (dppw == "1" if dppw else B >= 6144) else "back_pass_dpp_kernel<10,2,LTI>"
+        kern = {"x": mx, "d": rows, "g": "back_pass_kernel<10,2>"}.get(force, mx if B < 5120 else rows)
         pipe = os.environ.get("DDP_FORWARD_PIPE")
         fwd = "forward_pipe_kernel" if (pipe == "1" if pipe else B <= 1024) and os.environ.get("DDP_FORWARD_FUSE", "1") != "0" else "forward_dpp_kernel"
         return {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

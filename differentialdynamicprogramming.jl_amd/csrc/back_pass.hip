@@ -708,6 +708,12 @@ static int launch_back_pass_padded(ddp_handle h, const ddp_bp_desc *d, const dou
     return 0;
 }
 
+// back_pass_dppw.hip: the row kernel with a write-back wave per chain wave (n = 10, m = 2, LTI, no limits, large batches); 1 = not applicable
+int ddp_launch_back_pass_dppw(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                              const double *fu, const double *lambda, const int32_t *active, double *K,
+                              double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
+
 int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                          const double *cxx, const double *cxu, const double *cuu, const double *fx,
                          const double *fu, const double *lambda, const double *lims, const double *u,
@@ -743,6 +749,10 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     if (force == 'q' || force == 0) {                             // n = 4, m = 1: one trajectory per 4x4x4 MFMA block
         const int rc = ddp_launch_back_pass_q4(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) return rc;
+    }
+    if (force == 0 || force == 'd') {                             // machine-filling batches of the LTI shape: row kernel + write-back waves
+        const int rw = ddp_launch_back_pass_dppw(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rw <= 0) return rw;
     }
     if (force != 'g' && force != 'b') {
         const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);

@@ -16,3 +16,14 @@ def timed(f, reps=5):
 t = timed(lambda: x.fill_(1.0)); print("fill   (write only) : %.2f TB/s" % (8 * n / t / 1e12))
 t = timed(lambda: y.copy_(x[: n // 2])); print("copy   (read+write) : %.2f TB/s total traffic" % (2 * 8 * (n // 2) / t / 1e12))
 t = timed(lambda: x.sum()); print("sum    (read only)  : %.2f TB/s" % (8 * n / t / 1e12))
+
+# the write pattern of a machine-filling backward pass: B far-apart streams (one per trajectory, 800 KB apart), each receiving a burst of
+# `steps` x 800 bytes per visit, all streams visited before the next burst — against the same bytes written as one contiguous run
+B, N = 32768, 64
+v = torch.empty((B, N, 100), dtype=torch.float64, device=dev)              # [trajectory, step, 100 doubles]: Vxx[:, :, i, b] of 64 steps
+for steps in (1, 4, 8, 16, 64):
+    def strided():
+        for t in range(0, N, steps):
+            v[:, t:t + steps, :].fill_(1.0)
+    t = timed(strided, reps=3)
+    print("%5d streams x bursts of %5d bytes: %.2f TB/s" % (B, steps * 800, 8 * v.numel() / t / 1e12))

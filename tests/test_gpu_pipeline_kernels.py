@@ -266,3 +266,105 @@ def test_ilqg_compaction_survives_a_failed_allocation(ddp, monkeypatch):
     assert np.array_equal(r[6]["stats"][:5], ref[6]["stats"][:5])
     for a, b_ in zip(r[:2] + (r[2].K, r[2].k) + r[3:6], ref[:2] + (ref[2].K, ref[2].k) + ref[3:6]):
         assert np.array_equal(a, b_)
+
+
+@pytest.mark.parametrize("B,N,regType", [(1, 1, 1), (1, 2, 1), (3, 3, 2), (5, 4, 1), (4, 5, 1), (17, 9, 2), (16, 37, 1), (33, 64, 1), (70, 101, 2), (29, 6, 1), (61, 7, 1)])
+def test_back_pass_dppw_vs_row_kernel_and_oracle(ddp, monkeypatch, B, N, regType):
+    """back_pass_dppw.hip (row kernel + write-back waves, the machine-filling kernel of the LTI shape) forced on small batches: 1e-11
+    against back_pass_dpp (same products; its accumulators start from the cost Hessians), Vxx exactly symmetric, the oracle at 1e-8 on every trajectory; horizons around the group
+    size of 4, ragged batches (partial chain waves and work-groups), both regularisations"""
+    from oracle import oracle_ctypes as oc
+    from oracle import np_restatement as npr
+    rng = np.random.default_rng(100 * B + N)
+    P = npr.make_lq_problem(rng, T=N)
+    cx = 0.05 * rng.standard_normal((10, N, B)); cu = 0.01 * rng.standard_normal((2, N, B))
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    cxu = 0.001 * rng.standard_normal((10, 2))
+    outs = {}
+    for tag, env in (("w", {"DDP_BACKPASS": "dpp", "DDP_DPPW": "1"}), ("d", {"DDP_BACKPASS": "dpp", "DDP_DPPW": "0"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        outs[tag] = ddp.back_pass(cx, cu, P["Q"], cxu, P["R"], P["A"], P["B"], lam, regType, None, None, np.zeros((2, N, B)))
+    (dw, pw, vxw, vxxw, dvw), (dd, pd, vxd, vxxd, dvd) = outs["w"], outs["d"]
+    assert np.array_equal(dw, dd) and not dw.any()
+    for got, ref in ((pw.K, pd.K), (pw.Σi, pd.Σi), (vxxw, vxxd), (pw.k, pd.k), (vxw, vxd), (dvw, dvd)):
+        assert relerr(got, ref) < 1e-11                               # same products, summed in another order (accumulators start from the cost Hessians)
+    assert np.array_equal(vxxw, np.transpose(vxxw, (1, 0, 2, 3)))
+    for b in range(B):
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], P["Q"], cxu, P["R"], P["A"], P["B"], lam[b], regType, None, None, np.zeros((2, N)))
+        assert d == 0
+        for got, ref, nm in ((pw.K[..., b], K, "K"), (pw.k[..., b], k, "k"), (pw.Σi[..., b], Quu, "Quu"), (vxw[..., b], vx, "Vx"),
+                             (vxxw[..., b], vxx, "Vxx"), (dvw[:, b], dv, "dV")):
+            assert relerr(got, ref) < RTOL, (nm, b, relerr(got, ref))
+
+
+def test_back_pass_dppw_divergence_and_inactive_trajectories(ddp, monkeypatch):
+    """a trajectory whose QuuF loses positive definiteness half-way (zero-fill behind the writer's copies, the failing step's Quu kept)
+    next to healthy ones, against the row kernel bit for bit and the oracle's diverge index"""
+    from oracle import oracle_ctypes as oc
+    from oracle import np_restatement as npr
+    rng = np.random.default_rng(9)
+    N, B = 30, 9
+    P = npr.make_lq_problem(rng, T=N)
+    cx = 0.05 * rng.standard_normal((10, N, B)); cu = 0.01 * rng.standard_normal((2, N, B))
+    R = P["R"].copy()
+    lam = np.full(B, 1e-3); lam[4] = -50.0 * np.abs(R).max()                 # QuuF = Quu + λI indefinite from the first step on for trajectory 4
+    outs = {}
+    for tag, w in (("w", "1"), ("d", "0")):
+        monkeypatch.setenv("DDP_BACKPASS", "dpp"); monkeypatch.setenv("DDP_DPPW", w)
+        outs[tag] = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), R, P["A"], P["B"], lam, 1, None, None, np.zeros((2, N, B)))
+    (dw, pw, vxw, vxxw, dvw), (dd, pd, vxd, vxxd, dvd) = outs["w"], outs["d"]
+    assert np.array_equal(dw, dd) and dw[4] == N - 1 and not np.delete(dw, 4).any()
+    d4 = oc.back_pass(cx[..., 4], cu[..., 4], P["Q"], np.zeros((10, 2)), R, P["A"], P["B"], lam[4], 1, None, None, np.zeros((2, N)))[0]
+    assert d4 == dw[4]
+    for got, ref in ((pw.K, pd.K), (pw.Σi, pd.Σi), (vxxw, vxxd), (pw.k, pd.k), (vxw, vxd), (dvw, dvd)):
+        assert relerr(got, ref) < 1e-11
+    assert not vxxw[:, :, : N - 2, 4].any() and vxxw[:, :, N - 1, 4].any()
+
+
+def test_back_pass_dppw_is_the_default_for_large_batches(ddp, monkeypatch):
+    """B >= 6144 of the shared-LTI shape goes to back_pass_dppw without any switch: against the row kernel on every trajectory, the oracle on a
+    sample; N - 1 not a multiple of the group size (short first group, held Vx / k pairs on both parities)"""
+    from oracle import oracle_ctypes as oc
+    from oracle import np_restatement as npr
+    rng = np.random.default_rng(61)
+    B, N = 6144 + 37, 23
+    P = npr.make_lq_problem(rng, T=N)
+    cx = 0.05 * rng.standard_normal((10, N, B)); cu = 0.01 * rng.standard_normal((2, N, B))
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    u = np.zeros((2, N, B))
+    monkeypatch.delenv("DDP_BACKPASS", raising=False); monkeypatch.delenv("DDP_DPPW", raising=False)
+    dw, pw, vxw, vxxw, dvw = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], lam, 1, None, None, u)
+    monkeypatch.setenv("DDP_DPPW", "0")
+    dd, pd, vxd, vxxd, dvd = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], lam, 1, None, None, u)
+    assert not dw.any() and not dd.any()
+    assert np.array_equal(vxxw, np.transpose(vxxw, (1, 0, 2, 3)))
+    assert not np.array_equal(vxw, vxd)                                    # (two kernels: their sums are ordered differently)
+    for got, ref in ((pw.K, pd.K), (pw.Σi, pd.Σi), (vxxw, vxxd), (pw.k, pd.k), (vxw, vxd), (dvw, dvd)):
+        assert relerr(got, ref) < 1e-11
+    for b in list(rng.integers(0, B, 24)) + [0, B - 1, B - 37, 6143]:
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], P["Q"], np.zeros((10, 2)), P["R"], P["A"], P["B"], lam[b], 1, None, None, u[..., b])
+        assert d == 0
+        for got, ref in ((pw.K[..., b], K), (pw.k[..., b], k), (pw.Σi[..., b], Quu), (vxw[..., b], vx), (vxxw[..., b], vxx), (dvw[:, b], dv)):
+            assert relerr(got, ref) < RTOL
+
+
+def test_ilqg_with_dppw_and_finished_trajectories(ddp, monkeypatch):
+    """the device-resident iLQG loop with back_pass_dppw forced: trajectories that have converged are masked out of later backward passes
+    (the writer's per-trajectory store mask) — same iterations and results as with the row kernel"""
+    from oracle import np_restatement as npr
+    rng = np.random.default_rng(23)
+    B, T = 41, 60
+    P = npr.make_lq_problem(rng, T=T)
+    prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+    x0 = np.ones((10, B)) + 0.1 * rng.standard_normal((10, B))
+    u0 = 0.1 * rng.standard_normal((2, T, B)) * (1 + 3 * np.arange(B))[None, None, :]
+    monkeypatch.setenv("DDP_ILQG_COMPACT", "0"); monkeypatch.setenv("DDP_BACKPASS", "dpp")
+    monkeypatch.setenv("DDP_DPPW", "0")
+    ref = ddp.iLQG(prob, x0, u0, tol_fun=1e-6)
+    monkeypatch.setenv("DDP_DPPW", "1")
+    r = ddp.iLQG(prob, x0, u0, tol_fun=1e-6)
+    assert np.array_equal(r[6]["stats"][0], ref[6]["stats"][0])           # iterations per trajectory
+    assert len(set(r[6]["stats"][0].tolist())) > 1                         # ... which differ: some trajectories sat out passes
+    for a, b_ in zip(r[:2] + (r[2].K, r[2].k) + r[3:6], ref[:2] + (ref[2].K, ref[2].k) + ref[3:6]):
+        assert relerr(a, b_) < 1e-9
