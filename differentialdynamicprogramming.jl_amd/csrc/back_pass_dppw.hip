@@ -298,12 +298,15 @@ __global__ __launch_bounds__(DDP_WAVE * (NCW + NWW)) void back_pass_dppw_kernel(
         // this lane's record cells: column j of Vxx (x-lanes), K[:, j] and Vx[j] (x-lanes), Quu[:, j-n] (u-lanes), k (spare lane)
         double *rw = &recs[cw][0][grp][0];
         auto rc_load = [&](int i) { return inx ? cx[(size_t)n * i + jx] : cu[(size_t)m * i + ja]; };     // cx[j, i] | cu[j-n, i]
-        double rc = rc_load(N - 2);
+        // the gradient entry of step i is requested four steps ahead: with the result stores of a machine-filling batch in the memory
+        // pipeline a load takes several microseconds
+        auto rc_at = [&](int i) { return rc_load(i > 0 ? i : 0); };
+        double rc = rc_load(N - 2), rc1 = rc_at(N - 3), rc2 = rc_at(N - 4), rc3 = rc_at(N - 5);
         dpp_fence(Vcol);
         asm volatile("s_nop 1" : "+v"(vj));
         int g = 0, slot = GW - 1 - (N - 2) % GW;                // groups end on multiples of GW of the step index (the writer's whole lines)
         for (int i = N - 2; i >= 0; --i) {
-            const double rcn = rc_load(i > 0 ? i - 1 : 0);       // next step's gradient entry: a whole step (~1.5 us) ahead of its use
+            const double rc4 = EXP == 3 ? 0.001 : rc_at(i - 4);
             double *rec = rw + slot * SLOT;
             // ================= P1: w = Vxx·F[:,j],  q = c + F[:,j]'Vx ==================================
             double w[n], qj = 0.0;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(DDP_WAVE * (NCW + NWW)) void back_pass_dppw_kernel(
                 for (int r = 0; r < n; ++r) rec[n * j + r] = Vcol[r];
             }
             vj = vx;
-            rc = rcn;
+            rc = rc1; rc1 = rc2; rc2 = rc3; rc3 = rc4;
             dpp_fence(Vcol);
             asm volatile("s_nop 1" : "+v"(vj));
             if (++slot == GW) {                                          // the group is complete (i is a multiple of GW)
@@ -493,6 +496,7 @@ int ddp_launch_back_pass_dppw(ddp_handle h, const ddp_bp_desc *d, const double *
     const int exp = exp_env ? atoi(exp_env) : 0;
     if (exp == 1) hipLaunchKernelGGL((back_pass_dppw_kernel<10, 2, 1>), grid, block, 0, h->stream, a);
     else if (exp == 2) hipLaunchKernelGGL((back_pass_dppw_kernel<10, 2, 2>), grid, block, 0, h->stream, a);
+    else if (exp == 3) hipLaunchKernelGGL((back_pass_dppw_kernel<10, 2, 3>), grid, block, 0, h->stream, a);
     else hipLaunchKernelGGL((back_pass_dppw_kernel<10, 2, 0>), grid, block, 0, h->stream, a);
     DDP_HIP(hipGetLastError());
     return 0;

@@ -100,8 +100,13 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     const bool act = valid && !(a.active && a.active[b] == 0);
     if (!__any(act)) return;                                    // every rollout of this wave belongs to a finished trajectory
     const double alpha = a.alpha[ai];
-    const bool inx = j < n, inu = j < m;
-    const int jx = inx ? j : 0, ju = inu ? j : 0;
+    // FAST, LQ: the idle lanes n+m .. 15 of a row MIRROR lanes 0 .. : same row of A and B, same loads, same x̂, same store to the same
+    // address — every lane stores every step without an exec mask, and nobody writes to a shared dump address (with a machine-filling
+    // batch 8 192 waves storing their idle lanes to ONE line made the rollout 9 % slower than the masked variant).  Their cost weight is 0.
+    constexpr bool MIR = FAST && KIND == DDP_PROBLEM_LQ;
+    const int jm = MIR ? j % (n + m) : j;
+    const bool inx = jm < n, inu = j < m;
+    const int jx = inx ? jm : 0, ju = inu ? j : 0;
 
     constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m;
     const double *ug = a.u + (size_t)m * N * b;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     double *co = nullptr;
     const int CL = pendk ? N + 1 : N;
     if (FUSE) {
-        if (inx) { cw = 0.5 * a.Q[jx + n * jx]; cg = pendk ? a.goal[jx & 3] : 0.0; }
+        if (j < n) { cw = 0.5 * a.Q[jx + n * jx]; cg = pendk ? a.goal[jx & 3] : 0.0; }
         else if (j < n + m) cw = 0.5 * a.R[(j - n) + m * (j - n)];
         co = a.cnew + (size_t)CL * ((size_t)b + (size_t)B * ai);
     }
@@ -163,15 +168,25 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
     };
 
     // one predicated store per step: lane j < n writes xnew[j,i], lanes n..n+m-1 write unew[j-n,i]
-    const bool st_u = j >= n && j < n + m;
+    const bool st_u = jm >= n && jm < n + m;
     const bool st_on = act && (inx || st_u);
-    double *st_base = (FAST && !st_on) ? a.sink + lane : (st_u ? uo + (j - n) : xo + jx);
+    double *st_base = (FAST && !st_on) ? a.sink + lane : (st_u ? uo + (jm - n) : xo + jx);
     const unsigned st_stride = (FAST && !st_on) ? 0u : (st_u ? m : n) * (unsigned)sizeof(double);
 
     // Loads are UNCONDITIONAL (clamped lane index): a load inside an exec-masked branch makes the compiler
     // drain all outstanding loads (s_waitcnt vmcnt(0)) at the join and would serialise the prefetch ring.
     struct Ops { double u[m], k[m], K[m], x; };                 // ū_i, k_i (row-uniform), K_i[:, j], x_i[j]
     auto fetch = [&](int i, Ops &o) {
+        if constexpr (FAST && POLICY && m == 2) {
+            // ū_i, k_i, K_i[:, j] as ONE 16-byte load each (the launcher has checked the alignment): 4 instead of 7 vector-memory
+            // instructions per step — with a machine-filling batch the rollout is bound by the address unit its four SIMDs share
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            const d2v uv = *(const d2v *)(ug + (size_t)m * i), kv = *(const d2v *)(kg + (size_t)m * i),
+                      Kv = *(const d2v *)(Kg + nm * i + m * jx);
+            o.u[0] = uv.x; o.u[1] = uv.y; o.k[0] = kv.x; o.k[1] = kv.y; o.K[0] = Kv.x; o.K[1] = Kv.y;
+            o.x = xg[(size_t)n * i + jx];
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < m; ++q) o.u[q] = ug[(size_t)m * i + q];
         if (POLICY) {
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
         {
             double v = xh;
 #pragma unroll
-            for (int q = 0; q < m; ++q) v = (j == n + q) ? uu[q] : v;
+            for (int q = 0; q < m; ++q) v = (jm == n + q) ? uu[q] : v;
             if (FAST || st_on) *(double *)((char *)st_base + (size_t)i * st_stride) = v;
             if (FUSE) {
                 const double dv = pendk ? v - cg : v;
@@ -685,7 +700,8 @@ int launch_dpp(ddp_handle h, const FDArgs &a)
     const int gpw = DDP_WAVE / 16;
     const dim3 grid((unsigned)((total + gpw - 1) / gpw)), block(DDP_WAVE);
     const char *fv = getenv("DDP_FORWARD_FAST");                // 0: the variant with the run-time dyn_tv test and masked stores (A/B, tests)
-    if (a.has_policy && !a.dyn_tv && a.sink && !(fv && fv[0] == '0')) {
+    const bool al16 = MS != 2 || ((((uintptr_t)a.u | (uintptr_t)a.k | (uintptr_t)a.K) & 15) == 0);     // 16-byte loads of ū_i, k_i, K_i[:, j]
+    if (a.has_policy && !a.dyn_tv && a.sink && al16 && !(fv && fv[0] == '0')) {
         if (a.has_lims) hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, true, FUSE, true>), grid, block, 0, h->stream, a);
         else hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, false, FUSE, true>), grid, block, 0, h->stream, a);
         DDP_HIP(hipGetLastError());
