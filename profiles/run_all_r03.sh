@@ -13,3 +13,7 @@ tail -30 gpurun_out/r03_run_profile.log | cut -c1-300
 for c in c3 c2tv c4 c5; do cat gpurun_out/r03_$c/summary.txt | tail -60; done
 cat gpurun_out/r03_c4_lims.json
 cat gpurun_out/r03_solves.txt
+# machine-filling batch: removal experiments of back_pass_dppw and the batch cross-over of the three LTI backward kernels
+bash profiles/ab_dppw_exp.sh > gpurun_out/r03_fill_dppw_exp.txt 2>&1
+bash profiles/ab_fill_crossover.sh > gpurun_out/r03_fill_crossover.txt 2>&1
+cat gpurun_out/r03_fill_dppw_exp.txt gpurun_out/r03_fill_crossover.txt
