@@ -72,7 +72,8 @@ def one_case(ddp, oc, rng, case):
     if c["impl"]:
         os.environ["DDP_BACKPASS"] = c["impl"]
     # the work-group pipelines of round 3 (back_pass_mx2: chain + writer wave; forward_pass_pipe) forced on / off / as dispatched
-    for var, pick in (("DDP_MX2", case % 3), ("DDP_FORWARD_PIPE", (case // 3) % 3)):
+    # back_pass_dppw (row kernel + write-back waves, default only from B = 6 144) forced on / off; the rollout's FAST variant (mirrored idle lanes) off / as dispatched
+    for var, pick in (("DDP_MX2", case % 3), ("DDP_FORWARD_PIPE", (case // 3) % 3), ("DDP_DPPW", (case // 2) % 3), ("DDP_FORWARD_FAST", 2 * ((case // 5) % 2))):
         os.environ.pop(var, None)
         if pick < 2:
             os.environ[var] = str(pick)
@@ -101,7 +102,8 @@ def one_case(ddp, oc, rng, case):
                 e = relerr(got, ref)
                 worst = max(worst, e)
                 assert e < RTOL, (name, e, tag, "trajectory %d" % b)
-    os.environ.pop("DDP_MX2", None); os.environ.pop("DDP_FORWARD_PIPE", None)
+    for var in ("DDP_MX2", "DDP_FORWARD_PIPE", "DDP_DPPW", "DDP_FORWARD_FAST"):
+        os.environ.pop(var, None)
     return worst
 
 

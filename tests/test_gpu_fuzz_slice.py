@@ -1,5 +1,5 @@
 """A bounded, seeded slice of the randomised GPU-vs-oracle sweep (tests/fuzz_gpu_parity.py) inside `-m gpu`, so that the driver's
-GPU run exercises random shapes, operand layouts, forced kernels (DDP_BACKPASS, DDP_MX2, DDP_FORWARD_PIPE), limits, divergences and
+GPU run exercises random shapes, operand layouts, forced kernels (DDP_BACKPASS, DDP_MX2, DDP_FORWARD_PIPE, DDP_DPPW, DDP_FORWARD_FAST), limits, divergences and
 odd horizons every round — not only when somebody runs the sweep by hand.  ~2 500 cases (under a minute); every case is reproducible on its own
 (`python tests/fuzz_gpu_parity.py --cond 31 <case>` shows its conditioning)."""
 import importlib.util
@@ -26,7 +26,7 @@ def fz():
 
 @pytest.fixture(autouse=True)
 def _clean_env():
-    keys = ("DDP_BACKPASS", "DDP_MX2", "DDP_FORWARD_PIPE", "DDP_FORWARD", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND")
+    keys = ("DDP_BACKPASS", "DDP_MX2", "DDP_FORWARD_PIPE", "DDP_FORWARD", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND", "DDP_DPPW", "DDP_FORWARD_FAST")
     old = {k: os.environ.get(k) for k in keys}
     yield
     for k, v in old.items():
