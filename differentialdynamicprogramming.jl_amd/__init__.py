@@ -28,7 +28,7 @@ from . import _lib
 from ._lib import DDPError, Handle, default_handle  # noqa: F401
 
 __all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing", "mpc_shift", "demo_linear", "demo_pendcart",
-           "df", "Handle", "DDPError", "DEFAULT_ALPHA"]
+           "df", "Handle", "DDPError", "DEFAULT_ALPHA", "WrappedDiff"]
 
 DEFAULT_ALPHA = 10.0 ** np.linspace(0, -3, 11)     # iLQG.jl:145
 
@@ -95,11 +95,46 @@ class PendcartProblem:
     dyn_batched = False
 
 
+class WrappedDiff:
+    """What stands in for a user ``diff_fun`` (forward_pass.jl:5,19; iLQG.jl:156): subtraction with the listed state coordinates
+    (0-based) wrapped to [-π, π], i.e. ``rem2pi(a[j] - b[j], RoundNearest)`` — ddp_problem::diff_wrap.  ``None`` / ``np.subtract``
+    mean the reference's default ``-``.  A Python closure cannot run on the device."""
+
+    def __init__(self, *coords):
+        self.coords = tuple(int(c) for c in coords)
+        if any(c < 0 or c >= 32 for c in self.coords):
+            raise ValueError("WrappedDiff: coordinates must be in 0..31")
+
+    @property
+    def mask(self):
+        m = 0
+        for c in self.coords:
+            m |= 1 << c
+        return m
+
+    def __call__(self, a, b):                                   # the same function on host arrays
+        d = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)
+        for c in self.coords:
+            d[c] = np.remainder(d[c] + np.pi, 2 * np.pi) - np.pi
+        return d
+
+
+def _diff_mask(diff, n):
+    if diff is None or diff is np.subtract:
+        return 0
+    if isinstance(diff, WrappedDiff):
+        if any(c >= n for c in diff.coords):
+            raise ValueError("WrappedDiff names coordinate %d of a state of length %d" % (max(diff.coords), n))
+        return diff.mask
+    raise TypeError("diff_fun must be None / np.subtract (the reference's `-`) or a WrappedDiff: a Python closure cannot run on the device")
+
+
 class _DevProblem:
     """ddp_problem struct + the arrays it points at (host arrays for the host-pointer flavours)."""
 
-    def __init__(self, prob, N, B):
+    def __init__(self, prob, N, B, diff=None):
         P = _lib.Problem()
+        P.diff_wrap = _diff_mask(diff, prob.n)
         P.kind, P.n, P.m, P.N, P.B = prob.kind, prob.n, prob.m, N, B
         self.Q, self.R = _lib.f64(prob.Q), _lib.f64(np.atleast_2d(prob.R))
         P.Q, P.R = _lib.ptr(self.Q), _lib.ptr(self.R)
@@ -273,9 +308,9 @@ def _check_problem(problem, n, m, N, B):
 
 
 # ------------------------------------------------------------------------------- forward_pass
-def forward_pass(traj_new, x0, u, x, α, problem, lims, *, handle=None):
+def forward_pass(traj_new, x0, u, x, α, problem, lims, diff=None, *, handle=None):
     """Drop-in for ``forward_pass(traj_new,x0,u,x,α,f,costfun,lims,diff)`` (forward_pass.jl:9) with a
-    registered ``problem`` standing in for the closures ``f``/``costfun`` (``diff`` is ``-``).
+    registered ``problem`` standing in for the closures ``f``/``costfun``; ``diff``: ``None`` (``-``) or a ``WrappedDiff``.
     ``traj_new`` may be an empty ``GaussianPolicy`` (then ``x`` is ignored, iLQG.jl:185).
     A vector ``α`` rolls all step sizes out concurrently (outputs get a trailing α axis).
     Returns ``(xnew, unew, cnew)``."""
@@ -285,7 +320,7 @@ def forward_pass(traj_new, x0, u, x, α, problem, lims, *, handle=None):
     m, N = u.shape[:2]
     n = x0.shape[0]
     B = u.shape[2] if batched else 1
-    dp = _DevProblem(problem, N, B)
+    dp = _DevProblem(problem, N, B, diff)
     if x0.shape != ((n, B) if batched else (n,)) and not (not batched and x0.shape == (n, 1)):
         raise ValueError("x0 should be (n,) — (n, B) with a batched u")
     _check_problem(problem, n, m, N, B)
@@ -361,9 +396,9 @@ STATUS = {1: "SUCCESS: gradient norm < tol_grad", 2: "SUCCESS: cost change < tol
 
 def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0,
          λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0, verbosity=0, trace_cap=None, cost=None,
-         timing=True, handle=None):
+         timing=True, diff_fun=None, handle=None):
     """Drop-in for ``iLQG(f,costfun,df,x0,u0; lims, α, tol_fun, ...)`` (iLQG.jl:143-163) with a registered
-    ``problem`` standing in for the three closures.  ``u0[m,N,B]`` / ``x0[n,B]`` solve a batch of
+    ``problem`` standing in for the three closures (``diff_fun``: ``None`` = ``-``, or a ``WrappedDiff``).  ``u0[m,N,B]`` / ``x0[n,B]`` solve a batch of
     independent problems, each with its own λ schedule, line search and termination.
     Returns ``(x, u, traj_new, Vx, Vxx, cost, trace)``; ``trace`` is a dict with the reference's trace
     keys that survive batching (``:cost`` per iteration) plus the per-trajectory summary ``stats``.
@@ -392,7 +427,7 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
     if x0.shape != (((n, N) if prerolled else (n,)) + ((B,) if batched else ())):
         raise ValueError("x0 should be (n,) / pre-rolled (n, N) — with a batched u0: (n, B) / (n, N, B)")
     _check_problem(problem, n, m, N, B)
-    dp = _DevProblem(problem, N, B)
+    dp = _DevProblem(problem, N, B, diff_fun)
     o = _lib.ILQGOpts()
     _lib.lib().ddp_ilqg_default_opts(_C.byref(o))
     o.lambda_, o.dlambda, o.lambda_factor, o.lambda_max, o.lambda_min = λ, dλ, λfactor, λmax, λmin

@@ -55,7 +55,7 @@ class Problem(C.Structure):
     _fields_ = [("kind", C.c_int), ("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("B", C.c_int),
                 ("A", vp), ("Bm", vp), ("dyn_tv", C.c_int), ("dyn_batched", C.c_int), ("Q", vp), ("R", vp),
                 ("g", C.c_double), ("l", C.c_double), ("h", C.c_double), ("d", C.c_double),
-                ("goal", C.c_double * 4), ("cost_diag", C.c_int)]
+                ("goal", C.c_double * 4), ("cost_diag", C.c_int), ("diff_wrap", C.c_uint32)]
 
 
 class ILQGOpts(C.Structure):

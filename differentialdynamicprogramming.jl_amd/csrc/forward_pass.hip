@@ -22,12 +22,21 @@ namespace {
 struct FPArgs {
     int n, m, N, B, nalpha;
     int dyn_tv, dyn_batched, has_policy, has_lims;
+    unsigned wrap;                                  // ddp_problem::diff_wrap
     const double *A, *Bm, *Q, *R, *K, *k, *x0, *u, *x, *lims;
     const int32_t *active;
     double alpha[16];
     double g, l, h, d, goal[4];
     double *xnew, *unew, *cnew, *csum;
 };
+
+// diff_fun for an angle coordinate (ddp_amd.h, ddp_problem::diff_wrap): d - 2π·rint(d / 2π) with 2π in two parts, so that the result is
+// within an ulp of rem2pi(d, RoundNearest) for every difference a rollout can produce
+__device__ __forceinline__ double wrap_pi(double d)
+{
+    const double q = rint(d * 0x1.45f306dc9c883p-3);                       // 1 / 2π
+    return fma(-q, 0x1.1a62633145c07p-52, fma(-q, 0x1.921fb54442d18p+2, d));   // 2π = 0x1.921fb54442d18p+2 + 0x1.1a62633145c07p-52
+}
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
@@ -149,10 +158,20 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pass_kernel(FPArgs a)
             if (a.has_policy) {
                 v += kn[q] * alpha;                                  // unew .+= k*α
                 double s = 0.0;
+                if (a.wrap == 0) {                                   // diff_fun = `-` (wave-uniform: the default pays nothing for the hook)
 #pragma unroll
-                for (int l = 0; l < NMAX; ++l) {
-                    if (PF) s += Kn[q + MM * l] * (xv[l] - xn_[l]);
-                    else if (l < n && q < m) s += Kg[nm * i + q + m * l] * (xv[l] - xg[(size_t)n * i + l]);
+                    for (int l = 0; l < NMAX; ++l) {
+                        if (PF) s += Kn[q + MM * l] * (xv[l] - xn_[l]);
+                        else if (l < n && q < m) s += Kg[nm * i + q + m * l] * (xv[l] - xg[(size_t)n * i + l]);
+                    }
+                } else {
+#pragma unroll
+                    for (int l = 0; l < NMAX; ++l) {
+                        if (!(PF || (l < n && q < m))) continue;
+                        double dxl = PF ? xv[l] - xn_[l] : xv[l] - xg[(size_t)n * i + l];
+                        if ((a.wrap >> l) & 1u) dxl = wrap_pi(dxl);
+                        s += (PF ? Kn[q + MM * l] : Kg[nm * i + q + m * l]) * dxl;
+                    }
                 }
                 v += s;                                              // unew .+= K*dx
             }
@@ -244,14 +263,17 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     // the trailing field of ddp_problem (library 0.2.0): a caller built against the older layout, or one that does not zero the struct,
     // hands over garbage here — anything but 0 / 1 is refused instead of silently selecting the diagonal-cost rollout
     DDP_CHECK(p->cost_diag == 0 || p->cost_diag == 1, "forward_pass: ddp_problem.cost_diag = %d (0 or 1; zero-initialise the struct)", p->cost_diag);
-    if (p->n > DDP_MAX_N_GENERIC || (getenv("DDP_FORWARD") && getenv("DDP_FORWARD")[0] == 'b')) {   // large states
+    // diff_fun with wrapped coordinates: only the run-time-sized kernel below implements it
+    DDP_CHECK(p->diff_wrap == 0 || (p->n <= DDP_MAX_N_GENERIC && (p->n >= 32 || (p->diff_wrap >> p->n) == 0)),
+              "forward_pass: ddp_problem.diff_wrap = 0x%x needs n <= %d and no bits at or above n = %d (zero-initialise the struct)", p->diff_wrap, DDP_MAX_N_GENERIC, p->n);
+    if (p->n > DDP_MAX_N_GENERIC || (p->diff_wrap == 0 && getenv("DDP_FORWARD") && getenv("DDP_FORWARD")[0] == 'b')) {   // large states
         const int rc = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rc <= 0) return rc;
         DDP_CHECK(p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d has no kernel", p->n, p->m);
     }
     // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
     const char *fwd_env = getenv("DDP_FORWARD");               // read per call so tests can switch paths
-    const bool force_group = fwd_env && fwd_env[0] == 103;
+    const bool force_group = (fwd_env && fwd_env[0] == 103) || p->diff_wrap != 0;
     if (!force_group) {
         const int rp = ddp_launch_forward_pipe(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rp <= 0) return rp;
@@ -261,6 +283,7 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     FPArgs a;
     a.n = p->n; a.m = p->m; a.N = p->N; a.B = p->B; a.nalpha = nalpha;
     a.dyn_tv = p->dyn_tv; a.dyn_batched = p->dyn_batched; a.has_policy = K != nullptr; a.has_lims = lims != nullptr;
+    a.wrap = p->diff_wrap;
     a.A = p->A; a.Bm = p->Bm; a.Q = p->Q; a.R = p->R; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.lims = lims;
     a.active = active;
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;

@@ -64,6 +64,7 @@ struct CProblem
     d::Cdouble
     goal::NTuple{4,Cdouble}
     cost_diag::Cint
+    diff_wrap::Cuint
 end
 
 struct ILQGOpts
@@ -201,11 +202,31 @@ cost_len(::LQProblem, N) = N
 cost_len(::PendcartProblem, N) = N + 1
 dyn_tv(p::LQProblem) = (ndims(p.A) - (p.dyn_batched ? 1 : 0)) == 3
 
+"""
+    WrappedDiff(coords...)
+
+What stands in for a user `diff_fun` (src/forward_pass.jl:5,19; iLQG.jl:156) on the device: subtraction with the listed state coordinates
+(1-based) wrapped to [-π, π], `rem2pi(a[j] - b[j], RoundNearest)` — `ddp_problem::diff_wrap`.  It is callable, so the same object can be
+handed to the reference's own `forward_pass`.  A Julia closure cannot cross the C ABI: any `diff_fun` other than `-` and a `WrappedDiff`
+is refused.
+"""
+struct WrappedDiff
+    coords::Vector{Int}
+    WrappedDiff(coords::Integer...) = (all(c -> 1 <= c <= 32, coords) || error("WrappedDiff: coordinates must be in 1..32"); new(collect(Int, coords)))
+end
+(w::WrappedDiff)(a, b) = (d = a - b; for c in w.coords; d[c] = rem2pi(d[c], RoundNearest); end; d)
+_diff_mask(::typeof(-), n) = Cuint(0)
+_diff_mask(w::WrappedDiff, n) = (all(c -> c <= n, w.coords) || error("WrappedDiff names a coordinate beyond the state length $n");
+                                 reduce(|, (Cuint(1) << (c - 1) for c in w.coords); init=Cuint(0)))
+_diff_mask(f, n) = error("diff_fun must be `-` or a DDPAmd.WrappedDiff: a Julia closure cannot run on the device")
+
 # C view of a problem; `A`, `Bm`, `Q`, `R` are host or device pointers depending on the entry point it is passed to
-cproblem(p::LQProblem, N, B; A=pointer(p.A), Bm=pointer(p.B), Q=pointer(p.Q), R=pointer(p.R)) =
-    CProblem(0, size(p.A, 1), size(p.B, 2), N, B, A, Bm, dyn_tv(p), p.dyn_batched, Q, R, 0.0, 0.0, 0.0, 0.0, (0.0, 0.0, 0.0, 0.0), isdiag(p.Q) && isdiag(p.R))
-cproblem(p::PendcartProblem, N, B; A=NULLF, Bm=NULLF, Q=pointer(p.Q), R=pointer(p.R)) =
-    CProblem(1, 4, 1, N, B, A, Bm, 0, 0, Q, R, p.g, p.l, p.h, p.d, (p.goal[1], p.goal[2], p.goal[3], p.goal[4]), isdiag(p.Q) && isdiag(p.R))
+cproblem(p::LQProblem, N, B; A=pointer(p.A), Bm=pointer(p.B), Q=pointer(p.Q), R=pointer(p.R), diff=-) =
+    CProblem(0, size(p.A, 1), size(p.B, 2), N, B, A, Bm, dyn_tv(p), p.dyn_batched, Q, R, 0.0, 0.0, 0.0, 0.0, (0.0, 0.0, 0.0, 0.0), isdiag(p.Q) && isdiag(p.R),
+             _diff_mask(diff, size(p.A, 1)))
+cproblem(p::PendcartProblem, N, B; A=NULLF, Bm=NULLF, Q=pointer(p.Q), R=pointer(p.R), diff=-) =
+    CProblem(1, 4, 1, N, B, A, Bm, 0, 0, Q, R, p.g, p.l, p.h, p.d, (p.goal[1], p.goal[2], p.goal[3], p.goal[4]), isdiag(p.Q) && isdiag(p.R),
+             _diff_mask(diff, 4))
 
 _f64(a) = Array{Float64}(a)      # dense column-major copy (handles Diagonal cxx, Vector cuu of the demos)
 _lims(lims) = (lims === nothing || isempty(lims)) ? Float64[] : _f64(lims)
@@ -283,15 +304,15 @@ end
 """
     forward_pass(traj_new, x0, u, x, α, problem, lims) -> xnew, unew, cnew
 
-`problem` (LQProblem / PendcartProblem) replaces the closures `f`, `costfun` of src/forward_pass.jl:9; `diff` is `-`.
+`problem` (LQProblem / PendcartProblem) replaces the closures `f`, `costfun` of src/forward_pass.jl:9; `diff` is `-` or a `WrappedDiff`.
 `u[m,N,B]` with `x0[n,B]` rolls a batch out; a vector `α` rolls all step sizes out concurrently (trailing α axis).
 """
-function forward_pass(traj_new, x0, u, x, α, problem::RegisteredProblem, lims; handle::Handle=default_handle())
+function forward_pass(traj_new, x0, u, x, α, problem::RegisteredProblem, lims, diff=-; handle::Handle=default_handle())
     batched = ndims(u) == 3
     m, N = size(u, 1), size(u, 2)
     n = size(x0, 1)
     B = batched ? size(u, 3) : 1
-    P = cproblem(problem, N, B)
+    P = cproblem(problem, N, B; diff=diff)
     CL = cost_len(problem, N)
     empty = _isempty_policy(traj_new)
     al = α isa Number ? [Float64(α)] : _f64(α)
@@ -366,7 +387,7 @@ function iLQG(problem::RegisteredProblem, x0, u0; lims=[], α=DEFAULT_ALPHA, tol
     if !prerolled && ndims(x0) == (batched ? 3 : 2) && !(ndims(x0) == 2 && batched)
         size(x0, 2) == 1 || error("pre-rolled initial trajectory must be of correct length (size(x0,2) == N)")   # iLQG.jl:199
     end
-    P = cproblem(problem, N, B)
+    P = cproblem(problem, N, B; diff=diff_fun)
     CL = cost_len(problem, N)
     o = _opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
     bt = batched ? (B,) : ()
@@ -680,7 +701,7 @@ closures, `fx_model[n,n,N(,B)]` / `R1[n,n]` are what `df(model,·)` / `covarianc
 :cost, :improvement, :expected_reduction, :grad_norm, :dV.  `traj_prev.k` is left untouched (the reference zeroes and restores it, :51,247).
 """
 function iLQGkl(problem::RegisteredProblem, x0, traj_prev, fx_model, R1; kl_step=1.0, lims=[], max_iter=50, cost=[],
-                ηbracket=[1e-8, 1.0, 1e16], del0=1e-4, constrain_per_step=false, handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
+                ηbracket=[1e-8, 1.0, 1e16], del0=1e-4, constrain_per_step=false, diff_fun=-, handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
     constrain_per_step && error("constrain_per_step (iLQGkl.jl:180-232) is not offloaded (it cannot run upstream either: klutils.jl:195)")
     isempty(cost) && error("Initial trajectory supplied, initial cost must also be supplied")                 # :69
     batched = ndims(x0) == 3
@@ -689,7 +710,7 @@ function iLQGkl(problem::RegisteredProblem, x0, traj_prev, fx_model, R1; kl_step
     m = size(u0, 1)
     size(u0, 2) == N || error("pre-rolled initial trajectory must be of correct length (size(x0,2) == N)")     # :72
     B = batched ? size(x0, 3) : 1
-    P = cproblem(problem, N, B)
+    P = cproblem(problem, N, B; diff=diff_fun)
     CL = cost_len(problem, N)
     x0 = _f64(x0); Kp = _f64(traj_prev.K); Sp = _f64(traj_prev.Σ); Sip = _f64(traj_prev.Σi); fxm = _f64(fx_model); R1 = _f64(R1)
     c0 = batched ? (ndims(cost) == 2 ? vec(sum(cost, dims=1)) : _f64(vec(cost))) : [Float64(sum(cost))]      # only sum(cost) enters (:74,135)

@@ -168,7 +168,7 @@ def calc_η(xnew, xold, sigmanew, ηbracket, traj_new, traj_prev, kl_step, *, ha
 
 
 def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50, cost=None, ηbracket=(1e-8, 1.0, 1e16),
-           del0=1e-4, constrain_per_step=False, handle=None):
+           del0=1e-4, constrain_per_step=False, diff_fun=None, handle=None):
     """``iLQGkl(dynamics,costfun,derivs,x0,traj_prev,model; kl_step, lims, max_iter, cost, ηbracket, del0)`` with a registered
     ``problem`` standing in for the three closures (single KL constraint, iLQGkl.jl:91-178).  ``x0[n,N(,B)]`` is the
     pre-rolled trajectory (the reference errors otherwise, :71-72) and ``cost`` its cost (:69).
@@ -194,7 +194,7 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
     del0 = np.full(B, float(del0))
     import os as _os
     if _os.environ.get("DDP_KL_HOSTLOOP") != "1":
-        return _ilqgkl_call(h, problem, model, prev0, lims, kl_step, max_iter, x, u, cost, etab, float(del0[0]), batched)
+        return _ilqgkl_call(h, problem, model, prev0, lims, kl_step, max_iter, x, u, cost, etab, float(del0[0]), batched, diff_fun)
     # ---- DDP_KL_HOSTLOOP=1: the loop of the reference on host arrays, one library call per array operation (cross-check in the tests)
     # STEP 1 (:86): the KL demos hand 3-D arrays to back_pass_gps (demo_linear.jl:91-101)
     fx, fu, _, _, _, cx, cu, cxx, cxu, cuu = df(problem, x, u, handle=h)
@@ -246,7 +246,7 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
         sel = (lambda a: a) if allB else (lambda a: a[..., idx])                                                # noqa: E731
         pb = problem if allB else _SubProblem(problem, idx, B)
         xs = sel(x)
-        xnew, unew, cnew = forward_pass(new, xs[:, 0, :], sel(u), xs, 1.0, pb, lims, handle=h)                  # :132
+        xnew, unew, cnew = forward_pass(new, xs[:, 0, :], sel(u), xs, 1.0, pb, lims, diff_fun, handle=h)                  # :132
         mdl = Model(model.fx if (np.ndim(model.fx) == 3 or allB) else model.fx[..., idx], model.fu, model.R1)
         sig = forward_covariance(mdl, xs, sel(u), new, handle=h)                                                # :133
         pv = prev0 if allB else GaussianPolicy(N, n, m, sel(prev0.K), sel(prev0.k), sel(prev0.Σ), sel(prev0.Σi))
@@ -281,11 +281,11 @@ def iLQGkl(problem, x0, traj_prev, model, *, kl_step=1.0, lims=None, max_iter=50
 
 
 
-def _ilqgkl_call(h, problem, model, prev0, lims, kl_step, max_iter, x, u, cost, etab, del0, batched):
+def _ilqgkl_call(h, problem, model, prev0, lims, kl_step, max_iter, x, u, cost, etab, del0, batched, diff_fun=None):
     """the whole loop of iLQGkl (iLQGkl.jl:91-178) as ONE library call: ``ddp_ilqgkl_f64`` (csrc/kl.hip)"""
     n, N, B = x.shape
     m = u.shape[0]
-    dp = _DevProblem(problem, N, B)
+    dp = _DevProblem(problem, N, B, diff_fun)
     CL = dp.cost_len
     c0 = np.asarray(cost, dtype=np.float64)                                                      # only sum(cost) enters (:74,135)
     c0 = (c0.sum(axis=0) if c0.ndim == 2 else c0.reshape(-1)) if batched else np.array([c0.sum()])   # batch: [CL,B] per-step costs or [B] sums

@@ -148,6 +148,12 @@ typedef struct {
      * device memory in the _dev entry points): a wrong 1 gives the cost of diag(Q), diag(R).  Any other value is refused, so a struct that
      * was not zero-initialised — or a caller built against the 0.1.0 layout, which ended at goal[] — fails loudly.               */
     int cost_diag;
+    /* diff_fun (src/forward_pass.jl:19, iLQG.jl:160: `K*diff_fun(x̂, x)`; default `-`).  A closure cannot cross the C ABI; what stands in
+     * is subtraction with the coordinates named in this bit mask (bit j = state j, n <= 32) wrapped to [-π, π]:
+     *     d = x̂_j - x_j;  d - 2π·rint(d / 2π)        (Julia: rem2pi(x̂[j] - x[j], RoundNearest))
+     * — the usual reason the hook exists (angles).  0 = the reference's default.  Bits at or above n are refused (a struct that was not
+     * zero-initialised fails loudly); with a non-zero mask the rollout runs in the run-time-sized kernel (n <= 32).                 */
+    uint32_t diff_wrap;
 } ddp_problem;
 
 /* cost vector length per trajectory: LQ -> N, pendcart -> N+1 */

@@ -537,7 +537,7 @@ void ddp_oracle_df(const ddp_oracle_problem *p, const double *X, double *U,
 }
 
 /* ===================================================================================
- * forward_pass — src/forward_pass.jl:9-33  (diff == `-`)
+ * forward_pass — src/forward_pass.jl:9-33  (diff == `-`, or `-` with the coordinates of p->diff_wrap wrapped to [-pi, pi])
  * =================================================================================== */
 void ddp_oracle_forward_pass(const ddp_oracle_problem *p,
                              const double *K, const double *k,
@@ -556,8 +556,11 @@ void ddp_oracle_forward_pass(const ddp_oracle_problem *p,
             for (int a = 0; a < m; ++a) ui[a] += k[IDX2(a, i, m)] * alpha;
             for (int a = 0; a < m; ++a) {
                 double s = 0.0;
-                for (int j = 0; j < n; ++j)
-                    s += K[(size_t)m * n * i + IDX2(a, j, m)] * (xi[j] - x[IDX2(j, i, n)]);
+                for (int j = 0; j < n; ++j) {
+                    double dxj = xi[j] - x[IDX2(j, i, n)];                  /* :19 diff(xnew[:,i], x[:,i]) */
+                    if (j < 32 && ((p->diff_wrap >> j) & 1u)) dxj = remainder(dxj, 6.283185307179586);
+                    s += K[(size_t)m * n * i + IDX2(a, j, m)] * dxj;
+                }
                 ui[a] += s;
             }
         }

@@ -78,6 +78,9 @@ typedef struct {
     /* pendcart (src/system_pendcart.jl:51-54,83-106,137-154); n=4, m=1; Q,R as above */
     double g, l, h, d;
     double goal[4];
+    /* the `diff` argument of forward_pass (src/forward_pass.jl:9,19; iLQG.jl:160 `diff_fun = -`): 0 = `-`; bit j set = coordinate j of
+     * the difference wrapped to [-pi, pi] (what a caller with an angle state passes: rem2pi(a[j] - b[j], RoundNearest)) */
+    unsigned diff_wrap;
 } ddp_oracle_problem;
 
 /* number of entries of the cost vector returned by costfun: LQ -> N (per-step split of the

@@ -171,8 +171,20 @@ def back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, lims, x, u):
 
 
 # ----------------------------------------------------------------- forward_pass.jl:9-33
-def forward_pass(policy, x0, u, x, alpha, f, costfun, lims):
-    """policy: None (empty GaussianPolicy) or (K, k)."""
+def wrapped_diff(mask):
+    """the `diff` a caller with angle states passes: subtraction, coordinates in the bit mask wrapped to [-pi, pi]"""
+    sel = np.array([(mask >> j) & 1 for j in range(32)], bool)
+
+    def diff(a, b):
+        d = a - b
+        w = sel[: d.shape[0]]
+        d[w] = np.remainder(d[w] + np.pi, 2 * np.pi) - np.pi
+        return d
+    return diff
+
+
+def forward_pass(policy, x0, u, x, alpha, f, costfun, lims, diff=np.subtract):
+    """policy: None (empty GaussianPolicy) or (K, k); diff: forward_pass.jl:9 (iLQG.jl:160 passes `-`)."""
     n = x0.shape[0]
     m, N = u.shape
     xnew = np.empty((n, N))
@@ -182,7 +194,7 @@ def forward_pass(policy, x0, u, x, alpha, f, costfun, lims):
         if policy is not None:
             K, k = policy
             unew[:, i] += k[:, i] * alpha
-            dx = xnew[:, i] - x[:, i]
+            dx = diff(xnew[:, i], x[:, i])
             unew[:, i] += K[:, :, i] @ dx
         if lims is not None and np.size(lims) > 0:
             unew[:, i] = jl_clamp(unew[:, i], lims[:, 0], lims[:, 1])
@@ -199,7 +211,7 @@ DEFAULT_ALPHA = 10.0 ** np.linspace(0, -3, 11)
 
 def iLQG(f, costfun, df, x0, u0, lims=None, alpha=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4,
          max_iter=500, lam=1.0, dlam=1.0, lam_factor=1.6, lam_max=1e10, lam_min=1e-6, regType=1,
-         reduce_ratio_min=0.0):
+         reduce_ratio_min=0.0, diff_fun=np.subtract):
     n = x0.shape[0]
     m, N = u0.shape
     u = u0
@@ -244,7 +256,7 @@ def iLQG(f, costfun, df, x0, u0, lims=None, alpha=DEFAULT_ALPHA, tol_fun=1e-7, t
         a_used = np.nan
         if back_pass_done:
             for ai in alpha:
-                xnew, unew, costnew = forward_pass((K, k), x0, u, x, ai, f, costfun, lims)
+                xnew, unew, costnew = forward_pass((K, k), x0, u, x, ai, f, costfun, lims, diff_fun)
                 n_fp += 1
                 a_used = ai
                 dcost = np.sum(cost) - np.sum(costnew)

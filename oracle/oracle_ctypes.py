@@ -26,7 +26,7 @@ class Problem(C.Structure):
     _fields_ = [("kind", C.c_int), ("n", C.c_int), ("m", C.c_int), ("N", C.c_int),
                 ("A", dp), ("Bm", dp), ("dyn_tv", C.c_int), ("Q", dp), ("R", dp),
                 ("g", C.c_double), ("l", C.c_double), ("h", C.c_double), ("d", C.c_double),
-                ("goal", C.c_double * 4)]
+                ("goal", C.c_double * 4), ("diff_wrap", C.c_uint)]
 
 
 class ILQGOpts(C.Structure):
@@ -107,8 +107,9 @@ class _Keep:
     """keeps numpy buffers alive next to the ctypes struct that points at them"""
 
 
-def make_problem(kind, n, m, N, A=None, B=None, Q=None, R=None, pend=None):
+def make_problem(kind, n, m, N, A=None, B=None, Q=None, R=None, pend=None, diff_wrap=0):
     p = Problem()
+    p.diff_wrap = int(diff_wrap)
     keep = _Keep()
     p.kind = 0 if kind == "lq" else 1
     p.n, p.m, p.N = n, m, N

@@ -27,7 +27,7 @@ CTYPES = {
 }
 STRUCTS = {"ddp_bp_desc": "BPDesc", "ddp_qp_opts": "QPOpts", "ddp_problem": "CProblem", "ddp_ilqg_opts": "ILQGOpts",
            "ddp_kl_cost_terms": "KLCostTerms", "ddp_kl_dual": "KLDual", "ddp_ilqgkl_opts": "ILQGKLOpts"}
-FIELD = {"int": {"Cint"}, "double": {"Cdouble", "Float64"}, "const double *": {"Ptr{Float64}"}, "double *": {"Ptr{Float64}"},
+FIELD = {"int": {"Cint"}, "uint32_t": {"Cuint", "UInt32"}, "double": {"Cdouble", "Float64"}, "const double *": {"Ptr{Float64}"}, "double *": {"Ptr{Float64}"},
          "int32_t *": {"Ptr{Int32}"}}
 
 
