@@ -430,6 +430,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4p_kernel(Q4Args a)
 constexpr int Q4L_CH = 8;
 constexpr int Q4L_IN = 896;          // doubles per input buffer: fx [4 pieces][4 traj][32] | fu [4][32] | cx [4][32] | cu,u [4][32] (8 + 8 used)
 constexpr int Q4L_IFU = 512, Q4L_ICX = 640, Q4L_ICU = 768;
+// time-varying cost (CTV; back_pass_gps: the combined c̃xx, c̃xu, c̃uu of the prepass): cxx like fx [4 pieces][4 traj][32] | cxu [4][32] | cuu [4][32] (8 used)
+constexpr int Q4L_IXX = Q4L_IN, Q4L_IXU = Q4L_IXX + 512, Q4L_IUU = Q4L_IXU + 128, Q4L_INC = Q4L_IUU + 128;
 constexpr int Q4L_OK = 512;          // outputs: Vxx [4][4][32] | K [4][32] + dump 96 | Vx [4][32] + dump 96 | k,Quu [4][16] + dump 144
 constexpr int Q4L_KD = 224;          // distance K -> Vx block (the two offsets of one ds_write2_b64)
 constexpr int Q4L_OKQ = Q4L_OK + 2 * Q4L_KD, Q4L_OUT = Q4L_OKQ + 64 + 144;
@@ -437,11 +439,11 @@ constexpr int Q4L_OKQ = Q4L_OK + 2 * Q4L_KD, Q4L_OUT = Q4L_OKQ + 64 + 144;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <bool LIMS, bool REG2>
+template <bool LIMS, bool REG2, bool CTV = false, bool GPS = false>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
 {
     constexpr int n = 4, CH = Q4L_CH;
-    __shared__ __attribute__((aligned(16))) double lin[2][Q4L_IN];
+    __shared__ __attribute__((aligned(16))) double lin[2][CTV ? Q4L_INC : Q4L_IN];
     __shared__ __attribute__((aligned(16))) double lout[Q4L_OUT];
     const int N = a.N, NC = N / CH;
     const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3, q16 = 4 * r + c;
@@ -462,7 +464,15 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
 
     const double *gfx = a.fx + a.fx_b * bd + 2 * q, *gfu = a.fu + a.fu_b * bd + 2 * q, *gcx = a.cx + (size_t)n * N * bd + 2 * q;
     const double *gcu = ((LIMS && q >= 4) ? a.u : a.cu) + (size_t)N * bd + 2 * (q & 3);
+    const double *gxx = a.cxx + a.cxx_b * bd + 2 * q, *gxu = a.cxu + a.cxu_b * bd + 2 * q, *guu = a.cuu + a.cuu_b * bd + 2 * (q & 3);     // (CTV)
     auto dma = [&](int ch, double *in) {
+        if (CTV) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_global_load_lds((glb_void *)(gxx + (size_t)ch * (16 * CH) + 32 * j), (lds_void *)(in + Q4L_IXX + 128 * j), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(gxu + (size_t)ch * (4 * CH)), (lds_void *)(in + Q4L_IXU), 16, 0, 0);
+            if (q < 4) __builtin_amdgcn_global_load_lds((glb_void *)(guu + (size_t)ch * CH), (lds_void *)(in + Q4L_IUU), 16, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_global_load_lds((glb_void *)(gfx + (size_t)ch * (16 * CH) + 32 * j), (lds_void *)(in + 128 * j), 16, 0, 0);
@@ -490,11 +500,12 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
     };
 
     Q4Par par;
-    par.lam = a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true; par.ieta = 1.0;
+    par.lam = GPS ? 0.0 : a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;      // back_pass_gps: η is the only regularisation
+    par.ieta = GPS ? 1.0 / a.eta[b] : 1.0;
     if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }
     const double *cxx = a.cxx + a.cxx_b * b, *cuu = a.cuu + a.cuu_b * b, *cxu = a.cxu + a.cxu_b * b;
     Q4In cst;
-    cst.cxx = cxx[e]; cst.cxxT = cxx[et]; cst.cxuc = cxu[r]; cst.cxur = cxu[c]; cst.cuu = cuu[0];
+    cst.cxx = cxx[e]; cst.cxxT = cxx[et]; cst.cxuc = cxu[r]; cst.cxur = cxu[c]; cst.cuu = cuu[0];      // (time-invariant cost; CTV reads the image instead)
 
     // per-lane LDS offsets (doubles) of the compute side
     const int ofx = 32 * blk + e, ofu = Q4L_IFU + 32 * blk + r, ocu = Q4L_ICU + 32 * blk;
@@ -507,7 +518,14 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
         o.cx = in[ofu + (Q4L_ICX - Q4L_IFU) + 4 * sidx];
         o.cu = in[ocu + sidx];
         o.u = LIMS ? in[ocu + 8 + sidx] : 0.0;
-        o.cxx = cst.cxx; o.cxxT = cst.cxxT; o.cxuc = cst.cxuc; o.cxur = cst.cxur; o.cuu = cst.cuu;
+        if (CTV) {
+            const int st = 128 * (sidx >> 1) + 16 * (sidx & 1);
+            o.cxx = in[Q4L_IXX + 32 * blk + e + st]; o.cxxT = in[Q4L_IXX + 32 * blk + et + st];
+            o.cxuc = in[Q4L_IXU + 32 * blk + r + 4 * sidx]; o.cxur = in[Q4L_IXU + 32 * blk + c + 4 * sidx];
+            o.cuu = in[Q4L_IUU + 32 * blk + sidx];
+        } else {
+            o.cxx = cst.cxx; o.cxxT = cst.cxxT; o.cxuc = cst.cxuc; o.cxur = cst.cxur; o.cuu = cst.cuu;
+        }
     };
     auto writeout = [&](int sidx, const Q4Out &o) __attribute__((always_inline)) {
         wV[128 * (sidx >> 1) + 16 * (sidx & 1)] = o.Vn;
@@ -536,12 +554,14 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
             Q4Out o;
             if (sidx == CH - 1 && ch == NC - 1) {
                 // terminal step (backward_pass.jl:21-23 / :234-236), see back_pass_q4_kernel
-                s.V = cst.cxx; s.VT = cst.cxxT; s.vxc = in.cx;
-                o.Vn = s.V; o.Kc = 0.0; o.vx = in.cx; o.kk = 0.0; o.Quu = cst.cuu;
+                s.V = in.cxx; s.VT = in.cxxT; s.vxc = in.cx;
+                o.Vn = s.V; o.Kc = 0.0; o.vx = in.cx; o.kk = 0.0; o.Quu = in.cuu;
             } else if (sidx == CH - 1)
-                q4_step<LIMS, REG2, 0>(CH * ch + sidx, in, s, o, par);
-            else
-                q4_step<LIMS, REG2, 0>(CH * ch + sidx, in, s, o, par, [&]() __attribute__((always_inline)) { writeout(sidx + 1, prev); });
+                q4_step<LIMS, REG2, 0, Q4NoMid, GPS>(CH * ch + sidx, in, s, o, par);
+            else {
+                auto mid = [&]() __attribute__((always_inline)) { writeout(sidx + 1, prev); };
+                q4_step<LIMS, REG2, 0, decltype(mid), GPS>(CH * ch + sidx, in, s, o, par, mid);
+            }
             if (sidx == 0) { writeout(0, o); }
             prev = o;
             in = nx;
@@ -703,7 +723,15 @@ int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     a.eta = kl->eta; a.sink = (double *)h->sink;
     const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
-    if (d->has_lims) hipLaunchKernelGGL((back_pass_q4_kernel<true, true, false, 0, true>), grid, block, 0, h->stream, a);
+    // chunks of eight steps through the LDS (the q4l scheme, here with the time-varying c̃xx, c̃xu, c̃uu in the image): 13 direct-to-LDS loads
+    // and 7 stores per 8 steps instead of 10 + 2 vector-memory instructions per step.  DDP_GPS_Q4L=0: the one-step kernel (A/B, tests)
+    const char *le = getenv("DDP_GPS_Q4L");
+    const bool al16 = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx |
+                         (uintptr_t)(d->has_lims ? u : fx)) & 15) == 0);
+    const bool chunked = !(le && le[0] == '0') && d->N % Q4L_CH == 0 && d->N >= 2 * Q4L_CH && al16 && h->sink != nullptr && d->B <= 6144;
+    if (chunked && d->has_lims) hipLaunchKernelGGL((back_pass_q4l_kernel<true, false, true, true>), grid, block, 0, h->stream, a);
+    else if (chunked) hipLaunchKernelGGL((back_pass_q4l_kernel<false, false, true, true>), grid, block, 0, h->stream, a);
+    else if (d->has_lims) hipLaunchKernelGGL((back_pass_q4_kernel<true, true, false, 0, true>), grid, block, 0, h->stream, a);
     else hipLaunchKernelGGL((back_pass_q4_kernel<false, true, false, 0, true>), grid, block, 0, h->stream, a);
     hipLaunchKernelGGL(gps_quui_kernel, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, h->stream, d->N, NB, (const double *)Quu,
                        (const int32_t *)diverge, active, Quui);

@@ -90,14 +90,16 @@ def test_fcov_and_kl_div_fast_kernels_match_generic(ddp, monkeypatch, m):
         assert relerr(kld[:, b], kr) < RTOL, b
 
 
+@pytest.mark.parametrize("N", [37, 40])
 @pytest.mark.parametrize("lims", [False, True])
-def test_gps_q4_batch_matches_lane_kernel_and_oracle(ddp, monkeypatch, lims):
+def test_gps_q4_batch_matches_lane_kernel_and_oracle(ddp, monkeypatch, lims, N):
     """back_pass_gps for n = 4, m = 1 on the matrix-core kernel (prepass c̃ = c/η + c_kl, 1/η on the products with V): a ragged batch with
-    per-trajectory η, per-trajectory and shared cost Hessians, one trajectory failing — against the lane-per-trajectory kernel and the oracle"""
+    per-trajectory η, per-trajectory and shared cost Hessians, one trajectory failing — against the lane-per-trajectory kernel and the oracle.
+    N = 40 (a multiple of 8) takes the kernel that moves chunks of eight steps through the LDS: same bits as the one-step kernel"""
     from oracle import oracle_ctypes as oc
     kl = ddp.kl
     rng = np.random.default_rng(19)
-    n, m, N, B = 4, 1, 37, 6
+    n, m, B = 4, 1, 6
 
     def spd(d, s=1.0):
         a = rng.standard_normal((d, d)); return s * (a @ a.T / d + 0.5 * np.eye(d))
@@ -108,7 +110,9 @@ def test_gps_q4_batch_matches_lane_kernel_and_oracle(ddp, monkeypatch, lims):
     cx, cu, u, x = rng.standard_normal((n, N, B)), rng.standard_normal((m, N, B)), 0.3 * rng.standard_normal((m, N, B)), rng.standard_normal((n, N, B))
     Kp, kp = 0.2 * rng.standard_normal((m, n, N, B)), 0.1 * rng.standard_normal((m, N, B))
     Sip = 0.5 + rng.uniform(0, 2, (m, m, N, B)); Sp = 1.0 / Sip
-    etab = np.stack([1e-8 * np.ones(B), np.array([1.0, 0.5, 2.0, 1.0, 4.0, 0.25]), 1e16 * np.ones(B)])
+    # (η >= 0.9: with clamped controls the value recursion is Vxx <- fx'Vxx fx / η + ..., i.e. 0.81 / η per step — η = 0.25 grew Vxx to 7e9 in
+    # 20 steps and the QP's stopping tests then sit on rounding noise, see the remark on the dynamics above)
+    etab = np.stack([1e-8 * np.ones(B), np.array([1.0, 0.9, 2.0, 1.0, 4.0, 1.25]), 1e16 * np.ones(B)])
     terms = kl.grad_kl(ddp.GaussianPolicy(N, n, m, Kp, kp, Sp, Sip))
     L = np.array([[-0.3, 0.25]]) if lims else None
     for batched_cost in (True, False):
@@ -122,7 +126,13 @@ def test_gps_q4_batch_matches_lane_kernel_and_oracle(ddp, monkeypatch, lims):
         for mode in ("1", "0"):
             monkeypatch.setenv("DDP_GPS_Q4", mode)
             res[mode] = kl.back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, L, x, u, (terms, etab))
+        monkeypatch.setenv("DDP_GPS_Q4", "1"); monkeypatch.setenv("DDP_GPS_Q4L", "0")
+        ds, ps, vxs, vxxs, dvs = kl.back_pass_gps(cx, cu, cxx, cxu, cuu, fx, fu, L, x, u, (terms, etab))
+        monkeypatch.delenv("DDP_GPS_Q4L")
         (d1, p1, vx1, vxx1, dv1), (d0, p0, vx0, vxx0, dv0) = res["1"], res["0"]
+        assert np.array_equal(ds, d1)
+        for got, ref in ((ps.K, p1.K), (ps.k, p1.k), (ps.Σ, p1.Σ), (ps.Σi, p1.Σi), (vxs, vx1), (vxxs, vxx1), (dvs, dv1)):
+            assert np.array_equal(got, ref)                                      # chunked and one-step kernel: the same step function
         assert np.array_equal(d1, d0) and (not batched_cost or lims or d1[3] == 10)      # (with limits a clamped control skips the factorisation)
         for got, ref, nm in ((p1.K, p0.K, "K"), (p1.k, p0.k, "k"), (p1.Σ, p0.Σ, "Quui"), (p1.Σi, p0.Σi, "Quu"), (vx1, vx0, "Vx"), (vxx1, vxx0, "Vxx"),
                              (dv1, dv0, "dV")):
