@@ -7,6 +7,7 @@
 #include "arena.h"
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
 #include "ddp_internal.h"
 
 // back_pass_gps on the matrix-core kernel of back_pass_q4.hip (n = 4, m = 1, one η per trajectory); 1 = shape not handled there
@@ -315,6 +316,11 @@ __global__ __launch_bounds__(DDP_WAVE) void kl_div_kernel(int n, int m, int N, c
 // 25 loads of a step's sigmanew each touch 64 different lines, and the kernel above moved 7.0 GB for 0.93 GB of operands
 // (profiles/r03_c5_pmc.txt).  Per-step strides in the image are odd numbers of doubles (no bank conflicts).
 struct KlSrc { const double *g; int len; };
+template <int I, int E, class F>
+__device__ __forceinline__ void kl_static_for(F &&f)
+{
+    if constexpr (I < E) { f(std::integral_constant<int, I>{}); kl_static_for<I + 1, E>(f); }
+}
 template <int NC, int MC>
 __global__ __launch_bounds__(DDP_WAVE) void kl_div_lds_kernel(int n, int m, int N, KlSrc s0, KlSrc s1, KlSrc s2, KlSrc s3, KlSrc s4, KlSrc s5,
                                                               KlSrc s6, KlSrc s7, KlSrc s8, KlSrc s9, double *__restrict__ kldiv,
@@ -338,6 +344,38 @@ __global__ __launch_bounds__(DDP_WAVE) void kl_div_lds_kernel(int n, int m, int 
     int threw = 0;
     for (int t0 = 0; t0 < N; t0 += DDP_WAVE) {
         const int cnt = N - t0 < DDP_WAVE ? N - t0 : DDP_WAVE;
+        if constexpr (NC != 0) {
+            // compile-time sizes: ALL loads of the chunk are issued before the first LDS write (46 per lane at n = 4, m = 1) — one memory
+            // latency per chunk.  The run-time-sized loop below waits for every load before its LDS write: 46 latencies per chunk, 0.62 ms
+            // of the 0.62 ms this kernel took on the C5 shape.
+            constexpr int P_ = NC + MC;
+            constexpr int LEN[10] = {NC, NC, P_ * P_, NC * MC, MC, MC * MC, NC * MC, MC, MC * MC, MC * MC};
+            constexpr int TOT = LEN[0] + LEN[1] + LEN[2] + LEN[3] + LEN[4] + LEN[5] + LEN[6] + LEN[7] + LEN[8] + LEN[9];
+            double v[TOT];
+            int vi = 0;
+            kl_static_for<0, 10>([&](auto ac) {
+                constexpr int a = decltype(ac)::value, len = LEN[a];
+                const double *gp = src[a].g + (size_t)len * ((size_t)N * b + t0);
+                const int total = cnt * len;
+#pragma unroll
+                for (int k = 0; k < len; ++k) {
+                    const int g = k * DDP_WAVE + lane;
+                    v[vi + k] = gp[g < total ? g : total - 1];
+                }
+                vi += len;
+            });
+            vi = 0;
+            kl_static_for<0, 10>([&](auto ac) {
+                constexpr int a = decltype(ac)::value, len = LEN[a];
+                const int total = cnt * len;
+#pragma unroll
+                for (int k = 0; k < len; ++k) {
+                    const int g = k * DDP_WAVE + lane;
+                    if (g < total) klds[off[a] + (g / len) * (len | 1) + g % len] = v[vi + k];
+                }
+                vi += len;
+            });
+        } else {
 #pragma unroll
         for (int a = 0; a < 10; ++a) {
             const int len = src[a].len, total = cnt * len, dq = DDP_WAVE / len, dr = DDP_WAVE % len;
@@ -348,6 +386,7 @@ __global__ __launch_bounds__(DDP_WAVE) void kl_div_lds_kernel(int n, int m, int 
                 t += dq; e += dr;
                 if (e >= len) { e -= len; ++t; }
             }
+        }
         }
         wave_sync();
         if (lane < cnt) {
