@@ -210,6 +210,125 @@ __global__ __launch_bounds__(DDP_WAVE) void fcov_q4_kernel(int N, int B, const d
     *(double *)(q3 + (size_t)s3 * (unsigned)(N - 1)) = 0.0;
 }
 
+// ---- the same chain with CHUNKS OF EIGHT TIME STEPS THROUGH THE LDS (m = 1, N a multiple of 8; the scheme of back_pass_q4l_kernel): the kernel
+// above issues three 8-byte loads and three 8-byte stores per step — ~60 issue cycles each for the lone wave this batch gives a SIMD, 0.40 ms
+// for 0.9 GB.  Here six direct-to-LDS loads fetch fx (four pieces), K, Σ_policy of 8 steps x 4 trajectories a chunk ahead, the 25 entries of
+// sigmanew[:,:,i] are assembled as one record per step in the LDS and leave as 16-byte pieces that are contiguous across the lanes (seven
+// stores per chunk); per step the wave issues 3 LDS reads + 3 LDS writes (lanes without an entry read zeros / write to a dump area).
+constexpr int FQL_CH = 8, FQL_IK = 512, FQL_IS = 640, FQL_IN = 768;          // in: fx [4 pieces][4 traj][32] | K [4][32] | Σ_policy [4][32] (8 used)
+constexpr int FQL_REC = 25, FQL_OT = FQL_CH * FQL_REC, FQL_DUMP = 4 * FQL_OT, FQL_OUT = FQL_DUMP + 64 + FQL_REC * (FQL_CH - 1) + 1;
+typedef __attribute__((address_space(3))) void fq_lds_void;
+typedef const __attribute__((address_space(1))) void fq_glb_void;
+typedef double fq_d2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(DDP_WAVE) void fcov_q4l_kernel(int N, int B, const double *__restrict__ fx, int fx_batched,
+                                                            const double *__restrict__ R1, const double *__restrict__ K,
+                                                            const double *__restrict__ Sigma, double *__restrict__ out, double *__restrict__ sink)
+{
+    constexpr int n = 4, M = 1, CH = FQL_CH;
+    __shared__ __attribute__((aligned(16))) double lin[2][FQL_IN];
+    __shared__ __attribute__((aligned(16))) double lout[FQL_OUT];
+    __shared__ __attribute__((aligned(16))) double lzero[32];
+    const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3;
+    const int NC = N / CH;
+    if (lane < 32) lzero[lane] = 0.0;
+    auto mm = [](double a_, double b_, double c_) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0); };
+    // ---- global side: lane = (trajectory tl, 16-byte piece q) of the lane-linear image
+    const int tl = lane >> 4, q = lane & 15;
+    long tbd = (long)blockIdx.x * 4 + tl;
+    const bool validd = tbd < B;
+    if (!validd) tbd = B - 1;
+    const size_t bd = (size_t)tbd;
+    const double *gfx = fx + (fx_batched ? (size_t)n * n * N * bd : 0) + 2 * q, *gK = K + (size_t)n * N * bd + 2 * q;
+    const double *gS = Sigma + (size_t)N * bd + 2 * (q & 3);
+    auto dma = [&](int ch, double *in) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((fq_glb_void *)(gfx + (size_t)ch * (16 * CH) + 32 * j), (fq_lds_void *)(in + 128 * j), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((fq_glb_void *)(gK + (size_t)ch * (4 * CH)), (fq_lds_void *)(in + FQL_IK), 16, 0, 0);
+        if (q < 4) __builtin_amdgcn_global_load_lds((fq_glb_void *)(gS + (size_t)ch * CH), (fq_lds_void *)(in + FQL_IS), 16, 0, 0);
+    };
+    // results: 4 trajectories x 8 steps x 25 doubles = 400 16-byte pieces per chunk, piece idx = 64 pass + lane (the last pass repeats piece 399)
+    constexpr int NPS = (4 * FQL_OT / 2 + DDP_WAVE - 1) / DDP_WAVE;
+    int dl[NPS];
+    double *dg[NPS];
+    size_t dstep[NPS];
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+        const int idx0 = ps * DDP_WAVE + lane, idx = idx0 < 4 * FQL_OT / 2 ? idx0 : 4 * FQL_OT / 2 - 1;
+        const int t = idx / (FQL_OT / 2), pc = idx % (FQL_OT / 2);
+        const long tb = (long)blockIdx.x * 4 + t;
+        const bool on = tb < B;
+        dl[ps] = t * FQL_OT + 2 * pc;
+        dg[ps] = on ? out + (size_t)FQL_REC * N * (size_t)tb + 2 * pc : sink + 2 * lane;
+        dstep[ps] = on ? (size_t)FQL_OT : 0;
+    }
+    auto drain = [&](int ch) {
+        fq_d2 v[NPS];
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) v[ps] = *(const fq_d2 *)(lout + dl[ps]);
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) *(fq_d2 *)(dg[ps] + dstep[ps] * (size_t)ch) = v[ps];
+    };
+    // ---- compute side: per-lane LDS offsets (doubles); lanes without an operand read zeros, lanes without a result write to the dump area
+    const int ox = 32 * blk + c + n * r;                                                             // X1[r][c] = fx[c, r]
+    const bool hasK = c < 2 * M, hasS = r == M && c == M;
+    const double *kb = hasK ? nullptr : lzero, *sb = hasS ? nullptr : lzero;                         // (selected per buffer below)
+    const int okk = FQL_IK + 32 * blk + r, oss = FQL_IS + 32 * blk;
+    double *w1 = lout + blk * FQL_OT + r + 5 * c;                                                    // sigmanew[ix,ix] = Σ
+    double *w2 = (r == 0) ? lout + blk * FQL_OT + 4 + 5 * c : hasS ? lout + blk * FQL_OT + 24 : lout + FQL_DUMP + lane;      // [iu,ix] = KΣ | [iu,iu]
+    double *w3 = (c == 0) ? lout + blk * FQL_OT + 20 + r : lout + FQL_DUMP + lane;                   // [ix,iu] = ΣK'
+    const bool isU1 = r < M;
+    const double I = r == c ? 1.0 : 0.0, Ish = c == r + M ? 1.0 : 0.0;
+    const double R1L = R1[r + n * c];
+    double S = R1L;                                                                                  // Σ0 = R1 (forward_pass.jl:43)
+    struct Ops { double X1, Kt, Sp; };
+    auto readin = [&](const double *in, int sidx, Ops &o) __attribute__((always_inline)) {
+        o.X1 = in[ox + 128 * (sidx >> 1) + 16 * (sidx & 1)];
+        o.Kt = (kb ? kb : in + okk)[4 * sidx];
+        o.Sp = (sb ? sb : in + oss)[sidx];
+    };
+    double *cur = lin[0], *nxt = lin[1];
+    dma(0, cur);
+    if (NC > 1) dma(1, nxt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Ops in;
+    readin(cur, 0, in);
+    for (int ch = 0; ch < NC; ++ch) {
+#pragma unroll
+        for (int sidx = 0; sidx < CH; ++sidx) {
+            Ops nx;
+            if (sidx < CH - 1) readin(cur, sidx + 1, nx);
+            else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk was requested a whole chunk ago
+                readin(nxt, 0, nx);
+            }
+            w1[FQL_REC * sidx] = S;                                                                    // sigmanew[ix,ix,i] (:45)
+            if (sidx == CH - 1 && ch == NC - 1) {
+                // the last step has no policy block (the loop of forward_pass.jl:44-53 ends before it): Σ, zeros elsewhere
+                w2[FQL_REC * sidx] = 0.0;
+                w3[FQL_REC * sidx] = 0.0;
+            } else {
+                const double T = mm(in.X1, S, 0.0);                                                    // fx Σ
+                const double U1 = mm(in.Kt, S, 0.0);                                                   // K Σ          (:50)
+                const double St = mm(S, I, 0.0);                                                       // Σ'
+                const double Tt = mm(T, I, 0.0);                                                       // (fx Σ)'
+                const double U1s = mm(U1, Ish, 0.0);                                                   // (K Σ)' shifted by M columns
+                const double U2 = mm(St, in.Kt, 0.0);                                                  // Σ K'         (:51)
+                const double Sn = mm(Tt, in.X1, R1L);                                                  // (fx Σ) fx' + R1 (:49)
+                const double U3 = mm(U1s, in.Kt, in.Sp);                                               // K Σ K' + Σ_policy (:52)
+                w2[FQL_REC * sidx] = isU1 ? U1 : U3;
+                w3[FQL_REC * sidx] = U2;
+                S = Sn;
+            }
+            in = nx;
+        }
+        drain(ch);
+        if (ch + 2 < NC) dma(ch + 2, cur);
+        double *t = cur; cur = nxt; nxt = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ kl_div_wiki
 // log|det A| and the sign of det A for the leading m x m block (LU with partial pivoting, like logdet of a Matrix)
 __device__ __forceinline__ double logabsdet_small(int m, const double *Ain, int &sgn)
@@ -563,7 +682,11 @@ int ddp_forward_covariance_f64_dev(ddp_handle h, int n, int m, int N, int B, con
     const char *q4env = getenv("DDP_FCOV_Q4");                     // 0: the run-time-sized kernel for every shape (cross-check in the tests)
     if (n == 4 && (m == 1 || m == 2) && h->sink && !(q4env && q4env[0] == '0')) {
         const dim3 grid((unsigned)((B + 3) / 4)), block(DDP_WAVE);
-        if (m == 1) hipLaunchKernelGGL(fcov_q4_kernel<1>, grid, block, 0, h->stream, N, B, fx, fx_batched, R1, K, Sigma, sigmanew, (double *)h->sink);
+        const char *le = getenv("DDP_FCOV_Q4L");                     // 0: the step-by-step kernel (A/B timing, cross-check in the tests)
+        const bool al16 = ((((uintptr_t)fx | (uintptr_t)K | (uintptr_t)Sigma | (uintptr_t)sigmanew) & 15) == 0);
+        if (m == 1 && N % FQL_CH == 0 && N >= 2 * FQL_CH && al16 && B <= 6144 && !(le && le[0] == '0'))
+            hipLaunchKernelGGL(fcov_q4l_kernel, grid, block, 0, h->stream, N, B, fx, fx_batched, R1, K, Sigma, sigmanew, (double *)h->sink);
+        else if (m == 1) hipLaunchKernelGGL(fcov_q4_kernel<1>, grid, block, 0, h->stream, N, B, fx, fx_batched, R1, K, Sigma, sigmanew, (double *)h->sink);
         else hipLaunchKernelGGL(fcov_q4_kernel<2>, grid, block, 0, h->stream, N, B, fx, fx_batched, R1, K, Sigma, sigmanew, (double *)h->sink);
         DDP_HIP(hipGetLastError());
         return 0;

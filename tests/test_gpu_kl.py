@@ -51,15 +51,16 @@ def test_gps_chain_golden(ddp, monkeypatch, name, mode):
     assert np.array_equal(np.isfinite(kld), fin) and relerr(kld[fin], g["kldiv"][fin]) < RTOL
 
 
-@pytest.mark.parametrize("m", [1, 2])
-def test_fcov_and_kl_div_fast_kernels_match_generic(ddp, monkeypatch, m):
+@pytest.mark.parametrize("m,N", [(1, 70), (2, 70), (1, 72), (1, 16)])
+def test_fcov_and_kl_div_fast_kernels_match_generic(ddp, monkeypatch, m, N):
     """forward_covariance on the matrix cores (n = 4) and kl_div_wiki through the LDS image against the run-time-sized kernels (which the
     goldens and the oracle pin): a ragged batch (B not a multiple of 4, N not a multiple of 64), per-trajectory model, and the oracle on
-    every trajectory"""
+    every trajectory.  m = 1 with N a multiple of 8 takes the chunked forward_covariance kernel (same products: the same bits as the
+    step-by-step one)"""
     from oracle import oracle_ctypes as oc
     kl = ddp.kl
     rng = np.random.default_rng(40 + m)
-    n, N, B = 4, 70, 7
+    n, B = 4, 7
 
     def spd(d, s=1.0):
         a = rng.standard_normal((d, d)); return s * (a @ a.T / d + 0.5 * np.eye(d))
@@ -79,6 +80,10 @@ def test_fcov_and_kl_div_fast_kernels_match_generic(ddp, monkeypatch, m):
         for fxm, tag in ((fx, "batched"), (fx[..., 2], "shared")):
             sig = kl.forward_covariance(kl.Model(fxm, None, R1), x, u, pol)
             out[fast, tag] = (sig, kl.kl_div_wiki(xnew, x, sig, pol, prev))
+    monkeypatch.setenv("DDP_FCOV_Q4", "1"); monkeypatch.setenv("DDP_FCOV_Q4L", "0")
+    for fxm, tag in ((fx, "batched"), (fx[..., 2], "shared")):
+        assert np.array_equal(kl.forward_covariance(kl.Model(fxm, None, R1), x, u, pol), out["1", tag][0]), tag
+    monkeypatch.delenv("DDP_FCOV_Q4L")
     for tag in ("batched", "shared"):
         assert relerr(out["1", tag][0], out["0", tag][0]) < 1e-12 and relerr(out["1", tag][1], out["0", tag][1]) < 1e-11
         assert not out["1", tag][0][n:, n:, N - 1].any() and not out["1", tag][0][n:, :n, N - 1].any()       # last step: no policy block
