@@ -56,7 +56,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
         return -2;
     }
     if (hipHostMalloc((void **)&h->h_pinned, 256) != hipSuccess) h->h_pinned = nullptr;
-    if (hipMalloc(&h->sink, 4096) != hipSuccess) h->sink = nullptr;
+    if (hipMalloc(&h->sink, 4096 + 256) != hipSuccess) h->sink = nullptr;     // + a flag word behind it (df.hip)
     *out = h;
     return 0;
 }

@@ -5,6 +5,7 @@
 //             exp of the 5x5 block matrix [fxc*h fuc*h; 0]          (src/system_pendcart.jl:112-116,137-154)
 // One lane per (time step, trajectory): both are embarrassingly parallel, HBM-bound streams
 // (pendcart adds ~1.5 kflop of 5x5 Padé arithmetic per element, still far below the fp64 ridge).
+#include <stdlib.h>
 #include "ddp_internal.h"
 
 namespace {
@@ -166,6 +167,132 @@ __device__ void expm_dev(const Mat<D> &Ain, Mat<D> &E)
     }
 }
 
+// ---- exp of the ZoH block matrix [fxc*h fuc*h; 0] of a 4-state system: the LAST ROW IS ZERO, and so is the last row of every power.
+// Same operations in the same order as expm_dev<5> on the rows 0..3 (the terms that drop out are products with exact zeros), Padé 3/5/7/9
+// only (norm <= 2.1; the caller sends larger norms to the dense routine).  Five 4x5 matrices live instead of seven 5x5 ones, every product
+// in place: 230 registers and no scratch against 256 + 168 bytes of scratch, i.e. two waves per SIMD instead of one.
+struct M45 {
+    double a[20];
+    __device__ double &operator()(int r, int c) { return a[r + 4 * c]; }
+    __device__ double operator()(int r, int c) const { return a[r + 4 * c]; }
+};
+__device__ __forceinline__ void expm5_zlast_small(const M45 &A, double nA, M45 &X)
+{
+    const double C9[10] = {17643225600., 8821612800., 2075673600., 302702400., 30270240., 2162160., 110880., 3960., 90., 1.};
+    const double C7[8] = {17297280., 8648640., 1995840., 277200., 25200., 1512., 56., 1.};
+    const double C5[6] = {30240., 15120., 3360., 420., 30., 1.};
+    const double C3[4] = {120., 60., 12., 1.};
+    double C[10];
+    int nc;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) C[i] = 0.0;
+    if (nA > 0.95) { nc = 10;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) C[i] = C9[i]; }
+    else if (nA > 0.25) { nc = 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) C[i] = C7[i]; }
+    else if (nA > 0.015) { nc = 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) C[i] = C5[i]; }
+    else { nc = 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) C[i] = C3[i]; }
+    M45 A2, P, U, V;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += A(i, k) * A(k, j);          // (k = 4: A(4, j) = 0)
+            A2(i, j) = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 20; ++i) { P.a[i] = 0.0; U.a[i] = 0.0; V.a[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { P(i, i) = 1.0; U(i, i) = C[1]; V(i, i) = C[0]; }
+    const double u44 = C[1], v44 = C[0];                                  // the (4,4) entries: the powers add nothing to the last row
+#pragma unroll
+    for (int kk = 1; kk <= 4; ++kk) {
+        if (kk <= nc / 2 - 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                                 // P <- P A2, row by row in place
+                double t[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s += P(i, k) * A2(k, j);
+                    t[j] = s;
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) P(i, j) = t[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 20; ++i) { U.a[i] += C[2 * kk + 1] * P.a[i]; V.a[i] += C[2 * kk] * P.a[i]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {                                         // U <- A U, column by column in place
+        double t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += A(i, k) * U(k, j);
+            if (j == 4) s += A(i, 4) * u44;                               // U(4, 4)
+            t[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) U(i, j) = t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 20; ++i) { const double u_ = U.a[i], v_ = V.a[i]; V.a[i] = v_ + u_; U.a[i] = v_ - u_; }     // V: right-hand side E, U: the matrix T
+    // solve T X = E by LU with partial pivoting; row 4 of both is [0 0 0 0 v44]: never a pivot candidate, untouched by the elimination
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int pr = c;
+        double best = fabs(U(c, c));
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            const double v = fabs(U(r, c));
+            if (v > best) { best = v; pr = r; }
+        }
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            if (pr == r) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    double t = U(c, j); U(c, j) = U(r, j); U(r, j) = t;
+                    t = V(c, j); V(c, j) = V(r, j); V(r, j) = t;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            const double f = U(r, c) / U(c, c);
+            U(r, c) = 0.0;
+#pragma unroll
+            for (int j = c + 1; j < 5; ++j) U(r, j) -= f * U(c, j);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) V(r, j) -= f * V(c, j);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const double x4 = (j == 4) ? v44 / v44 : 0.0 / v44;               // X(4, j)
+#pragma unroll
+        for (int r = 3; r >= 0; --r) {
+            double s = V(r, j);
+#pragma unroll
+            for (int c = r + 1; c < 4; ++c) s -= U(r, c) * X(c, j);
+            if (j == 4) s -= U(r, 4) * x4;                                // (j < 4: X(4, j) = 0)
+            X(r, j) = s / U(r, r);
+        }
+    }
+}
+
 __global__ void df_lq_kernel(int n, int m, int N, int B, const double *Q, const double *R, const double *x,
                              const double *u, const int32_t *active, double *cx, double *cu)
 {
@@ -231,47 +358,80 @@ __global__ __launch_bounds__(256) void df_lq_tiled_kernel(int n, int m, int N, l
     }
 }
 
+// MODE 0: everything by the dense routine (the handle has no flag word).  MODE 1: cx, cu, and the exponential by expm5_zlast_small;
+// an element whose norm asks for Padé 13 (> 2.1: controls in the hundreds — a diverging rollout) only raises *flag.  MODE 2: a fixed
+// small grid that leaves at once unless the flag is up, then walks all elements and does those by the dense routine.
+template <int MODE>
 __global__ __launch_bounds__(64) void df_pendcart_kernel(int N, int B, double g, double l, double h, double d,
                                                          double g0, double g1, double g2, double g3, const double *Q,
                                                          const double *R, const double *x, const double *u,
                                                          const int32_t *active, double *cx, double *cu, double *fx,
-                                                         double *fu)
+                                                         double *fu, int32_t *flag, int v2)
 {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)N * B) return;
-    const int b = (int)(t / N);
-    if (active && active[b] == 0) return;
-    const double goal[4] = {g0, g1, g2, g3};
-    double xv[4], dx[4];
+    const long total = (long)N * B;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = MODE == 2 ? (long)gridDim.x * blockDim.x : total;
+    if (MODE == 2 && *(volatile int32_t *)flag == 0) return;
+    for (; t < total; t += stride) {
+        const int b = (int)(t / N);
+        if (active && active[b] == 0) continue;
+        const double goal[4] = {g0, g1, g2, g3};
+        double xv[4], dx[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xv[i] = x[4 * t + i]; dx[i] = xv[i] - goal[i]; }
-    double uu = u[t];
-    if (uu != uu) uu = 0.0;
+        for (int i = 0; i < 4; ++i) { xv[i] = x[4 * t + i]; dx[i] = xv[i] - goal[i]; }
+        double uu = u[t];
+        if (uu != uu) uu = 0.0;
+        if (MODE != 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        double s = 0.0;
+            for (int i = 0; i < 4; ++i) {
+                double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += Q[i + 4 * j] * dx[j];
-        cx[4 * t + i] = s;                                            // system_pendcart.jl:113
+                for (int j = 0; j < 4; ++j) s += Q[i + 4 * j] * dx[j];
+                cx[4 * t + i] = s;                                        // system_pendcart.jl:113
+            }
+            cu[t] = R[0] * uu;                                            // :114
+        }
+        const double sn = sin(xv[0]), cs = cos(xv[0]);
+        const double m01 = 1.0 * h, m10 = (-g / l * cs - uu / l * sn) * h, m11 = (-d) * h, m23 = 1.0 * h, m14 = (cs / l) * h, m34 = 1.0 * h;     // fxc*h, fuc*h (:130-148)
+        // 1-norm of the block matrix: the largest column sum (columns 0, 1, 3, 4; column 2 is zero)
+        const double nA = fmax(fmax(0.0 + fabs(m10), fabs(m01) + fabs(m11)), fmax(fabs(m23), fabs(m14) + fabs(m34)));
+        if (MODE == 1) {
+            if (!(nA <= 2.1)) { *flag = 1; continue; }
+            M45 A, X;
+#pragma unroll
+            for (int i = 0; i < 20; ++i) A.a[i] = 0.0;
+            A(0, 1) = m01; A(1, 0) = m10; A(1, 1) = m11; A(2, 3) = m23; A(1, 4) = m14; A(3, 4) = m34;
+            expm5_zlast_small(A, nA, X);
+            if (v2) {                                                     // 16-byte stores (the launcher has checked the alignment)
+                typedef double d2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int e = 0; e < 20; e += 2) {
+                    const d2v v = {X.a[e], X.a[e + 1]};
+                    *(d2v *)((e < 16 ? fx + 16 * t : fu + 4 * t - 16) + e) = v;  // X is column-major 4 x 5: entries 0..15 = fx (:149), 16..19 = fu (:150)
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fx[16 * t + r + 4 * c] = X(r, c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fu[4 * t + r] = X(r, 4);
+            }
+        } else {
+            if (MODE == 2 && nA <= 2.1) continue;
+            Mat<5> M, E;
+#pragma unroll
+            for (int i = 0; i < 25; ++i) M.a[i] = 0.0;
+            M(0, 1) = m01; M(1, 0) = m10; M(1, 1) = m11; M(2, 3) = m23; M(1, 4) = m14; M(3, 4) = m34;
+            expm_dev<5>(M, E);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fx[16 * t + r + 4 * c] = E(r, c);    // :149
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fu[4 * t + r] = E(r, 4);                  // :150
+        }
     }
-    cu[t] = R[0] * uu;                                                // :114
-    Mat<5> M, E;
-#pragma unroll
-    for (int i = 0; i < 25; ++i) M.a[i] = 0.0;
-    const double sn = sin(xv[0]), cs = cos(xv[0]);
-    M(0, 1) = 1.0 * h;                                                // fxc*h, fuc*h  (:130-148)
-    M(1, 0) = (-g / l * cs - uu / l * sn) * h;
-    M(1, 1) = (-d) * h;
-    M(2, 3) = 1.0 * h;
-    M(1, 4) = (cs / l) * h;
-    M(3, 4) = 1.0 * h;
-    expm_dev<5>(M, E);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fx[16 * t + r + 4 * c] = E(r, c);    // :149
-#pragma unroll
-    for (int r = 0; r < 4; ++r) fu[4 * t + r] = E(r, 4);                  // :150
 }
 
 }   // namespace
@@ -299,8 +459,18 @@ int ddp_df_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const do
         DDP_CHECK(p->n == 4 && p->m == 1, "df: pendcart needs n=4, m=1");
         DDP_CHECK(fx && fu, "df: pendcart needs fx and fu outputs");
         const dim3 grid((unsigned)((cols + 63) / 64)), block(64);
-        hipLaunchKernelGGL(df_pendcart_kernel, grid, block, 0, h->stream, p->N, p->B, p->g, p->l, p->h, p->d, p->goal[0],
-                           p->goal[1], p->goal[2], p->goal[3], p->Q, p->R, x, u, active, cx, cu, fx, fu);
+        const char *de = getenv("DDP_DF_DENSE");                     // 1: the dense expm for every element (A/B timing, cross-check in the tests)
+        int32_t *flag = h->sink ? (int32_t *)((char *)h->sink + 4096) : nullptr;     // the word behind the 4 KB the masked lanes may write
+        const int v2 = ((((uintptr_t)fx | (uintptr_t)fu) & 15) == 0) ? 1 : 0;
+#define DDP_DFP(MODE_, GRID_) hipLaunchKernelGGL(df_pendcart_kernel<MODE_>, GRID_, block, 0, h->stream, p->N, p->B, p->g, p->l, p->h, p->d, p->goal[0], \
+                                                 p->goal[1], p->goal[2], p->goal[3], p->Q, p->R, x, u, active, cx, cu, fx, fu, flag, v2)
+        if (!flag || (de && de[0] == '1')) DDP_DFP(0, grid);
+        else {
+            DDP_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), h->stream));
+            DDP_DFP(1, grid);
+            DDP_DFP(2, dim3(1024));
+        }
+#undef DDP_DFP
     } else {
         DDP_CHECK(false, "df: unknown problem kind %d", p->kind);
     }

@@ -521,3 +521,31 @@ def test_pinned_result_arrays(ddp, monkeypatch):
     monkeypatch.setenv("DDP_PINNED_RESULTS", "1")
     other = ddp.back_pass(cx, cu, P["Q"], np.zeros((10, 2)), 2.0 * P["R"], P["A"], P["B"], 1.0, 1, None, x, u)      # would reuse a freed block
     assert np.array_equal(view, ref) and not np.array_equal(other[3][:, :, 5, 7], ref)
+
+
+def test_df_pendcart_structured_expm_matches_the_dense_one(ddp, monkeypatch):
+    """df for the pendulum (system_pendcart.jl:137-154): the exponential of the ZoH block matrix by the routine that uses its zero last row
+    (two passes: small norms in place, norms > 2.1 — controls in the hundreds — by the dense routine in a second launch that otherwise leaves
+    at once) against the dense routine for every element: the same operations in the same order, the same bits; the oracle on a sample"""
+    from oracle import np_restatement as npr
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(77)
+    N, B = 50, 9
+    x = np.stack([rng.uniform(-4, 4, (N, B)), rng.standard_normal((N, B)), rng.standard_normal((N, B)), rng.standard_normal((N, B))])
+    u = rng.standard_normal((1, N, B))
+    u[0, 7, 3] = 400.0; u[0, 8, 3] = -2500.0; u[0, 0, 0] = 90.0; u[0, N - 1, B - 1] = 1e5; u[0, 5, 5] = np.nan      # norms beyond 2.1 (Padé 13, with squarings), a NaN control
+    prob = ddp.PendcartProblem()
+    monkeypatch.delenv("DDP_DF_DENSE", raising=False)
+    fast = ddp.df(prob, x, u)
+    monkeypatch.setenv("DDP_DF_DENSE", "1")
+    dense = ddp.df(prob, x, u)
+    for a, b_, nm in zip(fast, dense, ("fx", "fu", "fxx", "fxu", "fuu", "cx", "cu", "cxx", "cxu", "cuu")):
+        if a is None or b_ is None:
+            assert a is None and b_ is None, nm
+            continue
+        assert np.array_equal(a, b_), nm
+    P = npr.PENDCART
+    p = oc.make_problem("pendcart", 4, 1, N, Q=P["Q"], R=P["R"], pend=P)
+    for b in (0, 3, 5, B - 1):
+        r = oc.df(p, x[..., b], u[..., b])
+        assert relerr(fast[0][..., b], r[0]) < 1e-12 and relerr(fast[1][..., b], r[1]) < 1e-12
