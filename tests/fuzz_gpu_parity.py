@@ -162,7 +162,28 @@ def ilqg_case(ddp, oc, rng, case):
         cg, cr_ = float(cost[:, b].sum()), float(cr.sum())
         # (two solves that leave one iteration apart differ by what that iteration gained: a few tol_fun = 1e-7 in absolute terms; seen:
         #  1.07e-6 relative at cost 5.39 with control limits)
-        assert abs(cg - cr_) <= 5e-6 * abs(cr_), ("cost", cg, cr_, case, dict(n=n, m=m, N=N, B=B, lims=lims is not None, regType=regType))
+        if abs(cg - cr_) > 5e-6 * abs(cr_):
+            # The reference's algorithm is not continuous in its inputs: with limits a control can sit on its bound with a multiplier that is
+            # zero to rounding, boxQP's `grad > 0` then decides by the last bit whether the coordinate is clamped, K_i loses a row or not, dV
+            # changes in the third digit and the line search goes another way (seed 97, case 39: states equal to 4e-16, the ORACLE's own
+            # back_pass gives dV = (-1.33e-5, 6.6e-6) on its state and (-3.17e-5, 1.58e-5) on the HIP path's; case 127: the HIP solve ends on
+            # tol_fun at 5.70322 after 97 rollouts where the oracle reaches 5.70131).  A defect or that?  The oracle decides: restarted from
+            # the HIP path's state at the iteration where the two cost traces part (same λ, dλ: the decisions agree up to there), it has
+            # to arrive where the HIP path arrived.
+            assert lims is not None, ("cost", cg, cr_, case, "no limits: nothing discontinuous to blame")
+            to, tg = np.asarray(info["trace"]["cost"]), tr["cost"][:, b]
+            L = min(len(to), int(st[1]) + 1)
+            part = [i for i in range(L) if abs(to[i] - tg[i]) > 1e-12 * abs(to[i])]
+            i0 = part[0] if part else L - 1
+            xa, ua, _, _, _, ca, tra = ddp.iLQG(ddp.LQProblem(A, Bm, Q, R), x0, u0, lims=lims, regType=regType, max_iter=i0)
+            xo, uo, _, _, _, co, io = oc.ilqg(p, x0[:, b], u0[..., b], lims=lims, regType=regType, max_iter=i0)
+            assert relerr(ua[..., b], uo) < 1e-10 and tra["stats"][5, b] == io["lam"], ("state where the traces part", case, i0)
+            x2, u2, _, _, _, c2, i2 = oc.ilqg_prerolled(p, xa[..., b], ua[..., b], cost0=ca[:, b], lims=lims, regType=regType, lam=io["lam"],
+                                                        dlam=io["dlam"])
+            assert abs(float(c2.sum()) - cg) <= 5e-6 * abs(cg), ("cost", cg, cr_, "oracle restarted from the HIP state at iteration %d" % i0,
+                                                                float(c2.sum()), case, dict(n=n, m=m, N=N, B=B, regType=regType))
+            ilqg_case.knife_edge = getattr(ilqg_case, "knife_edge", 0) + 1
+            continue
         if same_path and lims is None:
             for got, ref, name in ((x[..., b], xr, "x"), (u[..., b], ur, "u"), (Vxx[..., b], vxxr, "Vxx")):
                 e = relerr(got, ref)
@@ -308,7 +329,8 @@ def main():
     worst = 0.0
     for c in range(cases // 10):
         worst = max(worst, ilqg_case(ddp, oc, rng, c))
-    print("fuzz: %d iLQG solves passed, worst relative error %.3g" % (cases // 10, worst))
+    print("fuzz: %d iLQG solves passed, worst relative error %.3g; %d solves with limits more than 5e-6 apart in cost (boxQP knife edge: the oracle restarted from the HIP "
+          "state at the parting iteration arrives where the HIP path did)" % (cases // 10, worst, getattr(ilqg_case, "knife_edge", 0)))
     worst = 0.0
     for c in range(cases // 4):
         worst = max(worst, pendcart_case(ddp, oc, np.random.default_rng([seed, 100000 + c]), c))
@@ -319,8 +341,27 @@ def main():
     print("fuzz: %d KL-path cases passed (%d exploded draws not compared), worst relative error %.3g" % (cases // 4, getattr(gps_case, "skipped", 0), worst))
 
 
+def main_ilqg(solves, seed):
+    """`--ilqg solves seed`: only the whole-solve part of a sweep (the same draws as `main` makes for cases = 10 solves)"""
+    import ddp_amd as ddp
+    from oracle import oracle_ctypes as oc
+    ddp.default_handle()
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for c in range(solves):
+        try:
+            worst = max(worst, ilqg_case(ddp, oc, rng, c))
+        except AssertionError as e:
+            if os.environ.get("FUZZ_KEEP_GOING") != "1":
+                raise
+            print("FAILED", e)
+    print("fuzz: %d iLQG solves passed (seed %d), worst relative error %.3g; %d on the boxQP knife edge" % (solves, seed, worst, getattr(ilqg_case, "knife_edge", 0)))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--cond":
         conditioning(int(sys.argv[2]), int(sys.argv[3]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--ilqg":
+        main_ilqg(int(sys.argv[2]), int(sys.argv[3]))
     else:
         main()
