@@ -12,6 +12,7 @@ rng = np.random.default_rng(1234)
 P = npr.make_lq_problem(rng)
 prob = ddp_amd.LQProblem(P["A"], P["B"], P["Q"], P["R"])
 x0 = np.ones((10, B)) + 0.1 * rng.standard_normal((10, B)); u0 = 0.1 * rng.standard_normal((2, T, B))
+x0, u0 = np.asfortranarray(x0), np.asfortranarray(u0)      # the layout a Julia caller has (a C-ordered u0 costs the mirror an 8 ms transposing copy)
 for it in range(3):
     t = time.perf_counter()
     r = ddp_amd.iLQG(prob, x0, u0)
