@@ -78,12 +78,33 @@ class DDPError(RuntimeError):
     pass
 
 
+def _share_torch_hip():
+    """ONE HIP runtime per process: a PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64 (torch/lib), libddp_amd.so is
+    linked against the system ROCm.  Whoever loads first decides which copy the other binds to; with the system copy first, a later
+    `import torch` finds "No HIP GPUs".  If torch is installed but not imported yet, its bundled runtime is loaded (globally) before the
+    library, which is what happens anyway when torch is imported first (bench.py, the tests).  DDP_AMD_SHARE_TORCH_HIP=0 switches this off."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("DDP_AMD_SHARE_TORCH_HIP", "1") == "0":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise DDPError("libddp_amd.so not built (%s): run `python __graft_entry__.py` or "
                            "`python differentialdynamicprogramming.jl_amd/build.py`; there is no CPU fallback" % LIB_PATH)
+        _share_torch_hip()
         L = C.CDLL(LIB_PATH)
         L.ddp_last_error.restype = C.c_char_p
         L.ddp_version.restype = C.c_char_p

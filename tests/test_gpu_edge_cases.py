@@ -549,3 +549,19 @@ def test_df_pendcart_structured_expm_matches_the_dense_one(ddp, monkeypatch):
     for b in (0, 3, 5, B - 1):
         r = oc.df(p, x[..., b], u[..., b])
         assert relerr(fast[0][..., b], r[0]) < 1e-12 and relerr(fast[1][..., b], r[1]) < 1e-12
+
+
+def test_torch_imported_after_the_library_still_finds_the_gpu():
+    """one HIP runtime per process: the PyTorch wheel bundles its own libamdhip64, libddp_amd.so is linked against the system ROCm — with the
+    system copy loaded first a later `import torch` reported "No HIP GPUs".  The mirror loads torch's bundled runtime first when torch is
+    installed (what happens anyway when torch is imported first); a fresh interpreter, library first, torch second"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; import ddp_amd; ddp_amd.default_handle();\n"
+            "x, u, c = ddp_amd.forward_pass(None, np.array([3.0, 0, 0, 0]), np.zeros((1, 8)), None, 1.0, ddp_amd.PendcartProblem(), None)\n"
+            "import torch; assert torch.cuda.device_count() >= 1; t = (torch.ones(4, device='cuda') * 2).sum().item(); assert t == 8.0\n"
+            "x2, u2, c2 = ddp_amd.forward_pass(None, np.array([3.0, 0, 0, 0]), np.zeros((1, 8)), None, 1.0, ddp_amd.PendcartProblem(), None)\n"
+            "assert np.array_equal(c, c2); print('both ok')") % root
+    env = dict(os.environ); env.pop("DDP_AMD_SHARE_TORCH_HIP", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "both ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
