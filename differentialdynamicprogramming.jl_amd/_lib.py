@@ -19,7 +19,7 @@ u8p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
 
 EXPORTS = [
-    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_stream",
+    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_reload_env", "ddp_last_kernel", "ddp_stream",
     "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_memset", "ddp_host_alloc", "ddp_host_free", "ddp_host_trim",
     "ddp_event_create", "ddp_event_destroy", "ddp_event_record", "ddp_event_elapsed_ms",
     "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
@@ -110,9 +110,11 @@ def lib():
         L.ddp_version.restype = C.c_char_p
         L.ddp_stream.restype = vp
         L.ddp_stream.argtypes = [vp]
+        L.ddp_last_kernel.restype = C.c_char_p
+        L.ddp_last_kernel.argtypes = [vp, C.c_int]
         for name in EXPORTS:
             fn = getattr(L, name)
-            if name not in ("ddp_last_error", "ddp_version", "ddp_stream"):
+            if name not in ("ddp_last_error", "ddp_version", "ddp_stream", "ddp_last_kernel"):
                 fn.restype = C.c_int
         L.ddp_ilqg_default_opts.restype = None
         L.ddp_ilqgkl_default_opts.restype = None
@@ -123,6 +125,10 @@ def lib():
 def check(rc):
     if rc != 0:
         raise DDPError("libddp_amd: %s (rc=%d)" % (lib().ddp_last_error().decode(), rc))
+
+
+def _env_snapshot():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("DDP_")))
 
 
 class Handle:
@@ -136,6 +142,7 @@ class Handle:
         else:
             check(lib().ddp_create_with_stream(int(device), vp(stream), C.byref(self._h)))
         self.device = device
+        self._env = _env_snapshot()
 
     def close(self):
         if self._h:
@@ -150,7 +157,17 @@ class Handle:
 
     @property
     def raw(self):
+        """the ddp_handle for a C call.  The library reads its DDP_* switches once per handle; a host that changes them (the tests
+        do, per case) gets them re-read here, so `os.environ[...] = ...` keeps working as it did when every launch called getenv."""
+        snap = _env_snapshot()
+        if snap != self._env:
+            self._env = snap
+            lib().ddp_reload_env(self._h)
         return self._h
+
+    def last_kernel(self, which=0):
+        """kernel of the last back_pass (0) / forward_pass (1) dispatch (ddp_last_kernel)"""
+        return lib().ddp_last_kernel(self._h, int(which)).decode()
 
     def sync(self):
         check(lib().ddp_sync(self._h))

@@ -714,17 +714,12 @@ int ddp_launch_back_pass_dppw(ddp_handle h, const ddp_bp_desc *d, const double *
                               const double *fu, const double *lambda, const int32_t *active, double *K,
                               double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
 
-int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                          const double *cxx, const double *cxu, const double *cuu, const double *fx,
                          const double *fu, const double *lambda, const double *lims, const double *u,
                          const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                          double *Vxx, double *dV, int32_t *diverge)
 {
-    DDP_DEVICE(h);
-    DDP_CHECK(d->n >= 1 && d->m >= 1 && d->N >= 1 && d->B >= 1, "back_pass: bad sizes n=%d m=%d N=%d B=%d", d->n, d->m, d->N, d->B);
-    DDP_CHECK(d->regType == 1 || d->regType == 2, "back_pass: regType must be 1 or 2 (got %d)", d->regType);
-    DDP_CHECK(!d->has_lims || (lims && u), "back_pass: has_lims needs lims and u");
-    DDP_CHECK(d->m <= DDP_MAX_M, "back_pass: m=%d exceeds DDP_MAX_M=%d", d->m, DDP_MAX_M);
     // Kernel choice.  Several implementations of the same arithmetic exist:
     //   x (mx)  one 16x16 fp64 MFMA tile per trajectory, one wave each (back_pass_mx.hip; n=10, m=2, no limits): shortest
     //           dependent chain per time step, best while the batch gives a SIMD only one or two waves (B=1024: 0.55 ms
@@ -733,31 +728,32 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     //           batch gives every SIMD a few wavefronts; also the kernel for control limits;
     //   general 64 lanes per trajectory, any n <= 32 / m <= 8 / limits (this file).
     // DDP_BACKPASS=x|q|general|dpp|big forces one (A/B timing, tests of every code path).
-    const char *force_env = getenv("DDP_BACKPASS");          // read per call so tests can switch paths
+    const char *force_env = ddp_env(h, ENV_BACKPASS);          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
     if (force == 'x' || (force == 0 && d->B < 5120)) {
         // two waves per trajectory (chain + write-back, back_pass_mx2.hip) while a CU's four SIMDs hold one trajectory each;
         // DDP_MX2=0 / 1 forces the one-wave / two-wave kernel
-        const char *mx2_env = getenv("DDP_MX2");
+        const char *mx2_env = ddp_env(h, ENV_MX2);
         if (mx2_env ? mx2_env[0] == '1' : d->B <= 1024) {
             const int r2 = ddp_launch_back_pass_mx2(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
-            if (r2 <= 0) return r2;
+            if (r2 <= 0) { h->last_kernel[0] = "back_pass_mx2_kernel"; return r2; }
         }
         const int rc = ddp_launch_back_pass_mx(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mx_kernel"; return rc; }
     }
     if (force == 'q' || force == 0) {                             // n = 4, m = 1: one trajectory per 4x4x4 MFMA block
         const int rc = ddp_launch_back_pass_q4(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_q4"; return rc; }
     }
     if (force == 0 || force == 'd') {                             // machine-filling batches of the LTI shape: row kernel + write-back waves
         const int rw = ddp_launch_back_pass_dppw(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
-        if (rw <= 0) return rw;
+        if (rw <= 0) { h->last_kernel[0] = "back_pass_dppw_kernel"; return rw; }
     }
     if (force != 'g' && force != 'b') {
         const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_dpp_kernel"; return rc; }
     }
+    h->last_kernel[0] = "back_pass_kernel";
     BPArgs a = {};
     a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;
     a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.regType = d->regType;
@@ -770,11 +766,11 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
     if (d->n == 6 && d->m == 3) return launch_nm<6, 3>(h, d, a);
     if (force != 'b' && force != 'g') {                          // n=64, m=8: fp64 matrix cores
         const int rc = ddp_launch_back_pass_mfma(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mfma_kernel"; return rc; }
     }
     if (d->n > DDP_MAX_N_GENERIC || force == 'b') {               // large states: 256-thread work-group per trajectory
         const int rc = ddp_launch_back_pass_big(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_big_kernel"; return rc; }
     }
     if (d->n > DDP_MAX_N_GENERIC && d->n <= 64 && ((d->n | d->m) & 1))      // odd n or m: embed in the next even sizes
         return launch_back_pass_padded(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
@@ -783,4 +779,37 @@ int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, c
 #else
     DDP_CHECK(false, "back_pass: DDP_FAST_BUILD only has the (10,2) LTI kernel");
 #endif
+}
+
+int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                         const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                         const double *fu, const double *lambda, const double *lims, const double *u,
+                         const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                         double *Vxx, double *dV, int32_t *diverge)
+{
+    DDP_DEVICE(h);
+    DDP_CHECK(d->n >= 1 && d->m >= 1 && d->N >= 1 && d->B >= 1, "back_pass: bad sizes n=%d m=%d N=%d B=%d", d->n, d->m, d->N, d->B);
+    DDP_CHECK(d->regType == 1 || d->regType == 2, "back_pass: regType must be 1 or 2 (got %d)", d->regType);
+    DDP_CHECK(!d->has_lims || (lims && u), "back_pass: has_lims needs lims and u");
+    DDP_CHECK(d->m <= DDP_MAX_M, "back_pass: m=%d exceeds DDP_MAX_M=%d", d->m, DDP_MAX_M);
+    const char *force_env = ddp_env(h, ENV_BACKPASS);
+    const char force = force_env ? force_env[0] : 0;
+    // Operands shared by the batch (the reference's LTI method with ONE fx, fu, cxx, cxu, cuu): the matrix recursion once per distinct
+    // λ (back_pass_sh.hip).  What it leaves out (λ values that occur once, more distinct values than it has groups) comes back as the
+    // activity mask of the per-trajectory kernels, which are launched behind it and exit at once when there is nothing for them.
+    // Measured (profiles/ab_sh.py): B = 1 024 0.42 ms (= the per-trajectory kernel: both wait for one 999-step matrix chain),
+    // 2 048 0.45 vs 0.97 ms, 32 768 6.7 vs 9.4 ms.  DDP_SH_MIN_B moves the threshold (tests run it at B = 6).
+    const char *sh_env = ddp_env(h, ENV_SH_MIN_B);
+    const int sh_min = sh_env ? atoi(sh_env) : 1024;
+    if ((force == 0 || force == 's') && d->B >= sh_min) {
+        const int32_t *fb = nullptr;
+        const int rs = ddp_launch_back_pass_sh(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge, &fb);
+        if (rs < 0) return rs;
+        if (rs == 0) {
+            const int rc = launch_back_pass_inner(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, fb, K, k, Quu, Vx, Vxx, dV, diverge);
+            h->last_kernel[0] = "sh_back_kernel";
+            return rc;
+        }
+    }
+    return launch_back_pass_inner(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
 }

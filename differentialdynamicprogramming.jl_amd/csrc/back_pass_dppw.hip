@@ -483,7 +483,7 @@ int ddp_launch_back_pass_dppw(ddp_handle h, const ddp_bp_desc *d, const double *
 {
     if (d->N > 400000) return 1;                                 // 32-bit lane offsets inside a chain wave's four trajectories
     if (d->n != 10 || d->m != 2 || d->has_lims || d->fx_tv || d->cost_tv || d->fx_batched || d->cost_batched || !h->sink) return 1;
-    const char *env = getenv("DDP_DPPW");                        // 0: never, 1: whenever the shape allows (A/B timing, tests)
+    const char *env = ddp_env(h, ENV_DPPW);                        // 0: never, 1: whenever the shape allows (A/B timing, tests)
     if (env && env[0] == '0') return 1;
     if (!(env && env[0] == '1') && d->B < 6144) return 1;        // measured cross-over (profiles/ab_fill_crossover.sh): 4 096: dpp 1.81, this 1.97 ms; 6 144: mx 2.84, this 2.21
     if ((((uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx) & 15) != 0) return 1;     // 16-byte pieces
@@ -492,7 +492,7 @@ int ddp_launch_back_pass_dppw(ddp_handle h, const ddp_bp_desc *d, const double *
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge; a.sink = (double *)h->sink;
     const dim3 grid((unsigned)((d->B + NCW * 4 - 1) / (NCW * 4))), block(DDP_WAVE * (NCW + NWW));
-    const char *exp_env = getenv("DDP_DPPW_EXP");
+    const char *exp_env = ddp_env(h, ENV_DPPW_EXP);
     const int exp = exp_env ? atoi(exp_env) : 0;
     if (exp == 1) hipLaunchKernelGGL((back_pass_dppw_kernel<10, 2, 1>), grid, block, 0, h->stream, a);
     else if (exp == 2) hipLaunchKernelGGL((back_pass_dppw_kernel<10, 2, 2>), grid, block, 0, h->stream, a);

@@ -439,7 +439,7 @@ int ddp_launch_back_pass_mx(ddp_handle h, const ddp_bp_desc *d, const double *cx
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     // the group write-back needs 16-byte aligned arrays (every per-step size of this shape is a multiple of 16 bytes)
-    const char *lv = getenv("DDP_MX_LDS");                    // 0: results straight to global memory, step by step (A/B, tests)
+    const char *lv = ddp_env(h, ENV_MX_LDS);                    // 0: results straight to global memory, step by step (A/B, tests)
     const bool al16 = ((((uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx) & 15) == 0);
     if (al16 && !(lv && lv[0] == '0')) return d->regType == 2 ? launch_mx<true, true>(h, d, a) : launch_mx<false, true>(h, d, a);
     return d->regType == 2 ? launch_mx<true, false>(h, d, a) : launch_mx<false, false>(h, d, a);

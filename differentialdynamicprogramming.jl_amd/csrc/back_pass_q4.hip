@@ -640,16 +640,16 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     a.sink = (double *)h->sink;
     const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
-    const char *ex = getenv("DDP_Q4_EXP");
+    const char *ex = ddp_env(h, ENV_Q4_EXP);
     const int exp = ex ? atoi(ex) : 0;
-    const char *sg = getenv("DDP_Q4_SINGLE");                  // 1: force the one-step-at-a-time kernel (tests)
+    const char *sg = ddp_env(h, ENV_Q4_SINGLE);                  // 1: force the one-step-at-a-time kernel (tests)
     const bool aligned16 = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu |
                               (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)(d->has_lims ? u : cu)) & 15) == 0);
     const bool paired = !d->cost_tv && (d->N % 2 == 0) && d->N >= 4 * Q4_DP && aligned16 && h->sink != nullptr && !(sg && sg[0] == '1');
 #define Q4P(L_, R_, E_) hipLaunchKernelGGL((back_pass_q4p_kernel<L_, R_, E_>), grid, block, 0, h->stream, a)
 #define Q4S(L_, C_, R_) hipLaunchKernelGGL((back_pass_q4_kernel<L_, C_, R_>), grid, block, 0, h->stream, a)
     const bool reg2 = d->regType == 2;
-    const char *lv = getenv("DDP_Q4_LDS");                     // 0 / 1: never / whenever possible the LDS-group kernel (A/B, tests)
+    const char *lv = ddp_env(h, ENV_Q4_LDS);                     // 0 / 1: never / whenever possible the LDS-group kernel (A/B, tests)
     // the LDS-group kernel is the latency kernel: 24 KB of LDS per wave let 6 of them share a CU, and from two waves per SIMD on the
     // pair kernel hides its issue gaps behind the other wave (B = 8192: 0.66 ms against 0.90 ms; B = 6144: 0.61 against 0.53, B = 4096: 0.44 against 0.39)
     const bool few = lv ? lv[0] == '1' : d->B <= 6144;
@@ -691,7 +691,7 @@ int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double
                                 double *Vxx, double *dV, int32_t *diverge)
 {
     if (!(d->n == 4 && d->m == 1) || d->N < 2 || !d->fx_tv || !d->cost_tv || kl->eta_tv) return 1;
-    const char *q4e = getenv("DDP_GPS_Q4");                      // 0: never (the lane-per-trajectory kernel instead; A/B timing, tests)
+    const char *q4e = ddp_env(h, ENV_GPS_Q4);                      // 0: never (the lane-per-trajectory kernel instead; A/B timing, tests)
     if (q4e && q4e[0] == '0') return 1;
     const long N = d->N, B = d->B, NB = N * B;
     auto al = [](size_t b_) { return (b_ + 255) & ~(size_t)255; };
@@ -725,7 +725,7 @@ int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double
     const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
     // chunks of eight steps through the LDS (the q4l scheme, here with the time-varying c̃xx, c̃xu, c̃uu in the image): 13 direct-to-LDS loads
     // and 7 stores per 8 steps instead of 10 + 2 vector-memory instructions per step.  DDP_GPS_Q4L=0: the one-step kernel (A/B, tests)
-    const char *le = getenv("DDP_GPS_Q4L");
+    const char *le = ddp_env(h, ENV_GPS_Q4L);
     const bool al16 = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx |
                          (uintptr_t)(d->has_lims ? u : fx)) & 15) == 0);
     const bool chunked = !(le && le[0] == '0') && d->N % Q4L_CH == 0 && d->N >= 2 * Q4L_CH && al16 && h->sink != nullptr && d->B <= 6144;

@@ -22,7 +22,26 @@ void ddp_set_error(const char *fmt, ...)
 extern "C" {
 
 const char *ddp_last_error(void) { return g_err; }
-const char *ddp_version(void) { return "ddp_amd 0.2.0 (gfx950, fp64)"; }
+const char *ddp_version(void) { return "ddp_amd 0.3.0 (gfx950, fp64)"; }
+
+static const char *const ddp_env_names[ENV_COUNT] = {"DDP_BACKPASS", "DDP_SH_MIN_B", "DDP_MX2", "DDP_DPPW", "DDP_DPPW_EXP", "DDP_MX_LDS", "DDP_Q4_EXP", "DDP_Q4_SINGLE", "DDP_Q4_LDS", "DDP_GPS_Q4", "DDP_GPS_Q4L", "DDP_DF_DENSE", "DDP_FORWARD", "DDP_FORWARD64", "DDP_FORWARD_FAST", "DDP_FORWARD_FUSE", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND", "DDP_FORWARD_PIPE", "DDP_ILQG_COMPACT", "DDP_ILQG_LSGROUPS", "DDP_TEST_COMPACT_ALLOC_FAIL", "DDP_GPS_LANE", "DDP_FCOV_Q4", "DDP_FCOV_Q4L", "DDP_KL_LDS"};
+
+int ddp_reload_env(ddp_handle h)
+{
+    if (!h) { ddp_set_error("null handle"); return -1; }
+    for (int i = 0; i < ENV_COUNT; ++i) {
+        const char *v = getenv(ddp_env_names[i]);
+        h->envset[i] = v != nullptr;
+        if (v) { strncpy(h->envv[i], v, sizeof h->envv[i] - 1); h->envv[i][sizeof h->envv[i] - 1] = 0; }
+    }
+    return 0;
+}
+
+const char *ddp_last_kernel(ddp_handle h, int which)
+{
+    if (!h || which < 0 || which > 1 || !h->last_kernel[which]) return "";
+    return h->last_kernel[which];
+}
 
 int ddp_device_count(void)
 {
@@ -44,7 +63,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
     h->device = device;
     h->scratch = nullptr;
     h->scratch_bytes = 0;
-    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr;
+    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr; h->sh = nullptr; h->sh_bytes = 0; h->sh_attr = false; h->ncu = 0; h->last_kernel[0] = h->last_kernel[1] = nullptr; ddp_reload_env(h);
     h->h_pinned = nullptr;
     h->timing = nullptr; h->timing_cap = 0; h->tev_ok = false;
     h->owns_stream = !adopt;
@@ -73,6 +92,7 @@ int ddp_destroy(ddp_handle h)
     if (h->h_pinned) hipHostFree(h->h_pinned);
     if (h->sink) hipFree(h->sink);
     if (h->pad) hipFree(h->pad);
+    if (h->sh) hipFree(h->sh);
     if (h->tev_ok) for (int e = 0; e < 4; ++e) hipEventDestroy(h->tev[e]);
     if (h->owns_stream) hipStreamDestroy(h->stream);
     delete h;

@@ -9,6 +9,11 @@
 #define DDP_WAVE 64
 #define DDP_MAX_N_GENERIC 32      // run-time-sized kernels: n <= 32, m <= DDP_MAX_M
 
+// The DDP_* switches of the dispatchers (kernel choice for A/B timing and for the tests that force every code path) are read from the
+// environment ONCE per handle (ddp_create) and again on ddp_reload_env(): no launch calls getenv, and a setenv() in another thread
+// cannot race with a launch.  ddp_env() returns the cached value or nullptr.
+enum ddp_env_id { ENV_BACKPASS, ENV_SH_MIN_B, ENV_MX2, ENV_DPPW, ENV_DPPW_EXP, ENV_MX_LDS, ENV_Q4_EXP, ENV_Q4_SINGLE, ENV_Q4_LDS, ENV_GPS_Q4, ENV_GPS_Q4L, ENV_DF_DENSE, ENV_FORWARD, ENV_FORWARD64, ENV_FORWARD_FAST, ENV_FORWARD_FUSE, ENV_FORWARD_LANE, ENV_FORWARD_PEND, ENV_FORWARD_PIPE, ENV_ILQG_COMPACT, ENV_ILQG_LSGROUPS, ENV_TEST_COMPACT_ALLOC_FAIL, ENV_GPS_LANE, ENV_FCOV_Q4, ENV_FCOV_Q4L, ENV_KL_LDS, ENV_COUNT };
+
 struct ddp_handle_s {
     int          device;
     hipStream_t  stream;
@@ -19,6 +24,13 @@ struct ddp_handle_s {
     int32_t     *h_pinned;        // small pinned buffer for polling
     void        *pad;             // operands / results of a backward pass padded to even sizes (back_pass.hip), grown on demand
     size_t       pad_bytes;
+    void        *sh;              // back_pass_sh.hip: control block, work items, record streams of the shared-LTI backward pass
+    size_t       sh_bytes;
+    bool         sh_attr;         // its dynamic-LDS attribute has been set on this device
+    int          ncu;             // compute units of the device (0: not asked yet)
+    char         envv[ENV_COUNT][24];
+    bool         envset[ENV_COUNT];
+    const char  *last_kernel[2];  // what the last backward / forward dispatch launched (ddp_last_kernel)
     void        *sink;            // 4 KB of device memory that masked-out lanes may write (stores without an exec-mask branch)
     double      *timing;          // ddp_ilqg_set_timing: host buffer [3, timing_cap] or NULL
     int          timing_cap;
@@ -27,6 +39,7 @@ struct ddp_handle_s {
 };
 
 void ddp_set_error(const char *fmt, ...);
+static inline const char *ddp_env(ddp_handle h, int id) { return h->envset[id] ? h->envv[id] : nullptr; }
 
 #define DDP_HIP(call)                                                                         \
     do {                                                                                      \
@@ -85,6 +98,14 @@ int ddp_launch_back_pass_mx2(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
                              const double *fu, const double *lambda, const int32_t *active, double *K,
                              double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
+
+// shared time-invariant operands (n=10, m=2, no limits): the matrix recursion once per distinct λ, an affine chain per trajectory
+// (back_pass_sh.hip); 1 = not applicable; 0 = launched, the trajectories it left out are flagged in *fb_active
+int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                            const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                            const double *fu, const double *lambda, const int32_t *active, double *K,
+                            double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge,
+                            const int32_t **fb_active);
 
 // 16-lane DPP-row backward pass (4 trajectories per wave); returns 1 when the shape has no such kernel
 int ddp_launch_back_pass_dpp(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,

@@ -459,7 +459,7 @@ int ddp_df_f64_dev(ddp_handle h, const ddp_problem *p, const double *x, const do
         DDP_CHECK(p->n == 4 && p->m == 1, "df: pendcart needs n=4, m=1");
         DDP_CHECK(fx && fu, "df: pendcart needs fx and fu outputs");
         const dim3 grid((unsigned)((cols + 63) / 64)), block(64);
-        const char *de = getenv("DDP_DF_DENSE");                     // 1: the dense expm for every element (A/B timing, cross-check in the tests)
+        const char *de = ddp_env(h, ENV_DF_DENSE);                     // 1: the dense expm for every element (A/B timing, cross-check in the tests)
         int32_t *flag = h->sink ? (int32_t *)((char *)h->sink + 4096) : nullptr;     // the word behind the 4 KB the masked lanes may write
         const int v2 = ((((uintptr_t)fx | (uintptr_t)fu) & 15) == 0) ? 1 : 0;
 #define DDP_DFP(MODE_, GRID_) hipLaunchKernelGGL(df_pendcart_kernel<MODE_>, GRID_, block, 0, h->stream, p->N, p->B, p->g, p->l, p->h, p->d, p->goal[0], \

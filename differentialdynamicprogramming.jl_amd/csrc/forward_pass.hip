@@ -266,20 +266,21 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     // diff_fun with wrapped coordinates: only the run-time-sized kernel below implements it
     DDP_CHECK(p->diff_wrap == 0 || (p->n <= DDP_MAX_N_GENERIC && (p->n >= 32 || (p->diff_wrap >> p->n) == 0)),
               "forward_pass: ddp_problem.diff_wrap = 0x%x needs n <= %d and no bits at or above n = %d (zero-initialise the struct)", p->diff_wrap, DDP_MAX_N_GENERIC, p->n);
-    if (p->n > DDP_MAX_N_GENERIC || (p->diff_wrap == 0 && getenv("DDP_FORWARD") && getenv("DDP_FORWARD")[0] == 'b')) {   // large states
+    if (p->n > DDP_MAX_N_GENERIC || (p->diff_wrap == 0 && ddp_env(h, ENV_FORWARD) && ddp_env(h, ENV_FORWARD)[0] == 'b')) {   // large states
         const int rc = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { h->last_kernel[1] = "forward_big_kernel"; return rc; }
         DDP_CHECK(p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d has no kernel", p->n, p->m);
     }
     // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
-    const char *fwd_env = getenv("DDP_FORWARD");               // read per call so tests can switch paths
+    const char *fwd_env = ddp_env(h, ENV_FORWARD);               // read per call so tests can switch paths
     const bool force_group = (fwd_env && fwd_env[0] == 103) || p->diff_wrap != 0;
     if (!force_group) {
         const int rp = ddp_launch_forward_pipe(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
-        if (rp <= 0) return rp;
+        if (rp <= 0) { h->last_kernel[1] = "forward_pipe_kernel"; return rp; }
         const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
-        if (rc <= 0) return rc;
+        if (rc <= 0) { h->last_kernel[1] = "forward_dpp_kernel"; return rc; }
     }
+    h->last_kernel[1] = "forward_pass_kernel";
     FPArgs a;
     a.n = p->n; a.m = p->m; a.N = p->N; a.B = p->B; a.nalpha = nalpha;
     a.dyn_tv = p->dyn_tv; a.dyn_batched = p->dyn_batched; a.has_policy = K != nullptr; a.has_lims = lims != nullptr;

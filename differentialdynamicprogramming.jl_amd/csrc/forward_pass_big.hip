@@ -344,7 +344,7 @@ int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, 
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.xnew = xnew; a.unew = unew; a.cnew = cnew; a.csum = csum;
     const dim3 grid((unsigned)((long)p->B * nalpha)), block(DDP_WAVE);
-    const char *env = getenv("DDP_FORWARD64");                       // DDP_FORWARD64=0: run-time-sized kernels also at n = 64, m = 8
+    const char *env = ddp_env(h, ENV_FORWARD64);                       // DDP_FORWARD64=0: run-time-sized kernels also at n = 64, m = 8
     if (p->n == 64 && p->m == 8 && !(env && env[0] == '0')) {
         // up to 4 step sizes of a trajectory per wave (operands fetched once); a single α keeps the one-rollout instantiation
         const int na = nalpha >= 3 ? 4 : (nalpha == 2 ? 2 : 1);

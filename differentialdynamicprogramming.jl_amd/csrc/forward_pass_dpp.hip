@@ -699,7 +699,7 @@ int launch_dpp(ddp_handle h, const FDArgs &a)
     const long total = (long)a.B * a.nalpha;
     const int gpw = DDP_WAVE / 16;
     const dim3 grid((unsigned)((total + gpw - 1) / gpw)), block(DDP_WAVE);
-    const char *fv = getenv("DDP_FORWARD_FAST");                // 0: the variant with the run-time dyn_tv test and masked stores (A/B, tests)
+    const char *fv = ddp_env(h, ENV_FORWARD_FAST);                // 0: the variant with the run-time dyn_tv test and masked stores (A/B, tests)
     const bool al16 = MS != 2 || ((((uintptr_t)a.u | (uintptr_t)a.k | (uintptr_t)a.K) & 15) == 0);     // 16-byte loads of ū_i, k_i, K_i[:, j]
     if (a.has_policy && !a.dyn_tv && a.sink && al16 && !(fv && fv[0] == '0')) {
         if (a.has_lims) hipLaunchKernelGGL((forward_dpp_kernel<KIND, NS, MS, true, true, FUSE, true>), grid, block, 0, h->stream, a);
@@ -749,12 +749,12 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
     a.xnew = xnew; a.unew = unew; a.sink = (double *)h->sink;
-    const char *fuse_env = getenv("DDP_FORWARD_FUSE");           // 0: keep the separate cost kernel (A/B timing, tests)
+    const char *fuse_env = ddp_env(h, ENV_FORWARD_FUSE);           // 0: keep the separate cost kernel (A/B timing, tests)
     const bool fuse = p->cost_diag != 0 && !(fuse_env && fuse_env[0] == '0');     // Q, R declared diagonal: cost inside the rollout kernel
     a.Q = p->Q; a.R = p->R; a.cnew = cnew; a.csum = csum;
     for (int i = 0; i < 4; ++i) a.goal[i] = p->goal[i];
     int rc;
-    const char *lane_env = getenv("DDP_FORWARD_LANE");          // 1 / 0 forces the lane-per-rollout pendcart kernel on / off
+    const char *lane_env = ddp_env(h, ENV_FORWARD_LANE);          // 1 / 0 forces the lane-per-rollout pendcart kernel on / off
     const long total = (long)p->B * nalpha;
     const bool lane = !lq && (lane_env ? lane_env[0] == '1' : total >= 3L * 4096);       // at least ~3 rollouts per lane of a row kernel wave
     if (lane) {
@@ -774,7 +774,7 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
 #undef DDP_LANE
         DDP_HIP(hipGetLastError());
         rc = 0;
-    } else if (!lq && a.sink && !(getenv("DDP_FORWARD_PEND") && getenv("DDP_FORWARD_PEND")[0] == '0')) {
+    } else if (!lq && a.sink && !(ddp_env(h, ENV_FORWARD_PEND) && ddp_env(h, ENV_FORWARD_PEND)[0] == '0')) {
         // the pendulum's own row kernel (DDP_FORWARD_PEND=0: the generic row kernel, for A/B timing and the tests of both)
         rc = fuse ? launch_pend_row<true>(h, a) : launch_pend_row<false>(h, a);
     } else {

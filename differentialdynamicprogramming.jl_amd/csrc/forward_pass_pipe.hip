@@ -483,9 +483,9 @@ int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K,
                             const int32_t *active, double *xnew, double *unew, double *cnew, double *csum)
 {
     if (p->kind != DDP_PROBLEM_LQ || p->n != 10 || p->m != 2 || !K || lims || !p->cost_diag || !h->sink) return 1;
-    const char *env = getenv("DDP_FORWARD_PIPE");               // 0: never, 1: whenever the shape allows (A/B timing, tests)
+    const char *env = ddp_env(h, ENV_FORWARD_PIPE);               // 0: never, 1: whenever the shape allows (A/B timing, tests)
     if (env && env[0] == '0') return 1;
-    const char *fuse_env = getenv("DDP_FORWARD_FUSE");
+    const char *fuse_env = ddp_env(h, ENV_FORWARD_FUSE);
     if (fuse_env && fuse_env[0] == '0') return 1;
     const long total = (long)p->B * nalpha;
     // one work-group (4 rollouts) per CU: with two the chain waves share their SIMDs and the pass is no faster than the row kernel

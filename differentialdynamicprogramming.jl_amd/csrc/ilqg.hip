@@ -458,12 +458,12 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
     //    DDP_ILQG_COMPACT=0: never;  =k (k > 1): whenever a working set of >= k slots is half empty.
     //  * line search in groups: the reference stops at the first accepted step size (iLQG.jl:267-281); groups [0,1) [1,3) [3,n_alpha)
     //    roll the later step sizes out only for the trajectories whose search is still open.  DDP_ILQG_LSGROUPS=0 / 1: never / always.
-    const char *cenv = getenv("DDP_ILQG_COMPACT");
+    const char *cenv = ddp_env(h, ENV_ILQG_COMPACT);
     bool may_compact = !(cenv && cenv[0] == '0') && !(p->kind == DDP_PROBLEM_LQ && p->dyn_batched);
     // trajectories per wave of the backward kernel the dispatcher picks (back_pass.hip) -> slots that make two waves per SIMD
     const double tpw = (n == 4 && m == 1) ? 4.0 : (n == 10 && m == 2) ? (B < 5120 ? 1.0 : 4.0) : (n > DDP_MAX_N_GENERIC ? 0.25 : 1.0);
     const size_t min_slots = (cenv && atoi(cenv) > 1) ? (size_t)atoi(cenv) : (size_t)(2048.0 * tpw);
-    const char *genv = getenv("DDP_ILQG_LSGROUPS");
+    const char *genv = ddp_env(h, ENV_ILQG_LSGROUPS);
     const double rpw = pend ? 64.0 : (n <= 16 ? 4.0 : 1.0);                       // rollouts per wave of the forward kernels
     // Measured: it pays where the rollouts of all step sizes together are throughput-bound (two waves per SIMD and more) AND the first
     // step size is usually accepted, as in the linear-quadratic family (1 024 n=10 solves with 11 step sizes: 15.7 -> 10.6 ms); the
@@ -496,7 +496,7 @@ static int ilqg_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo
                                al(m * m * N * R * 8) + al(n * N * R * 8) + al(n * n * N * R * 8) + al(n * R * 8) + 4 * al(R * 8) + 12 * al(R * 4) +
                                al(Bw * 4) + 256;
             void *blk = nullptr;
-            if (getenv("DDP_TEST_COMPACT_ALLOC_FAIL") || hipMalloc(&blk, w_d) != hipSuccess) {      // (the variable: tests of this path)
+            if (ddp_env(h, ENV_TEST_COMPACT_ALLOC_FAIL) || hipMalloc(&blk, w_d) != hipSuccess) {      // (the variable: tests of this path)
                 (void)hipGetLastError();                         // clear the sticky error: the solve goes on with the current working set
                 may_compact = false;
                 continue;

@@ -663,7 +663,7 @@ int ddp_back_pass_gps_f64_dev(ddp_handle h, const ddp_bp_desc *d,
     DDP_CHECK(h && d && cx && cu && cxx && cxu && cuu && fx && fu && kl && K && k && Quu && Quui && Vx && Vxx && dV && diverge,
               "back_pass_gps: null argument");
     DDP_HIP(hipMemsetAsync(Quui, 0, sizeof(double) * (size_t)d->m * d->m * d->N * d->B, h->stream));
-    const char *env = getenv("DDP_GPS_LANE");                     // 0: always the run-time-sized kernel (cross-check in the tests)
+    const char *env = ddp_env(h, ENV_GPS_LANE);                     // 0: always the run-time-sized kernel (cross-check in the tests)
     if (!(env && env[0] == '0') && kl && kl->cx && kl->cu && kl->cxx && kl->cxu && kl->cuu && kl->eta && (!d->has_lims || (lims && u))) {
         const int r4 = ddp_launch_back_pass_gps_q4(h, d, cx, cu, cxx, cxu, cuu, fx, fu, kl, lims, u, active, K, k, Quu, Quui, Vx, Vxx, dV, diverge);
         if (r4 <= 0) return r4;                                   // n = 4, m = 1, one η per trajectory: the matrix-core kernel (DDP_GPS_Q4=0: not)
@@ -679,10 +679,10 @@ int ddp_forward_covariance_f64_dev(ddp_handle h, int n, int m, int N, int B, con
     DDP_DEVICE(h);
     DDP_CHECK(h && fx && R1 && K && Sigma && sigmanew, "forward_covariance: null argument");
     DDP_CHECK(n >= 1 && n <= NMAXK && m >= 1 && m <= MMAXK && N >= 1 && B >= 1, "forward_covariance: bad sizes n=%d m=%d N=%d B=%d", n, m, N, B);
-    const char *q4env = getenv("DDP_FCOV_Q4");                     // 0: the run-time-sized kernel for every shape (cross-check in the tests)
+    const char *q4env = ddp_env(h, ENV_FCOV_Q4);                     // 0: the run-time-sized kernel for every shape (cross-check in the tests)
     if (n == 4 && (m == 1 || m == 2) && h->sink && !(q4env && q4env[0] == '0')) {
         const dim3 grid((unsigned)((B + 3) / 4)), block(DDP_WAVE);
-        const char *le = getenv("DDP_FCOV_Q4L");                     // 0: the step-by-step kernel (A/B timing, cross-check in the tests)
+        const char *le = ddp_env(h, ENV_FCOV_Q4L);                     // 0: the step-by-step kernel (A/B timing, cross-check in the tests)
         const bool al16 = ((((uintptr_t)fx | (uintptr_t)K | (uintptr_t)Sigma | (uintptr_t)sigmanew) & 15) == 0);
         if (m == 1 && N % FQL_CH == 0 && N >= 2 * FQL_CH && al16 && B <= 6144 && !(le && le[0] == '0'))
             hipLaunchKernelGGL(fcov_q4l_kernel, grid, block, 0, h->stream, N, B, fx, fx_batched, R1, K, Sigma, sigmanew, (double *)h->sink);
@@ -708,7 +708,7 @@ int ddp_kl_div_f64_dev(ddp_handle h, int n, int m, int N, int B, const double *x
     const int lens[10] = {n, n, (n + m) * (n + m), n * m, m, m * m, n * m, m, m * m, m * m};
     size_t image = 0;
     for (int l : lens) image += (size_t)(l | 1) * DDP_WAVE * sizeof(double);
-    const char *lenv = getenv("DDP_KL_LDS");
+    const char *lenv = ddp_env(h, ENV_KL_LDS);
     if (image <= 48 * 1024 && !(lenv && lenv[0] == '0')) {
         const double *ptr[10] = {xnew, xold, sigmanew, Kn, kn, Sn, Kp, kp, Sp, Sip};
         KlSrc a[10];

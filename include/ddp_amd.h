@@ -39,6 +39,12 @@ int  ddp_create(int device, ddp_handle *out);
 int  ddp_create_with_stream(int device, void *hip_stream, ddp_handle *out);
 int  ddp_destroy(ddp_handle h);
 int  ddp_sync(ddp_handle h);
+/* The DDP_* environment switches (kernel choice for A/B timing and for the tests that force every code path; none is needed in
+ * production) are read ONCE, in ddp_create(); no launch calls getenv().  ddp_reload_env() reads them again for this handle.          */
+int  ddp_reload_env(ddp_handle h);
+/* name of the kernel the last back_pass (which = 0) / forward_pass (which = 1) dispatch of this handle launched ("" before the first
+ * one): a debug query — the tests assert through it that the timed path is the one they checked                                    */
+const char *ddp_last_kernel(ddp_handle h, int which);
 void *ddp_stream(ddp_handle h);                 /* the hipStream_t of the handle */
 /* device memory helpers for hosts without their own allocator (the Julia wrapper, tests) */
 int  ddp_malloc(ddp_handle h, size_t bytes, void **dptr);

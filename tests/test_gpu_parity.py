@@ -230,6 +230,41 @@ def test_full_size_c2_properties(ddp):
     par_map(check, range(B))
 
 
+def test_full_size_c2_the_timed_step(ddp):
+    """EXACTLY the step bench.py times (BASELINE config 2: B = 1024, N = 1000, λ = 1, regType 1, then forward_pass(α = 1)), default
+    dispatch — asserted through ddp_last_kernel: the shared-LTI backward kernel and the pipeline rollout — every one of the 1 024
+    trajectories against the oracle (src/backward_pass.jl:217-252, src/forward_pass.jl:9-33)"""
+    from ddp_amd import _lib
+    from oracle import np_restatement as npr
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(1234)
+    n, m, N, B = 10, 2, 1000, 1024
+    P = npr.make_lq_problem(rng)
+    prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
+    u0 = 0.1 * rng.standard_normal((m, N, B))
+    x, u, c = ddp.forward_pass(ddp.GaussianPolicy(), x0, u0, None, 1.0, prob, None)
+    cx = np.einsum("ij,jtb->itb", P["Q"], x); cu = np.einsum("ij,jtb->itb", P["R"], u)
+    div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, P["Q"], np.zeros((n, m)), P["R"], P["A"], P["B"], 1.0, 1, None, x, u)
+    assert _lib.default_handle().last_kernel(0) == "sh_back_kernel"
+    xn, un, cn = ddp.forward_pass(pol, x0, u, x, 1.0, prob, None)
+    assert _lib.default_handle().last_kernel(1) == "forward_pipe_kernel"
+    assert not div.any()
+    assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2, 3)))
+    p = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=P["Q"], R=P["R"])
+
+    def check(b):
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], P["Q"], np.zeros((n, m)), P["R"], P["A"], P["B"], 1.0, 1,
+                                                  None, x[..., b], u[..., b])
+        assert d == 0
+        for got, ref, name in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (Vxx[..., b], vxx, "Vxx"), (Vx[..., b], vx, "Vx"),
+                               (pol.Σi[..., b], Quu, "Quu"), (dV[:, b], dv, "dV")):
+            assert relerr(got, ref) < RTOL, (name, b)
+        xr, ur, cr = oc.forward_pass(p, (K, k), x0[:, b], u[..., b], x[..., b], 1.0, None)
+        assert relerr(xn[..., b], xr) < RTOL and relerr(un[..., b], ur) < RTOL and relerr(cn[..., b], cr) < RTOL, b
+    par_map(check, range(B))
+
+
 # ------------------------------------------------------------------ every kernel implementation of back_pass
 def _tv_problem(rng, n, m, N, B):
     import scipy.linalg as sla
