@@ -230,7 +230,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run,
+        # exactly the command line the driver uses) and pass their output through — rank 0 of the children prints the one JSON line
+        return spawn_ranks(args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     backend = os.environ.get("DDP_BENCH_BACKEND", "nccl")   # "gloo": test mode — several ranks may share one GPU (RCCL refuses that), the
     local = local % torch.cuda.device_count() if backend == "gloo" else local     # statistics vector travels through host memory
@@ -349,6 +351,7 @@ def main():
                           "batch_per_gpu": B, "n": n, "m": m, "N": N, "sharding": "batch (independent trajectories), "
                           "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1 (issued by %s)" % ("the C ABI, ddp_allreduce_stats_f64_dev" if args.collective == "capi" else "torch.distributed")},
                "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill, "full_line_search": ls, "other_configs": other}
+        out["n_ranks_seen"] = dist.get_world_size() if use_dist else 1     # from the communicator, not from the command line
         if use_dist:
             # the vector the ranks share per step (Σ new cost, Σ dV[1], Σ dV[2], #diverged — summed over the ranks) after the last step
             out["collective"] = {"issued_by": args.collective, "stats": [float(v) for v in stats_vec]}
@@ -361,6 +364,23 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the host driver only supports dmabuf IPC (RCCL across processes)
+    r = subprocess.run(cmd, env=env)
+    if r.returncode != 0:
+        raise SystemExit(r.returncode)
+    return None
 
 
 def measure_traffic(kernel, B, N):

@@ -135,6 +135,10 @@ const _default = Ref{Union{Nothing,Handle}}(nothing)
 default_handle() = (_default[] === nothing && (_default[] = Handle(0)); _default[]::Handle)
 sync(h::Handle=default_handle()) = check(@ccall libddp.ddp_sync(h.ptr::Ptr{Cvoid})::Cint)
 device_count() = Int(@ccall libddp.ddp_device_count()::Cint)
+"re-read the DDP_* switches (kernel choice for A/B timing / tests) for this handle; they are read once, in ddp_create"
+reload_env(h::Handle=default_handle()) = check(@ccall libddp.ddp_reload_env(h.ptr::Ptr{Cvoid})::Cint)
+"kernel of the last back_pass (0) / forward_pass (1) dispatch of the handle (debug query)"
+last_kernel(which::Integer=0; handle::Handle=default_handle()) = unsafe_string(@ccall libddp.ddp_last_kernel(handle.ptr::Ptr{Cvoid}, which::Cint)::Cstring)
 
 """
     result_array(dims...) -> Array{Float64}
@@ -152,6 +156,36 @@ function result_array(dims::Integer...)
     a = unsafe_wrap(Array, Ptr{Float64}(r[]), d; own=false)
     finalizer(x -> (@ccall libddp.ddp_host_free(pointer(x)::Ptr{Cvoid})::Cint), a)
     return a
+end
+
+"""
+    result_pair(work_dims, final_dims) -> (work, final)
+
+A result that is handed to the C call with one shape (`work`, batch / step-size axes included) and returned to the caller with another
+(`final`, singleton axes dropped).  `reshape` / `dropdims` of a pinned `result_array` must NOT be used for that: from Julia 1.11 on a
+reshaped `Array` shares the `Memory`, not the wrapper object the finalizer sits on, so the wrapper could be collected — and the block
+handed back to the library's cache and overwritten by the next call of the same size — while the caller still holds the reshaped
+result.  Here both shapes are wrappers of the same block made at allocation time; the block is freed when the LAST of them is
+collected (a shared atomic count).  Small results are ordinary GC memory, where `reshape` is safe.
+"""
+function result_pair(work::Tuple, final::Tuple)
+    w = map(Int, work); f = map(Int, final)
+    prod(w) == prod(f) || error("result_pair: shapes differ in length")
+    nbytes = prod(w) * sizeof(Float64)
+    if nbytes < (1 << 20) || get(ENV, "DDP_PINNED_RESULTS", "1") == "0"
+        z = zeros(w...)
+        return z, (w == f ? z : reshape(z, f))
+    end
+    w == f && (a = result_array(w...); return a, a)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(@ccall libddp.ddp_host_alloc(nbytes::Csize_t, r::Ptr{Ptr{Cvoid}})::Cint)
+    ptr = r[]
+    live = Threads.Atomic{Int}(2)
+    release = _ -> (Threads.atomic_sub!(live, 1) == 1 && (@ccall libddp.ddp_host_free(ptr::Ptr{Cvoid})::Cint); nothing)
+    a = unsafe_wrap(Array, Ptr{Float64}(ptr), w; own=false)
+    b = unsafe_wrap(Array, Ptr{Float64}(ptr), f; own=false)
+    finalizer(release, a); finalizer(release, b)
+    return a, b
 end
 
 # ---- output container (src/iLQG.jl:39-53); with a batch the arrays carry a trailing axis ------------
@@ -317,7 +351,10 @@ function forward_pass(traj_new, x0, u, x, α, problem::RegisteredProblem, lims, 
     empty = _isempty_policy(traj_new)
     al = α isa Number ? [Float64(α)] : _f64(α)
     na = length(al)
-    xnew = result_array(n, N, B, na); unew = result_array(m, N, B, na); cnew = result_array(CL, B, na); csum = zeros(B, na)
+    # the shapes the caller gets: batch axis only when batched, step-size axis only for a vector α (forward_pass.jl:9-33 returns [n,N])
+    fin(lead...) = (lead..., (batched ? (B,) : ())..., (α isa Number ? () : (na,))...)
+    xnew, xnew_r = result_pair((n, N, B, na), fin(n, N)); unew, unew_r = result_pair((m, N, B, na), fin(m, N))
+    cnew, cnew_r = result_pair((CL, B, na), fin(CL)); csum = zeros(B, na)
     x0 = _f64(x0); u = _f64(u)
     Kh = empty ? Float64[] : _f64(traj_new.K); kh = empty ? Float64[] : _f64(traj_new.k); xh = empty ? Float64[] : _f64(x)
     limsp = _lims(lims)
@@ -327,12 +364,7 @@ function forward_pass(traj_new, x0, u, x, α, problem::RegisteredProblem, lims, 
             na::Cint, _ptr_or_null(limsp)::Ptr{Float64},
             xnew::Ptr{Float64}, unew::Ptr{Float64}, cnew::Ptr{Float64}, csum::Ptr{Float64})::Cint)
     end
-    sel(a) = (batched ? a : dropdims(a, dims=ndims(a) - 1))
-    xnew, unew, cnew = sel(xnew), sel(unew), sel(cnew)
-    if α isa Number
-        xnew, unew, cnew = map(a -> dropdims(a, dims=ndims(a)), (xnew, unew, cnew))
-    end
-    return xnew, unew, cnew
+    return xnew_r, unew_r, cnew_r
 end
 
 """
@@ -719,8 +751,11 @@ function iLQGkl(problem::RegisteredProblem, x0, traj_prev, fx_model, R1; kl_step
     size(etab) == (3, B) || error("ηbracket must be a 3-vector or 3×B")
     limsp = _lims(lims)
     o = ILQGKLOpts(kl_step, max_iter, (1e-8, 1.0, 1e16), del0)
-    x = result_array(n, N, B); u = result_array(m, N, B); K = result_array(m, n, N, B); S = result_array(m, m, N, B); Si = result_array(m, m, N, B)
-    Vx = result_array(n, N, B); Vxx = result_array(n, n, N, B); cnew = result_array(CL, B); dV = zeros(2, B); st = zeros(12, B)
+    bt = batched ? (B,) : ()                                     # unbatched: the caller's arrays have no batch axis (result_pair, not dropdims)
+    x, x_r = result_pair((n, N, B), (n, N, bt...)); u, u_r = result_pair((m, N, B), (m, N, bt...)); K, K_r = result_pair((m, n, N, B), (m, n, N, bt...))
+    S, S_r = result_pair((m, m, N, B), (m, m, N, bt...)); Si, Si_r = result_pair((m, m, N, B), (m, m, N, bt...))
+    Vx, Vx_r = result_pair((n, N, B), (n, N, bt...)); Vxx, Vxx_r = result_pair((n, n, N, B), (n, n, N, bt...))
+    cnew, cnew_r = result_pair((CL, B), (CL, bt...)); dV = zeros(2, B); st = zeros(12, B)
     its = Ref{Cint}(0)
     GC.@preserve problem x0 c0 Kp u0 Sp Sip fxm R1 limsp etab x u K S Si Vx Vxx cnew dV st begin
         check(@ccall libddp.ddp_ilqgkl_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGKLOpts}, x0::Ptr{Float64},
@@ -732,10 +767,8 @@ function iLQGkl(problem::RegisteredProblem, x0, traj_prev, fx_model, R1; kl_step
     trace = Dict{Symbol,Any}(:status => Int.(st[1, :]), :iter => Int.(st[2, :]), :n_backpass => Int.(st[3, :]), :satisfied => st[4, :] .!= 0,
                              :η => etab, :divergence => st[8, :], :cost => st[9, :], :improvement => st[10, :],
                              :expected_reduction => st[11, :], :grad_norm => st[12, :], :dV => dV, :batch_iterations => Int(its[]))
-    sel(a) = batched ? a : dropdims(a, dims=ndims(a))
-    x, u, K, S, Si, Vx, Vxx, cnew = map(sel, (x, u, K, S, Si, Vx, Vxx, cnew))
-    traj_new = policy(N, n, m, K, copy(u), S, Si)                                                             # traj_new.k = copy(u) (:239)
-    return x, u, traj_new, Vx, Vxx, cnew, trace
+    traj_new = policy(N, n, m, K_r, copy(u_r), S_r, Si_r)                                                     # traj_new.k = copy(u) (:239)
+    return x_r, u_r, traj_new, Vx_r, Vxx_r, cnew_r, trace
 end
 
 end # module

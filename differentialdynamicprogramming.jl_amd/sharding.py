@@ -44,10 +44,10 @@ def stats_from_solve(stats, cost):
 
 def allreduce_stats(v, device=None):
     """all-reduce a statistics vector over the default torch.distributed group (no-op when not initialised)"""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    dist = _torch_dist()
+    if dist is None or dist.get_world_size() == 1:           # also the torch-absent, single-rank mode: nothing to import, nothing to reduce
         return np.asarray(v, dtype=np.float64)
+    import torch
     # ONE collective: gather the tiny vectors, reduce locally (SUM for the first N_SUM entries, MAX for the rest) — the same
     # scheme as ddp_allreduce_stats_f64_dev of the C ABI (csrc/comm.hip)
     t = torch.as_tensor(np.asarray(v, dtype=np.float64), device=device)
@@ -174,8 +174,18 @@ def solve_sharded(problem, x0, u0, *, solver=None, device=None, comm=None, handl
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     B = u0.shape[2]
     lo, hi = shard_range(B, rank, world)
-    if solver is None:
+    own_solver = solver is None
+    if own_solver:
         from . import iLQG as solver        # GPU path (raises without a GPU: no CPU fallback)
+        # ONE handle for the solve and for the collective: the caller's, or the default handle of this rank's device.  With per-rank
+        # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES isolation every rank sees its GPU as device 0; without it LOCAL_RANK names it.
+        if handle is None:
+            from . import default_handle
+            from . import _lib
+            local = int(os.environ.get("LOCAL_RANK", rank))
+            ndev = _lib.lib().ddp_device_count()
+            handle = default_handle(local if local < ndev else 0)
+        kw = dict(kw, handle=handle)
     res = solver(problem, np.ascontiguousarray(x0[:, lo:hi]), np.ascontiguousarray(u0[:, :, lo:hi]), **kw)
     x, u, pol, Vx, Vxx, cost, trace = res
     v = stats_from_solve(trace["stats"], cost)
@@ -183,8 +193,18 @@ def solve_sharded(problem, x0, u0, *, solver=None, device=None, comm=None, handl
         path = os.environ.get("DDP_COMM_ID_FILE")
         if not path:
             raise RuntimeError("solve_sharded without torch.distributed: pass comm=CApiComm(...) or name a shared file in DDP_COMM_ID_FILE")
-        from . import default_handle
-        handle = handle or default_handle(int(os.environ.get("LOCAL_RANK", rank)))
+        if handle is None:
+            from . import default_handle
+            from . import _lib
+            local = int(os.environ.get("LOCAL_RANK", rank))
+            handle = default_handle(local if local < _lib.lib().ddp_device_count() else 0)
         comm = CApiComm(handle, rank, world, exchange=file_exchange(path, rank))
+        if rank == 0:
+            # every rank has the id once the communicator exists (ddp_comm_create is collective): a path that is reused by a later
+            # job must not hand that job a stale id
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
     g = comm.allreduce_host(v, N_SUM) if comm is not None else allreduce_stats(v, device=device)
     return res, dict(zip(STAT_NAMES, g)), (lo, hi)

@@ -64,3 +64,43 @@ def test_one_rank_collective_torch_and_capi_agree():
     assert len(sa) == 4 and sa[3] == 0.0 and sa[0] > 0.0
     assert all(abs(x - y) <= 1e-12 * max(1.0, abs(x)) for x, y in zip(sa, sb)), (sa, sb)
     assert b["collective"]["rccl_version"] >= 21800 and b["collective"]["rccl_instance"].startswith("the one already resident")
+
+
+@pytest.mark.gpu
+def test_bare_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the way the driver calls `--gpus 1`): bench.py starts its two ranks itself under
+    torch.distributed.run and rank 0 prints the one line.  Test mode: gloo (two ranks may share the box's single GPU, RCCL refuses
+    that); `n_ranks_seen` comes from the communicator."""
+    env = dict(os.environ, DDP_BENCH_BACKEND="gloo", DDP_BENCH_REHEARSALS="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--preheat", "0", "--batch", "256",
+                        "--no-cpu-baseline", "--no-other-configs", "--fill-batch", "0", "--no-traffic"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak" and d["steps"] == 4
+    assert abs(d["value"] - 2 * 256 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-3 * d["value"]             # whole-job units / max-over-ranks time
+    assert len(d["collective"]["stats"]) == 4 and d["collective"]["stats"][0] > 0.0
+
+
+def test_spawn_ranks_builds_the_driver_command(monkeypatch):
+    """CPU: the command line bench.py hands to subprocess when it is asked for N GPUs without a launcher"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert bench.spawn_ranks(4) is None
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert cmd[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -120,3 +120,13 @@ def test_solve_sharded_without_torch_distributed_uses_the_capi_comm(monkeypatch)
     monkeypatch.delenv("DDP_COMM_ID_FILE", raising=False)
     with pytest.raises(RuntimeError, match="DDP_COMM_ID_FILE"):
         sharding.solve_sharded(P, x0, u0, solver=_oracle_solver)
+
+
+def test_allreduce_stats_single_rank_needs_no_torch(monkeypatch):
+    """the torch-absent mode the docstring of solve_sharded promises: one rank, no process group -> the vector comes back as it is and
+    torch is not even imported"""
+    import sys
+    monkeypatch.setitem(sys.modules, "torch", None)               # `import torch` now raises ImportError
+    monkeypatch.setitem(sys.modules, "torch.distributed", None)
+    v = np.arange(len(sharding.STAT_NAMES), dtype=float)
+    assert np.array_equal(sharding.allreduce_stats(v), v)
