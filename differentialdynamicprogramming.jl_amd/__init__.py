@@ -493,3 +493,72 @@ def iLQG(problem, x0, u0, *, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad
         return x[..., 0], u[..., 0], pol, Vx[..., 0], Vxx[..., 0], cost[:, 0], trace
     pol = GaussianPolicy(N, n, m, K, k, np.zeros((m, m, N, B)), Quu)
     return x, u, pol, Vx, Vxx, cost, trace
+
+
+def _ilqg_opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min):
+    o = _lib.ILQGOpts()
+    _lib.lib().ddp_ilqg_default_opts(_C.byref(o))
+    o.lambda_, o.dlambda, o.lambda_factor, o.lambda_max, o.lambda_min = λ, dλ, λfactor, λmax, λmin
+    o.tol_fun, o.tol_grad, o.max_iter, o.regType, o.reduce_ratio_min = tol_fun, tol_grad, max_iter, regType, reduce_ratio_min
+    alphas = np.asarray(α, dtype=np.float64)
+    if len(alphas) > 16:
+        raise ValueError("at most 16 line-search step sizes are supported")
+    o.n_alpha = len(alphas)
+    for i, a in enumerate(alphas):
+        o.alpha[i] = a
+    return o
+
+
+def iLQG_queue(problem, x0, u0, *, slots=0, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0,
+               λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0, diff_fun=None, handle=None):
+    """``P = u0.shape[2]`` independent solves of ``iLQG`` through ``slots`` resident trajectories (``ddp_ilqg_queue_f64``): a slot whose
+    solve has ended is flushed and armed with the next problem on the device, instead of idling until the slowest trajectory of a
+    lock-step batch has ended.  Every solve is the solve ``iLQG`` performs at batch size ``slots``.
+    Returns ``(x, u, traj_new, Vx, Vxx, cost, trace)`` with P columns; ``trace`` holds ``stats[8,P]``, ``status``, ``iter``, ``global_iters``."""
+    h = handle or default_handle()
+    u0, x0 = _lib.f64(u0), _lib.f64(x0)
+    if u0.ndim != 3 or x0.ndim != 2:
+        raise ValueError("iLQG_queue: x0[n,P], u0[m,N,P]")
+    m, N, P = u0.shape
+    n = x0.shape[0]
+    _check_problem(problem, n, m, N, P)
+    dp = _DevProblem(problem, N, P, diff_fun)
+    o = _ilqg_opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
+    L = _lims(lims)
+    CL = dp.cost_len
+    x = _lib.result_array((n, N, P)); u = _lib.result_array((m, N, P))
+    K = _lib.result_array((m, n, N, P)); k = _lib.result_array((m, N, P)); Quu = _lib.result_array((m, m, N, P))
+    Vx = _lib.result_array((n, N, P)); Vxx = _lib.result_array((n, n, N, P)); cost = _lib.result_array((CL, P))
+    stats = np.zeros((8, P), order="F")
+    git = _C.c_int(0)
+    t0 = _time.time()
+    _lib.check(_lib.lib().ddp_ilqg_queue_f64(h.raw, _C.byref(dp.struct), _C.byref(o), int(slots), _lib.ptr(x0), _lib.ptr(u0), _lib.ptr(L),
+                                             *map(_lib.ptr, (x, u, K, k, Quu, Vx, Vxx, cost, stats)), _C.byref(git)))
+    trace = dict(stats=stats, status=stats[0].astype(int), iter=stats[1].astype(int), λ=stats[5], grad_norm=stats[6],
+                 global_iters=git.value, time_total=_time.time() - t0)
+    return x, u, GaussianPolicy(N, n, m, K, k, np.zeros((m, m, N, P)), Quu), Vx, Vxx, cost, trace
+
+
+def iLQG_mpc(problem, x0, u0, steps, *, zero_tail=False, lims=None, α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0,
+             dλ=1.0, λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1, reduce_ratio_min=0.0, diff_fun=None, handle=None):
+    """Closed loop on the device (``ddp_ilqg_mpc_f64``): every trajectory of the batch is solved ``steps`` times; after each solve the
+    first control is applied (model = plant: the next initial state is ``x[:,1]`` of the solution), the control sequence is shifted by
+    one step (``mpc_shift``) and the problem is solved again without returning to the host.
+    Returns ``(xcl[n,steps+1,B], ucl[m,steps,B], stats[8,steps,B], x_plan[n,N,B], u_plan[m,N,B], global_iters)``."""
+    h = handle or default_handle()
+    u0, x0 = _lib.f64(u0), _lib.f64(x0)
+    if u0.ndim != 3 or x0.ndim != 2:
+        raise ValueError("iLQG_mpc: x0[n,B], u0[m,N,B]")
+    m, N, B = u0.shape
+    n = x0.shape[0]
+    _check_problem(problem, n, m, N, B)
+    dp = _DevProblem(problem, N, B, diff_fun)
+    o = _ilqg_opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
+    L = _lims(lims)
+    steps = int(steps)
+    xcl = np.zeros((n, steps + 1, B), order="F"); ucl = np.zeros((m, steps, B), order="F"); scl = np.zeros((8, steps, B), order="F")
+    x = _lib.result_array((n, N, B)); u = _lib.result_array((m, N, B))
+    git = _C.c_int(0)
+    _lib.check(_lib.lib().ddp_ilqg_mpc_f64(h.raw, _C.byref(dp.struct), _C.byref(o), steps, int(bool(zero_tail)), _lib.ptr(x0), _lib.ptr(u0),
+                                           _lib.ptr(L), *map(_lib.ptr, (xcl, ucl, scl, x, u)), _C.byref(git)))
+    return xcl, ucl, scl, x, u, git.value

@@ -24,7 +24,7 @@ EXPORTS = [
     "ddp_event_create", "ddp_event_destroy", "ddp_event_record", "ddp_event_elapsed_ms",
     "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
     "ddp_cost_len", "ddp_forward_pass_f64_dev", "ddp_forward_pass_f64", "ddp_df_f64_dev", "ddp_df_f64",
-    "ddp_ilqg_default_opts", "ddp_ilqg_f64", "ddp_ilqg_f64_dev", "ddp_ilqg_warm_f64", "ddp_ilqg_warm_f64_dev", "ddp_ilqg_ex_f64", "ddp_ilqg_ex_f64_dev", "ddp_ilqg_set_timing", "ddp_mpc_shift_f64_dev", "ddp_costfun_f64_dev", "ddp_batch_stats_f64_dev",
+    "ddp_ilqg_default_opts", "ddp_ilqg_f64", "ddp_ilqg_f64_dev", "ddp_ilqg_warm_f64", "ddp_ilqg_warm_f64_dev", "ddp_ilqg_ex_f64", "ddp_ilqg_ex_f64_dev", "ddp_ilqg_set_timing", "ddp_ilqg_queue_f64", "ddp_ilqg_queue_f64_dev", "ddp_ilqg_mpc_f64", "ddp_ilqg_mpc_f64_dev", "ddp_mpc_shift_f64_dev", "ddp_costfun_f64_dev", "ddp_batch_stats_f64_dev",
     "ddp_kl_terms_f64_dev", "ddp_kl_terms_f64", "ddp_back_pass_gps_f64_dev", "ddp_back_pass_gps_f64",
     "ddp_forward_covariance_f64_dev", "ddp_forward_covariance_f64", "ddp_kl_div_f64_dev", "ddp_kl_div_f64",
     "ddp_kl_dual_begin_f64_dev", "ddp_kl_dual_retry_f64_dev", "ddp_kl_dual_update_f64_dev",

@@ -63,7 +63,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
     h->device = device;
     h->scratch = nullptr;
     h->scratch_bytes = 0;
-    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr; h->sh = nullptr; h->sh_bytes = 0; h->sh_attr = false; h->ncu = 0; h->last_kernel[0] = h->last_kernel[1] = nullptr; ddp_reload_env(h);
+    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr; h->sh = nullptr; h->sh_bytes = 0; h->sh_attr = false; h->ncu = 0; h->sched_aux = nullptr; h->last_kernel[0] = h->last_kernel[1] = nullptr; ddp_reload_env(h);
     h->h_pinned = nullptr;
     h->timing = nullptr; h->timing_cap = 0; h->tev_ok = false;
     h->owns_stream = !adopt;
@@ -93,6 +93,7 @@ int ddp_destroy(ddp_handle h)
     if (h->sink) hipFree(h->sink);
     if (h->pad) hipFree(h->pad);
     if (h->sh) hipFree(h->sh);
+    if (h->sched_aux) { hipStreamDestroy(h->sched_aux); hipEventDestroy(h->sched_ev[0]); hipEventDestroy(h->sched_ev[1]); }
     if (h->tev_ok) for (int e = 0; e < 4; ++e) hipEventDestroy(h->tev[e]);
     if (h->owns_stream) hipStreamDestroy(h->stream);
     delete h;

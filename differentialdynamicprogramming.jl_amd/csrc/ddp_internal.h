@@ -28,6 +28,8 @@ struct ddp_handle_s {
     size_t       sh_bytes;
     bool         sh_attr;         // its dynamic-LDS attribute has been set on this device
     int          ncu;             // compute units of the device (0: not asked yet)
+    hipStream_t  sched_aux;       // ilqg.hip, slot scheduler: side stream of the initial rollouts + its two events (created on first use)
+    hipEvent_t   sched_ev[2];
     char         envv[ENV_COUNT][24];
     bool         envset[ENV_COUNT];
     const char  *last_kernel[2];  // what the last backward / forward dispatch launched (ddp_last_kernel)

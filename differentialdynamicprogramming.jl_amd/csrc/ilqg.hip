@@ -328,6 +328,144 @@ __global__ void stats_kernel(int B, Traj s, const int32_t *map, int only_finishe
     r[5] = s.lam[b]; r[6] = s.gnorm[b]; r[7] = s.csum[b];
 }
 
+
+// ---- slot scheduler (ddp_ilqg_queue_f64_dev, ddp_ilqg_mpc_f64_dev): S resident slots work through P >= S problems (queue), or every
+// slot re-solves its own problem `steps` times in closed loop (MPC: apply u_0, the model is the plant, shift, solve again).  A slot
+// whose solve has ended is flushed and re-armed ON THE DEVICE at the end of the global iteration in which it ended; the host only
+// polls the number of busy slots.  The state machine of a solve is the one of ilqg_impl (same kernels, same launches per global
+// iteration), so a solve does the arithmetic of its stand-alone solve at the same batch size.
+struct Sched {
+    int P, mpc_steps, zero_tail, nalpha;
+    double alpha[16];
+    double lam0, dlam0;
+    const double *x0g, *u0g;            // problems: x0[n,P], u0[m,N,P]
+    double *u0s, *us, *x0s;             // per slot: the control sequence the solve starts from, its scaled copy α·u0s, the initial state
+    int32_t *initm, *ai, *map, *left, *noflush, *ready;
+    int *qhead;
+    // results per problem (queue) / last plan per trajectory (MPC)
+    double *x, *u, *cost, *K, *k, *Quu, *Vx, *Vxx, *stats;
+    double *xcl, *ucl, *stats_cl;       // MPC: closed-loop states [n,steps+1,P], controls [m,steps,P], summaries [8,steps,P]
+};
+
+// end of a global iteration (and once before the first): flush the slots whose solve has ended, re-arm them — one wave per slot
+constexpr int TAKE_T = 256;                                      // threads per slot of sched_take_kernel
+__global__ __launch_bounds__(TAKE_T) void sched_take_kernel(int n, int m, int N, int CL, Sched q, WorkSet ws, int *counter)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    Traj &s = ws.s;
+    // the slot's state as every thread of the work-group sees it BEFORE anybody changes it
+    const int ready = q.ready[b], running = s.run[b], arming = q.initm[b], prob = q.map[b], left0 = q.left[b], nofl = q.noflush[b];
+    __syncthreads();
+    if (ready) {                                                   // its initial rollout (on the side stream) passed: the solve starts with
+        if (lane == 0) { q.ready[b] = 0; q.initm[b] = 0; s.run[b] = 1; s.dodf[b] = 1; atomicAdd(counter, 1); }     // the next global iteration
+        return;
+    }
+    if (running || arming) { if (lane == 0) atomicAdd(counter, 1); return; }
+    bool again = false;                                            // MPC: the same trajectory goes on
+    if (prob >= 0) {
+        const bool valid = !nofl;                                  // an initial divergence leaves nothing to copy (iLQG.jl:205-210)
+        const size_t t = (size_t)prob;
+        // (a finished solve leaves ~150 KB for n = 4, N = 600: 16-byte pieces where the sizes allow it)
+        auto cp = [&](double *d, const double *src, size_t per) {
+            double *dd = d + per * t; const double *ss = src + per * (size_t)b;
+            if (per % 2 == 0 && (((uintptr_t)dd | (uintptr_t)ss) & 15) == 0)
+                for (size_t e = lane; e < per / 2; e += TAKE_T) ((double2 *)dd)[e] = ((const double2 *)ss)[e];
+            else
+                for (size_t e = lane; e < per; e += TAKE_T) dd[e] = ss[e];
+        };
+        if (q.mpc_steps == 0) {
+            if (valid) {
+                cp(q.x, ws.x, (size_t)n * N); cp(q.u, ws.u, (size_t)m * N); cp(q.cost, ws.cost, (size_t)CL);
+                cp(q.K, ws.K, (size_t)m * n * N); cp(q.k, ws.k, (size_t)m * N); cp(q.Quu, ws.Quu, (size_t)m * m * N);
+                cp(q.Vx, ws.Vx, (size_t)n * N); cp(q.Vxx, ws.Vxx, (size_t)n * n * N);
+            }
+            if (lane == 0) {
+                double *r = q.stats + (size_t)DDP_ILQG_NSTATS * t;
+                r[0] = s.status[b]; r[1] = s.iter[b]; r[2] = s.acc[b]; r[3] = s.nbp[b]; r[4] = s.nfp[b]; r[5] = s.lam[b]; r[6] = s.gnorm[b];
+                r[7] = s.csum[b];
+            }
+        } else {
+            const int step = q.mpc_steps - left0;                   // 0-based index of the solve that has just ended
+            const double *xb = ws.x + (size_t)n * N * b, *ub = ws.u + (size_t)m * N * b;
+            if (lane == 0) {
+                double *r = q.stats_cl + (size_t)DDP_ILQG_NSTATS * ((size_t)q.mpc_steps * t + step);
+                r[0] = s.status[b]; r[1] = s.iter[b]; r[2] = s.acc[b]; r[3] = s.nbp[b]; r[4] = s.nfp[b]; r[5] = s.lam[b]; r[6] = s.gnorm[b];
+                r[7] = s.csum[b];
+            }
+            if (valid) {
+                for (int e = lane; e < n; e += TAKE_T) q.xcl[(size_t)n * ((size_t)(q.mpc_steps + 1) * t + step) + e] = xb[e];
+                for (int e = lane; e < m; e += TAKE_T) q.ucl[(size_t)m * ((size_t)q.mpc_steps * t + step) + e] = ub[e];
+                for (int e = lane; e < n; e += TAKE_T) q.xcl[(size_t)n * ((size_t)(q.mpc_steps + 1) * t + step + 1) + e] = xb[(N > 1 ? n : 0) + e];
+            }
+            const int left = left0 - 1;
+            again = valid && left > 0;                                // (a solve that diverged at its start ends the loop of its trajectory)
+            if (again) {
+                // the model is the plant: the next solve starts at x_1, from the shifted control sequence
+                double *u0b = q.u0s + (size_t)m * N * b;
+                for (size_t e = lane; e < (size_t)m * N; e += TAKE_T) {
+                    const size_t i = e / m, c = e % m;
+                    u0b[e] = (i + 1 < (size_t)N) ? ub[(i + 1) * m + c] : (q.zero_tail ? 0.0 : ub[(size_t)(N - 1) * m + c]);
+                }
+                for (int e = lane; e < n; e += TAKE_T) q.x0s[(size_t)n * b + e] = xb[(N > 1 ? n : 0) + e];
+            } else if (valid) {                                       // the last plan
+                cp(q.x, ws.x, (size_t)n * N); cp(q.u, ws.u, (size_t)m * N);
+            }
+            if (lane == 0) q.left[b] = left;
+        }
+    }
+    if (!again) {
+        // queue: the next problem; MPC: a slot takes a problem only at the initial fill (map == -1), afterwards it rests (map == -2)
+        __shared__ int head_s;
+        if (lane == 0) head_s = (prob != -2 && (q.mpc_steps == 0 || prob == -1)) ? atomicAdd(q.qhead, 1) : q.P;
+        __syncthreads();
+        const int head = head_s;
+        if (head >= q.P) { if (lane == 0) q.map[b] = -2; return; }
+        const double *u0p = q.u0g + (size_t)m * N * head;
+        double *u0b = q.u0s + (size_t)m * N * b;
+        for (size_t e = lane; e < (size_t)m * N; e += TAKE_T) u0b[e] = u0p[e];
+        for (int e = lane; e < n; e += TAKE_T) q.x0s[(size_t)n * b + e] = q.x0g[(size_t)n * head + e];
+        if (lane == 0) { q.map[b] = head; q.left[b] = q.mpc_steps; }
+    }
+    // arm the slot: the scalar state of a fresh solve (init_state_kernel), the first candidate of the initial rollout (iLQG.jl:181-192)
+    {
+        const double *u0b = q.u0s + (size_t)m * N * b;
+        double *usb = q.us + (size_t)m * N * b;
+        const double a0 = q.alpha[0];
+        for (size_t e = lane; e < (size_t)m * N; e += TAKE_T) usb[e] = a0 * u0b[e];
+    }
+    if (lane == 0) {
+        s.lam[b] = q.lam0; s.dlam[b] = q.dlam0; s.gnorm[b] = 0.0; s.csum[b] = 0.0;
+        s.status[b] = DDP_EXIT_RUNNING; s.iter[b] = 1; s.acc[b] = 1; s.nbp[b] = 0; s.nfp[b] = 0;
+        s.flg[b] = 1; s.run[b] = 0; s.dodf[b] = 0; s.dofwd[b] = 0; s.div0[b] = 1;
+        q.initm[b] = 1; q.ai[b] = 0; q.noflush[b] = 0;
+        atomicAdd(counter, 1);
+    }
+}
+
+// after the initial rollout of the armed slots and init_check_kernel: bounded -> the solve starts; else the next α, or the end (:205-210)
+__global__ __launch_bounds__(64) void sched_init_advance_kernel(int m, int N, Sched q, Traj s)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (!q.initm[b] || q.ready[b]) return;
+    if (!s.div0[b]) {
+        // bounded: hand the slot to the main stream's kernels through sched_take_kernel (this kernel runs beside df / back_pass / the
+        // line search of the running slots, whose masks must not change under them)
+        if (lane == 0) q.ready[b] = 1;
+        return;
+    }
+    const int ai = q.ai[b] + 1;
+    if (ai < q.nalpha) {
+        const double *u0b = q.u0s + (size_t)m * N * b;
+        double *usb = q.us + (size_t)m * N * b;
+        const double a = q.alpha[ai];
+        for (size_t e = lane; e < (size_t)m * N; e += 64) usb[e] = a * u0b[e];
+        if (lane == 0) q.ai[b] = ai;
+    } else if (lane == 0) {
+        q.initm[b] = 0; q.noflush[b] = 1;                              // (run stays 0: the slot is flushed and re-armed by the next sched_take_kernel)
+        s.status[b] = DDP_EXIT_INIT_DIVERGED; s.dodf[b] = 0; s.div0[b] = 0;
+    }
+}
+
 }   // namespace
 
 extern "C" {
@@ -598,6 +736,182 @@ int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opt
     return ilqg_impl(h, p, oo, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, trace_cap, trace_cost, global_iters, true, cost0);
 }
 
+// ---- the slot scheduler (kernels above).  S slots, P problems (queue: P >= S; MPC: S == P, `steps` solves per trajectory).
+static int ilqg_sched_impl(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *oo, int slots, int mpc_steps, int zero_tail,
+                           const double *x0, const double *u0, const double *lims, double *x, double *u, double *K, double *k,
+                           double *Quu, double *Vx, double *Vxx, double *cost, double *stats, double *xcl, double *ucl,
+                           double *stats_cl, int *global_iters)
+{
+    DDP_DEVICE(h);
+    DDP_CHECK(h && p && x0 && u0 && x && u, "ilqg_sched: null argument");
+    ddp_ilqg_opts od;
+    if (!oo) { ddp_ilqg_default_opts(&od); oo = &od; }
+    DDP_CHECK(oo->n_alpha >= 1 && oo->n_alpha <= 16, "ilqg_sched: n_alpha=%d out of [1,16]", oo->n_alpha);
+    const size_t n = p->n, m = p->m, N = p->N, P = p->B, na = oo->n_alpha, CL = ddp_cost_len(p);
+    const bool pend = p->kind == DDP_PROBLEM_PENDCART, mpc = mpc_steps > 0;
+    DDP_CHECK(N >= 2, "ilqg_sched: N=%d (at least two time steps)", (int)N);
+    if (mpc) slots = (int)P;                                            // every trajectory keeps its slot
+    if (slots <= 0 || (size_t)slots > P) slots = (int)(P < 4096 ? P : 4096);
+    const size_t S = (size_t)slots;
+    DDP_CHECK(!(p->kind == DDP_PROBLEM_LQ && p->dyn_batched) || mpc, "ilqg_queue: per-trajectory dynamics (dyn_batched) are not supported by the queue");
+    DDP_CHECK(mpc ? (xcl && ucl && stats_cl) : (K && k && Quu && Vx && Vxx && cost && stats), "ilqg_sched: null output");
+
+    // ---- one block: working set of S slots, derivative / candidate workspace, scheduler state
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t f_x = al(n * N * S * 8), f_u = al(m * N * S * 8), f_c = al(CL * S * 8), f_K = al(m * n * N * S * 8), f_Q = al(m * m * N * S * 8),
+                 f_V = al(n * n * N * S * 8), f_fx = pend ? al(n * n * N * S * 8) : 0, f_fu = pend ? al(n * m * N * S * 8) : 0,
+                 f_d = al(S * 8), f_i = al(S * 4);
+    const size_t bytes = 2 * f_x /* x, Vx */ + 2 * f_u /* u, k */ + f_c + f_K + f_Q + f_V + al(n * S * 8) /* x0s */ + 2 * f_u /* u0s, us */ +
+                         f_x + f_u /* cx, cu */ + f_fx + f_fu + na * (f_x + f_u + f_c + f_d) /* candidates */ + (f_x + f_u + f_c + f_d) /* initial rollout */ +
+                         al(2 * S * 8) + f_i /* dV, div */ + al(n * m * 8) + 4 * f_d + 10 * f_i /* Traj */ + 6 * f_i /* scheduler */ + 2 * f_i /* more */ + 512;
+    void *blk = nullptr;
+    DDP_HIP(hipMalloc(&blk, bytes));
+    struct Free { void *q; ~Free() { hipFree(q); } } free_blk{blk};
+    char *pp = (char *)blk;
+    auto take = [&](size_t b) { void *r = pp; pp += b; return r; };
+    WorkSet ws;
+    ws.x = (double *)take(f_x); ws.Vx = (double *)take(f_x); ws.u = (double *)take(f_u); ws.k = (double *)take(f_u); ws.cost = (double *)take(f_c);
+    ws.K = (double *)take(f_K); ws.Quu = (double *)take(f_Q); ws.Vxx = (double *)take(f_V); ws.x0 = (double *)take(al(n * S * 8));
+    double *u0s = (double *)take(f_u), *us = (double *)take(f_u);
+    double *cx = (double *)take(f_x), *cu = (double *)take(f_u), *fxw = pend ? (double *)take(f_fx) : nullptr, *fuw = pend ? (double *)take(f_fu) : nullptr;
+    double *xn = (double *)take(na * f_x), *un = (double *)take(na * f_u), *cn = (double *)take(na * f_c), *cs = (double *)take(na * f_d);
+    double *xi = (double *)take(f_x), *ui = (double *)take(f_u), *ci = (double *)take(f_c), *csi = (double *)take(f_d);
+    double *dV = (double *)take(al(2 * S * 8));
+    int32_t *div = (int32_t *)take(f_i);
+    double *cxu = (double *)take(al(n * m * 8));
+    Traj &s = ws.s;
+    s.lam = (double *)take(f_d); s.dlam = (double *)take(f_d); s.gnorm = (double *)take(f_d); s.csum = (double *)take(f_d);
+    s.status = (int32_t *)take(f_i); s.iter = (int32_t *)take(f_i); s.acc = (int32_t *)take(f_i); s.nbp = (int32_t *)take(f_i);
+    s.nfp = (int32_t *)take(f_i); s.flg = (int32_t *)take(f_i); s.run = (int32_t *)take(f_i); s.dodf = (int32_t *)take(f_i);
+    s.dofwd = (int32_t *)take(f_i); s.div0 = (int32_t *)take(f_i);
+    Sched q;
+    q.P = (int)P; q.mpc_steps = mpc_steps; q.zero_tail = zero_tail; q.nalpha = (int)na;
+    for (int i = 0; i < 16; ++i) q.alpha[i] = oo->alpha[i];
+    q.lam0 = oo->lambda; q.dlam0 = oo->dlambda; q.x0g = x0; q.u0g = u0; q.u0s = u0s; q.us = us; q.x0s = ws.x0;
+    q.initm = (int32_t *)take(f_i); q.ai = (int32_t *)take(f_i); q.map = (int32_t *)take(f_i); q.left = (int32_t *)take(f_i);
+    q.noflush = (int32_t *)take(f_i); q.ready = (int32_t *)take(f_i);
+    int32_t *more = (int32_t *)take(f_i), *more2 = (int32_t *)take(f_i);
+    int *counter = (int *)take(256);
+    q.qhead = (int *)take(256);
+    q.x = x; q.u = u; q.cost = cost; q.K = K; q.k = k; q.Quu = Quu; q.Vx = Vx; q.Vxx = Vxx; q.stats = stats; q.xcl = xcl; q.ucl = ucl; q.stats_cl = stats_cl;
+    ws.map = q.map;
+    DDP_CHECK(h->h_pinned, "ilqg_sched: pinned poll buffer missing");
+
+    Opt o;
+    o.lfac = oo->lambda_factor; o.lmax = oo->lambda_max; o.lmin = oo->lambda_min; o.tol_fun = oo->tol_fun;
+    o.tol_grad = oo->tol_grad; o.rrmin = oo->reduce_ratio_min; o.max_iter = oo->max_iter; o.nalpha = (int)na;
+    for (int i = 0; i < 16; ++i) o.alpha[i] = oo->alpha[i];
+
+    hipStream_t st = h->stream;
+    if (!h->sched_aux) {
+        DDP_HIP(hipStreamCreateWithFlags(&h->sched_aux, hipStreamNonBlocking));
+        for (int e = 0; e < 2; ++e) DDP_HIP(hipEventCreateWithFlags(&h->sched_ev[e], hipEventDisableTiming));
+    }
+    // slots start empty: nothing runs, nothing to flush (map = -1); the working set is finite from the start (the line-search launches
+    // touch every slot's operands only under their masks, but a masked wave may still prefetch)
+    DDP_HIP(hipMemsetAsync(blk, 0, bytes, st));
+    DDP_HIP(hipMemsetAsync(q.map, 0xff, S * 4, st));
+    // outputs of problems that never produce any (initial divergence) are zero, like the arrays ilqg_impl clears
+    if (!mpc) {
+        DDP_HIP(hipMemsetAsync(K, 0, m * n * N * P * 8, st)); DDP_HIP(hipMemsetAsync(k, 0, m * N * P * 8, st));
+        DDP_HIP(hipMemsetAsync(Quu, 0, m * m * N * P * 8, st)); DDP_HIP(hipMemsetAsync(Vx, 0, n * N * P * 8, st));
+        DDP_HIP(hipMemsetAsync(Vxx, 0, n * n * N * P * 8, st)); DDP_HIP(hipMemsetAsync(cost, 0, CL * P * 8, st));
+    } else {
+        DDP_HIP(hipMemsetAsync(xcl, 0, n * (size_t)(mpc_steps + 1) * P * 8, st)); DDP_HIP(hipMemsetAsync(ucl, 0, m * (size_t)mpc_steps * P * 8, st));
+        DDP_HIP(hipMemsetAsync(stats_cl, 0, (size_t)DDP_ILQG_NSTATS * mpc_steps * P * 8, st));
+    }
+    DDP_HIP(hipMemsetAsync(x, 0, n * N * P * 8, st));
+    DDP_HIP(hipMemsetAsync(u, 0, m * N * P * 8, st));
+
+    ddp_problem pw = *p;
+    pw.B = (int)S;
+    ddp_bp_desc d;
+    d.n = (int)n; d.m = (int)m; d.N = (int)N; d.B = (int)S;
+    d.fx_tv = pend ? 1 : p->dyn_tv; d.fx_batched = pend ? 1 : p->dyn_batched;
+    d.cost_tv = 0; d.cost_batched = 0; d.regType = oo->regType; d.has_lims = lims != nullptr;
+    const double *fx = pend ? fxw : p->A, *fu = pend ? fuw : p->Bm;
+    // the line search in the groups ilqg_impl uses at this batch size (same launches -> same kernels -> same bits per solve)
+    const char *genv = ddp_env(h, ENV_ILQG_LSGROUPS);
+    const double rpw = pend ? 64.0 : (n <= 16 ? 4.0 : 1.0);
+    const bool groups = na > 1 && (genv ? genv[0] == '1' : (p->kind == DDP_PROBLEM_LQ && (double)na * (double)S / rpw >= 2048.0));
+    const double one = 1.0;
+
+    hipLaunchKernelGGL(sched_take_kernel, dim3((unsigned)S), dim3(TAKE_T), 0, st, (int)n, (int)m, (int)N, (int)CL, q, ws, counter);      // initial fill
+    int git = 0, running = (int)S;
+    constexpr int POLL = 4;
+    const long hard_cap = ((long)(mpc ? mpc_steps : (P + S - 1) / S) + 1) * (4L * oo->max_iter + 1000 + na);
+    int rc = 0;
+    while (running > 0 && git < hard_cap) {
+        // armed slots: the initial rollout of α·u0 with an empty policy, its bound test, the step to the next α (iLQG.jl:181-192, :205-210)
+        // — on the side stream, beside STEPS 1-3 of the running slots (a 600-step rollout of a handful of slots costs the full latency
+        // of the kernel: 0.19 of the 1.2 ms a global iteration of 4 096 pendulums takes); the slots join at the next sched_take_kernel
+        DDP_HIP(hipEventRecord(h->sched_ev[0], st));
+        DDP_HIP(hipStreamWaitEvent(h->sched_aux, h->sched_ev[0], 0));
+        h->stream = h->sched_aux;
+        rc = ddp_forward_pass_f64_dev(h, &pw, nullptr, nullptr, ws.x0, us, nullptr, &one, 1, lims, q.initm, xi, ui, ci, csi);
+        h->stream = st;
+        if (rc) return rc;
+        hipLaunchKernelGGL(init_check_kernel, dim3((unsigned)S), dim3(64), 0, h->sched_aux, (int)n, (int)m, (int)N, (int)CL, xi, ui, ci, csi, s, ws.x, ws.u, ws.cost);
+        hipLaunchKernelGGL(sched_init_advance_kernel, dim3((unsigned)S), dim3(64), 0, h->sched_aux, (int)m, (int)N, q, s);
+        DDP_HIP(hipEventRecord(h->sched_ev[1], h->sched_aux));
+        rc = ddp_df_f64_dev(h, &pw, ws.x, ws.u, s.dodf, cx, cu, fxw, fuw);                                     // STEP 1
+        if (rc) return rc;
+        rc = ddp_launch_back_pass(h, &d, cx, cu, p->Q, cxu, p->R, fx, fu, s.lam, lims, ws.u, s.run, ws.K, ws.k, ws.Quu, ws.Vx, ws.Vxx, dV, div);   // STEP 2
+        if (rc) return rc;
+        hipLaunchKernelGGL(post_bp_kernel, dim3((unsigned)S), dim3(64), 0, st, (int)m, (int)N, o, div, ws.k, ws.u, s);
+        const size_t gb[4] = {0, groups ? 1 : na, groups ? (na < 3 ? na : 3) : na, na};                         // STEP 3
+        const int32_t *mask = s.dofwd;
+        for (int gi = 0; gi < 3; ++gi) {
+            const size_t a0 = gb[gi], a1 = gb[gi + 1];
+            if (a1 <= a0) continue;
+            if (a0 > 0) {
+                int32_t *mk = (gi == 1) ? more : more2;
+                hipLaunchKernelGGL(ls_more_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, (int)S, (int)a0, o, dV, cs, s,
+                                   gi == 1 ? (const int32_t *)nullptr : (const int32_t *)more, mk);
+                mask = mk;
+            }
+            rc = ddp_forward_pass_f64_dev(h, &pw, ws.K, ws.k, ws.x0, ws.u, ws.x, o.alpha + a0, (int)(a1 - a0), lims, mask, xn + n * N * S * a0,
+                                          un + m * N * S * a0, cn + CL * S * a0, cs + S * a0);
+            if (rc) return rc;
+        }
+        const int slot = git % POLL;
+        DDP_HIP(hipMemsetAsync(counter + slot, 0, 4, st));
+        hipLaunchKernelGGL(accept_kernel, dim3((unsigned)S), dim3(64), 0, st, (int)n, (int)m, (int)N, (int)S, (int)CL, o, dV, xn, un, cn, cs, s,
+                           ws.x, ws.u, ws.cost, ws.k, 0, (double *)nullptr, (double *)nullptr, (const int32_t *)nullptr, counter + 32);      // STEP 4
+        DDP_HIP(hipStreamWaitEvent(st, h->sched_ev[1], 0));
+        hipLaunchKernelGGL(sched_take_kernel, dim3((unsigned)S), dim3(TAKE_T), 0, st, (int)n, (int)m, (int)N, (int)CL, q, ws, counter + slot);
+        ++git;
+        if (slot == POLL - 1 || git >= hard_cap) {
+            DDP_HIP(hipMemcpyAsync(h->h_pinned, counter, 4 * (slot + 1), hipMemcpyDeviceToHost, st));
+            DDP_HIP(hipStreamSynchronize(st));
+            running = h->h_pinned[slot];
+            for (int e2 = 0; e2 <= slot; ++e2)
+                if (h->h_pinned[e2] == 0) { git -= slot - e2; running = 0; break; }       // the iterations after it did nothing
+        }
+    }
+    DDP_HIP(hipGetLastError());
+    DDP_HIP(hipStreamSynchronize(st));
+    DDP_CHECK(running == 0, "ilqg_sched: %d slots still busy after %d global iterations (the driver's own bound)", running, git);
+    if (global_iters) *global_iters = git;
+    return 0;
+}
+
+int ddp_ilqg_queue_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int slots, const double *x0, const double *u0,
+                           const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                           double *cost, double *stats, int *global_iters)
+{
+    return ilqg_sched_impl(h, p, o, slots, 0, 0, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, nullptr, nullptr, nullptr, global_iters);
+}
+
+int ddp_ilqg_mpc_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int steps, int zero_tail, const double *x0,
+                         const double *u0, const double *lims, double *xcl, double *ucl, double *stats_cl, double *x, double *u,
+                         int *global_iters)
+{
+    DDP_CHECK(steps >= 1, "ilqg_mpc: steps=%d", steps);
+    return ilqg_sched_impl(h, p, o, 0, steps, zero_tail, x0, u0, lims, x, u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           xcl, ucl, stats_cl, global_iters);
+}
+
 // batch-level line-search statistics in ONE launch: out[4] = [Σ_b csum, Σ_b dV[1,b], Σ_b dV[2,b], #diverged] — the vector a
 // multi-GPU job all-reduces once per pass (bench.py, sharding.py)
 __global__ __launch_bounds__(256) void batch_stats_kernel(int B, const double *csum, const double *dV, const int32_t *diverge, double *out)
@@ -742,7 +1056,69 @@ int ddp_ilqg_ex_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, 
                      trace_cap, nullptr, global_iters, trace7);
 }
 
+// host-pointer flavours of the slot scheduler: upload, run, download (the same staging as ilqg_host)
+static int sched_host(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int slots, int steps, int zero_tail, const double *x0,
+                      const double *u0, const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                      double *cost, double *stats, double *xcl, double *ucl, double *stats_cl, int *global_iters)
+{
+    DDP_DEVICE(h);
+    DDP_CHECK(h && p && x0 && u0, "ilqg_sched: null argument");
+    const size_t n = p->n, m = p->m, N = p->N, P = p->B, CL = ddp_cost_len(p);
+    const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? P : 1);
+    struct Buf { void *d; void *hdst; size_t bytes; };
+    std::vector<Buf> bufs;
+    bool failed = false;
+    auto dev = [&](const void *src, void *dst, size_t bytes) -> void * {
+        if (!src && !dst) return nullptr;
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 8) != hipSuccess) { failed = true; return nullptr; }
+        if (src && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) failed = true;
+        bufs.push_back({d, dst, bytes});
+        return d;
+    };
+    ddp_problem pd = *p;
+    if (p->kind == DDP_PROBLEM_LQ) { pd.A = (double *)dev(p->A, nullptr, n * n * dc * 8); pd.Bm = (double *)dev(p->Bm, nullptr, n * m * dc * 8); }
+    pd.Q = (double *)dev(p->Q, nullptr, n * n * 8);
+    pd.R = (double *)dev(p->R, nullptr, m * m * 8);
+    double *dx0 = (double *)dev(x0, nullptr, n * P * 8), *du0 = (double *)dev(u0, nullptr, m * N * P * 8),
+           *dl = lims ? (double *)dev(lims, nullptr, 2 * m * 8) : nullptr;
+    double *dx = (double *)dev(nullptr, x, n * N * P * 8), *du = (double *)dev(nullptr, u, m * N * P * 8),
+           *dK = (double *)dev(nullptr, K, m * n * N * P * 8), *dk = (double *)dev(nullptr, k, m * N * P * 8),
+           *dQuu = (double *)dev(nullptr, Quu, m * m * N * P * 8), *dVx = (double *)dev(nullptr, Vx, n * N * P * 8),
+           *dVxx = (double *)dev(nullptr, Vxx, n * n * N * P * 8), *dcost = (double *)dev(nullptr, cost, CL * P * 8),
+           *dstats = (double *)dev(nullptr, stats, DDP_ILQG_NSTATS * P * 8),
+           *dxcl = (double *)dev(nullptr, xcl, n * (size_t)(steps + 1) * P * 8), *ducl = (double *)dev(nullptr, ucl, m * (size_t)steps * P * 8),
+           *dscl = (double *)dev(nullptr, stats_cl, (size_t)DDP_ILQG_NSTATS * steps * P * 8);
+    int rc = failed ? -2 : 0;
+    if (failed) ddp_set_error("ilqg_sched: device allocation / upload failed");
+    if (!rc) rc = ilqg_sched_impl(h, &pd, o, slots, steps, zero_tail, dx0, du0, dl, dx, du, dK, dk, dQuu, dVx, dVxx, dcost, dstats, dxcl, ducl, dscl,
+                                  global_iters);
+    if (!rc)
+        for (auto &bf : bufs)
+            if (bf.hdst && hipMemcpyAsync(bf.hdst, bf.d, bf.bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = -2;
+    hipStreamSynchronize(h->stream);
+    for (auto &bf : bufs) hipFree(bf.d);
+    return rc;
+}
+
+int ddp_ilqg_queue_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int slots, const double *x0, const double *u0,
+                       const double *lims, double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx, double *cost,
+                       double *stats, int *global_iters)
+{
+    DDP_CHECK(x && u && K && k && Quu && Vx && Vxx && cost && stats, "ilqg_queue: null output");
+    return sched_host(h, p, o, slots, 0, 0, x0, u0, lims, x, u, K, k, Quu, Vx, Vxx, cost, stats, nullptr, nullptr, nullptr, global_iters);
+}
+
+int ddp_ilqg_mpc_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int steps, int zero_tail, const double *x0, const double *u0,
+                     const double *lims, double *xcl, double *ucl, double *stats_cl, double *x, double *u, int *global_iters)
+{
+    DDP_CHECK(steps >= 1 && xcl && ucl && stats_cl && x && u, "ilqg_mpc: steps=%d or a null output", steps);
+    return sched_host(h, p, o, 0, steps, zero_tail, x0, u0, lims, x, u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xcl, ucl,
+                      stats_cl, global_iters);
+}
+
 }   // extern "C"
+
 
 int ddp_ilqg_set_timing(ddp_handle h, double *host_buf, int cap)
 {

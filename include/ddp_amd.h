@@ -243,6 +243,34 @@ int ddp_ilqg_warm_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opt
                           const double *x0, const double *u0, const double *cost0, const double *lims,
                           double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
                           double *cost, double *stats, int trace_cap, double *trace_cost, int *global_iters);
+/* ---- slot scheduler: more problems than resident trajectories, and closed-loop MPC on the device -------------------------------
+ * The batch of ddp_ilqg_* advances in lock step: a trajectory that has ended keeps its place until the slowest one ends (pendcart:
+ * median 50 iterations, slowest 233).  Here `slots` trajectories are resident and the P = p->B problems go through them: a slot
+ * whose solve has ended is flushed to its problem's rows of the outputs and armed with the next problem ON THE DEVICE, in the global
+ * iteration in which it ended; the host only polls the number of busy slots.  Every solve performs the launches of its stand-alone
+ * solve at batch size `slots` (initial rollout of src/iLQG.jl:181-192 included), so its results are those of ddp_ilqg_f64 with
+ * p->B = slots.  inputs x0[n,P] u0[m,N,P]; outputs as ddp_ilqg_f64 with P columns; slots <= 0: min(P, 4096).  Per-trajectory
+ * dynamics (dyn_batched) are refused.                                                                                             */
+int ddp_ilqg_queue_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int slots,
+                       const double *x0, const double *u0, const double *lims,
+                       double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                       double *cost, double *stats, int *global_iters);
+int ddp_ilqg_queue_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int slots,
+                           const double *x0, const double *u0, const double *lims,
+                           double *x, double *u, double *K, double *k, double *Quu, double *Vx, double *Vxx,
+                           double *cost, double *stats, int *global_iters);
+/* Closed loop (the receding-horizon use of the warm-start hook, src/iLQG.jl:193-197): every trajectory is solved `steps` times; after
+ * solve t its first control is applied (the model is the plant: the next initial state is x_1 of the solution), the control
+ * sequence is shifted by one step (tail: last column repeated, or zeros) and solved again — shift and re-solve happen on the
+ * device by the same mechanism that re-arms a slot of the queue.  outputs: xcl[n,steps+1,B] (the closed-loop states, xcl[:,0,b] =
+ * x0[:,b]), ucl[m,steps,B] (the applied controls), stats_cl[8,steps,B] (the summary row of every solve), x[n,N,B] / u[m,N,B] (the
+ * last plan).  A solve whose initial rollout diverges ends the loop of its trajectory (later columns stay zero).                  */
+int ddp_ilqg_mpc_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int steps, int zero_tail,
+                     const double *x0, const double *u0, const double *lims,
+                     double *xcl, double *ucl, double *stats_cl, double *x, double *u, int *global_iters);
+int ddp_ilqg_mpc_f64_dev(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o, int steps, int zero_tail,
+                         const double *x0, const double *u0, const double *lims,
+                         double *xcl, double *ucl, double *stats_cl, double *x, double *u, int *global_iters);
 /* Per-phase GPU time of the following ddp_ilqg_* calls on this handle — the time_derivs / time_backward / time_forward
  * trace keys of the reference (src/iLQG.jl:227,241,281; print_timing :343-366): host_buf[3, cap] (row-major: row r at
  * host_buf + cap*r), seconds per GLOBAL iteration (the batch advances in lock step; the call's *global_iters says how many
