@@ -52,6 +52,7 @@ struct Q4Args {
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
     int32_t *diverge;
     const double *eta;          // back_pass_gps only: η per trajectory
+    double *Quui;               // back_pass_gps only (chunked kernel): inv(Quu)
     double *sink;               // >= 64 x 16 B that lanes without an output may write (paired kernel: stores carry no exec-mask branch)
 };
 
@@ -575,6 +576,286 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4l_kernel(Q4Args a)
 }
 
 
+// ---- CHUNKS THROUGH THE LDS, second layout: TRAJECTORY-INTERLEAVED image, chunk length a template parameter, back_pass_gps' combination
+// c̃• = c•/η + c•kl folded into the operand fetch.
+// Why a second layout (profiles/r03_c3_pmc.txt): in the image of back_pass_q4l_kernel the four trajectories of a wave lie 32 doubles
+// (= one whole row of LDS banks) apart, so the four lanes that read the same element of their trajectories always meet in one bank:
+// SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 4.  Here the trajectory index is the FASTEST index of the 16-byte pieces:
+//   matrix array (16 doubles / step / trajectory): piece p = 64 (step/2) + 32 (step&1) + 16 rh + 4 c + blk  holds elements (2rh, c), (2rh+1, c);
+//     lane (r, blk, c) reads double 2p + (r&1): the 32 lanes of a half-wave touch 32 consecutive doubles — no conflict
+//     (the transposed element, read for cxx' only: 2-way);
+//   vector array (4 doubles):  piece p = 8 step + 4 rh + blk   — column form (element r) and row form (element c) conflict-free;
+//   scalar array:              piece p = 4 (step/2) + blk      holds steps (2 step/2, +1).
+// A direct-to-LDS load writes lane L's 16 bytes to piece L of its 64-piece window, so the per-lane SOURCE address decides the layout;
+// every lane of every load / store belongs to trajectory blk = L & 3.  Loads of a kind are packed: with CH = 8 a load carries one
+// vector array or four scalar arrays, with CH = 4 two vector arrays or eight scalar arrays.
+// back_pass_gps (GPS): the image also takes cxx, cxu, cuu and the five KL terms as they are in memory (no prepass kernel, no c̃• round trip
+// through HBM: 1.1 GB per pass at C5); a step forms c̃• = c• ieta + c•kl while it fetches (7 multiply-adds), the terminal step takes the raw cx,
+// cxx (backward_pass.jl:281-283), Quui = 1/Quu leaves with k and Quu.  Its image is 9.3 KB per 4 steps: CH = 4 keeps a wave under the
+// 40 KB that four waves per CU (B = 4 096) leave.
+template <int CH, bool GPS>
+struct Q4C {
+    static constexpr int MAT = 64 * CH, VEC = 16 * CH, SCA = 4 * CH;                 // doubles per array and chunk (4 trajectories)
+    // input image
+    static constexpr int NMAT = GPS ? 3 : 1, NVEC = GPS ? 5 : 2, NSCA = GPS ? 5 : 2;  // fx [cxx kcxx] | fu cx [cxu kcx kcxu] | cu u [cuu kcu kcuu]
+    static constexpr int I_MAT = 0, I_VEC = NMAT * MAT, I_SCA = I_VEC + NVEC * VEC;
+    static constexpr int SCA_PAD = ((NSCA * SCA + 127) / 128) * 128;                  // whole 64-piece windows
+    static constexpr int IN = I_SCA + SCA_PAD;
+    static constexpr int LD_MAT = NMAT * MAT / 128, LD_VEC = (NVEC * VEC + 127) / 128, LD_SCA = SCA_PAD / 128;     // loads per chunk
+    static constexpr int NLD = LD_MAT + LD_VEC + LD_SCA;
+    // output image: Vxx | K Vx | k Quu [Quui], then the cells lanes without an output write to
+    static constexpr int O_VEC = MAT, O_SCA = O_VEC + 2 * VEC, NOS = GPS ? 3 : 2;
+    static constexpr int OSCA_PAD = ((NOS * SCA + 127) / 128) * 128;
+    static constexpr int O_DUMP = O_SCA + OSCA_PAD, OUT = O_DUMP + 64 + 16 * CH + 16;
+    static constexpr int ST_MAT = MAT / 128, ST_VEC = (2 * VEC + 127) / 128, ST_SCA = OSCA_PAD / 128, NST = ST_MAT + ST_VEC + ST_SCA;
+    static constexpr int NBUF = GPS ? 3 : 2;                                          // input images (see the kernel)
+};
+
+template <bool LIMS, bool REG2, bool GPS, int CH, int EXP = 0>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_q4c_kernel(Q4Args a, const ddp_kl_cost_terms kl)
+{
+    typedef Q4C<CH, GPS> L;
+    constexpr int n = 4;
+    static_assert(CH == 4 || CH == 8, "chunk length");
+    __shared__ __attribute__((aligned(16))) double lin[L::NBUF][L::IN];
+    __shared__ __attribute__((aligned(16))) double lout[L::OUT];
+    const int N = a.N, NC = N / CH;
+    const int lane = threadIdx.x, r = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3, q16 = 4 * r + c;
+    long tb = (long)blockIdx.x * 4 + blk;
+    const bool valid = tb < a.B;
+    if (!valid) tb = a.B - 1;
+    const int b = (int)tb;
+    const bool act = valid && !(a.active && a.active[b] == 0);
+    if (!__any(act)) return;
+    // the lane's trajectory on the global side: every piece of every load / store belongs to trajectory lane & 3
+    long tbd = (long)blockIdx.x * 4 + (lane & 3);
+    const bool validd = tbd < a.B;
+    if (!validd) tbd = a.B - 1;
+    const size_t bd = (size_t)tbd;
+    const bool actd = validd && !(a.active && a.active[bd] == 0);
+
+    // ---- sources of the loads (chunk 0; a chunk further on is CH * {16, 4, 1} doubles further)
+    const double *src[L::NLD];
+    bool ldon[L::NLD];
+    {
+        // matrix arrays: fx, [cxx, kcxx]
+        const double *mat[3] = {a.fx + a.fx_b * bd, GPS ? a.cxx + a.cxx_b * bd : a.fx, GPS ? kl.cxx + (size_t)16 * N * bd : a.fx};
+#pragma unroll
+        for (int i = 0; i < L::LD_MAT; ++i) {
+            const int g = 64 * i + lane, arr = g / (32 * CH), p = g % (32 * CH);
+            const int step = 2 * (p >> 6) + ((p >> 5) & 1), rh = (p >> 4) & 1, cc = (p >> 2) & 3;
+            src[i] = mat[arr] + 16 * step + 2 * rh + 4 * cc;
+            ldon[i] = true;
+        }
+        // vector arrays: fu, cx, [cxu, kcx, kcxu]
+        const double *vec[5] = {a.fu + a.fu_b * bd, a.cx + (size_t)n * N * bd, GPS ? a.cxu + a.cxu_b * bd : a.cx, GPS ? kl.cx + (size_t)n * N * bd : a.cx,
+                                GPS ? kl.cxu + (size_t)n * N * bd : a.cx};
+#pragma unroll
+        for (int i = 0; i < L::LD_VEC; ++i) {
+            const int g = 64 * i + lane, arr = g / (8 * CH), p = g % (8 * CH);
+            const int step = p >> 3, rh = (p >> 2) & 1;
+            ldon[L::LD_MAT + i] = arr < L::NVEC;
+            src[L::LD_MAT + i] = vec[arr < L::NVEC ? arr : 0] + 4 * step + 2 * rh;
+        }
+        // scalar arrays: cu, u, [cuu, kcu, kcuu]
+        const double *sca[5] = {a.cu + (size_t)N * bd, (LIMS ? a.u : a.cu) + (size_t)N * bd, GPS ? a.cuu + a.cuu_b * bd : a.cu, GPS ? kl.cu + (size_t)N * bd : a.cu,
+                                GPS ? kl.cuu + (size_t)N * bd : a.cu};
+#pragma unroll
+        for (int i = 0; i < L::LD_SCA; ++i) {
+            const int g = 64 * i + lane, arr = g / (2 * CH), p = g % (2 * CH);
+            ldon[L::LD_MAT + L::LD_VEC + i] = arr < L::NSCA;
+            src[L::LD_MAT + L::LD_VEC + i] = sca[arr < L::NSCA ? arr : 0] + 2 * (p >> 2);
+        }
+    }
+    auto dma_one = [&](int ch, double *in, int i) __attribute__((always_inline)) {
+        const int per = i < L::LD_MAT ? 16 : (i < L::LD_MAT + L::LD_VEC ? 4 : 1);
+        const int off = i < L::LD_MAT ? 128 * i : (i < L::LD_MAT + L::LD_VEC ? L::I_VEC + 128 * (i - L::LD_MAT) : L::I_SCA + 128 * (i - L::LD_MAT - L::LD_VEC));
+        if (ldon[i]) __builtin_amdgcn_global_load_lds((glb_void *)(src[i] + (size_t)ch * (CH * per)), (lds_void *)(in + off), 16, 0, 0);
+    };
+    auto dma = [&](int ch, double *in) {
+#pragma unroll
+        for (int i = 0; i < L::NLD; ++i) dma_one(ch, in, i);
+    };
+    // ---- destinations of the stores: Vxx | K, Vx | k, Quu [, Quui]; a lane without an output writes its 16 bytes of the sink
+    double *dst[L::NST];
+    bool ston[L::NST];
+    {
+#pragma unroll
+        for (int i = 0; i < L::ST_MAT; ++i) {
+            const int p = 64 * i + lane, step = 2 * (p >> 6) + ((p >> 5) & 1), rh = (p >> 4) & 1, cc = (p >> 2) & 3;
+            dst[i] = a.Vxx + (size_t)16 * N * bd + 16 * step + 2 * rh + 4 * cc;
+            ston[i] = true;
+        }
+        double *vec[2] = {a.K + (size_t)n * N * bd, a.Vx + (size_t)n * N * bd};
+#pragma unroll
+        for (int i = 0; i < L::ST_VEC; ++i) {
+            const int g = 64 * i + lane, arr = g / (8 * CH), p = g % (8 * CH);
+            ston[L::ST_MAT + i] = arr < 2;
+            dst[L::ST_MAT + i] = vec[arr < 2 ? arr : 0] + 4 * (p >> 3) + 2 * ((p >> 2) & 1);
+        }
+        double *sca[3] = {a.k + (size_t)N * bd, a.Quu + (size_t)N * bd, GPS ? a.Quui + (size_t)N * bd : a.k};
+#pragma unroll
+        for (int i = 0; i < L::ST_SCA; ++i) {
+            const int g = 64 * i + lane, arr = g / (2 * CH), p = g % (2 * CH);
+            ston[L::ST_MAT + L::ST_VEC + i] = arr < L::NOS;
+            dst[L::ST_MAT + L::ST_VEC + i] = sca[arr < L::NOS ? arr : 0] + 2 * (p >> 2);
+        }
+    }
+    auto drain = [&](int ch) {
+        d2 v[L::NST];
+#pragma unroll
+        for (int i = 0; i < L::NST; ++i) {
+            const int off = i < L::ST_MAT ? 128 * i : (i < L::ST_MAT + L::ST_VEC ? L::O_VEC + 128 * (i - L::ST_MAT) : L::O_SCA + 128 * (i - L::ST_MAT - L::ST_VEC));
+            v[i] = *(const d2 *)(lout + off + 2 * lane);
+        }
+#pragma unroll
+        for (int i = 0; i < L::NST; ++i) {
+            const int per = i < L::ST_MAT ? 16 : (i < L::ST_MAT + L::ST_VEC ? 4 : 1);
+            double *g = (actd && ston[i]) ? dst[i] + (size_t)ch * (CH * per) : a.sink + 2 * lane;
+            *(d2 *)g = v[i];
+        }
+    };
+
+    Q4Par par;
+    par.lam = GPS ? 0.0 : a.lambda[b]; par.limlo = 0.0; par.limhi = 0.0; par.nolims = true;      // back_pass_gps: η is the only regularisation
+    par.ieta = GPS ? 1.0 / a.eta[b] : 1.0;
+    if (LIMS) { par.limlo = a.lims[0]; par.limhi = a.lims[1]; par.nolims = par.limlo > par.limhi; }
+    Q4In cst;
+    if (!GPS) {
+        const double *cxx = a.cxx + a.cxx_b * b, *cuu = a.cuu + a.cuu_b * b, *cxu = a.cxu + a.cxu_b * b;
+        const int e = r + 4 * c, et = c + 4 * r;
+        cst.cxx = cxx[e]; cst.cxxT = cxx[et]; cst.cxuc = cxu[r]; cst.cxur = cxu[c]; cst.cuu = cuu[0];
+    }
+    // ---- per-lane offsets (doubles) of the compute side
+    const int omat = 32 * (r >> 1) + 8 * c + 2 * blk + (r & 1), omatT = 32 * (c >> 1) + 8 * r + 2 * blk + (c & 1);       // element (r, c) / (c, r)
+    const int ocol = 8 * (r >> 1) + 2 * blk + (r & 1), orow = 8 * (c >> 1) + 2 * blk + (c & 1);                            // vector element r / c
+    const int osca = 2 * blk;
+    auto smat = [](int sidx) { return 128 * (sidx >> 1) + 64 * (sidx & 1); };
+    auto ssca = [](int sidx) { return 8 * (sidx >> 1) + (sidx & 1); };
+    // outputs: V by every lane; K_i[0, r] by the lanes c == 0, Vx_i[r] by c == 1, k_i / Quu_i / Quui_i by lanes (0, 0) / (0, 1) / (0, 2) of a block
+    double *wV = lout + omat;
+    double *wK = lout + ((c == 0) ? L::O_VEC + ocol : (c == 1) ? L::O_VEC + L::VEC + ocol : L::O_DUMP + lane);
+    const int wKs = (c <= 1) ? 16 : 0;                                                                              // doubles per step (dump cells: none)
+    double *wS = lout + ((r == 0 && c < L::NOS) ? L::O_SCA + L::SCA * c + osca : L::O_DUMP + 64 + (lane & 15));
+    const bool sreal = (r == 0 && c < L::NOS);
+    auto readin = [&](const double *in, int sidx, Q4In &o, bool terminal) __attribute__((always_inline)) {
+        o.fx = in[L::I_MAT + omat + smat(sidx)];
+        o.fu = in[L::I_VEC + ocol + 16 * sidx];
+        const double cxr = in[L::I_VEC + L::VEC + ocol + 16 * sidx];
+        const double cur = in[L::I_SCA + osca + ssca(sidx)];
+        o.u = LIMS ? in[L::I_SCA + L::SCA + osca + ssca(sidx)] : 0.0;
+        if (GPS) {
+            const double ie = par.ieta;
+            const double xx = in[L::I_MAT + L::MAT + omat + smat(sidx)], xxT = in[L::I_MAT + L::MAT + omatT + smat(sidx)];
+            const double kxx = in[L::I_MAT + 2 * L::MAT + omat + smat(sidx)], kxxT = in[L::I_MAT + 2 * L::MAT + omatT + smat(sidx)];
+            const double xuc = in[L::I_VEC + 2 * L::VEC + ocol + 16 * sidx], xur = in[L::I_VEC + 2 * L::VEC + orow + 16 * sidx];
+            const double kx = in[L::I_VEC + 3 * L::VEC + ocol + 16 * sidx];
+            const double kxuc = in[L::I_VEC + 4 * L::VEC + ocol + 16 * sidx], kxur = in[L::I_VEC + 4 * L::VEC + orow + 16 * sidx];
+            const double uu = in[L::I_SCA + 2 * L::SCA + osca + ssca(sidx)], ku = in[L::I_SCA + 3 * L::SCA + osca + ssca(sidx)],
+                         kuu = in[L::I_SCA + 4 * L::SCA + osca + ssca(sidx)];
+            // c̃• = c•/η + c•kl (backward_pass.jl:293-299); the terminal step keeps cx, cxx as they are (:281) and Quu_N = cuu/η + cuukl (:282)
+            o.cx = terminal ? cxr : fma(cxr, ie, kx);
+            o.cu = fma(cur, ie, ku);
+            o.cxx = terminal ? xx : fma(xx, ie, kxx);
+            o.cxxT = terminal ? xxT : fma(xxT, ie, kxxT);
+            o.cxuc = fma(xuc, ie, kxuc); o.cxur = fma(xur, ie, kxur);
+            o.cuu = fma(uu, ie, kuu);
+        } else {
+            o.cx = cxr; o.cu = cur;
+            o.cxx = cst.cxx; o.cxxT = cst.cxxT; o.cxuc = cst.cxuc; o.cxur = cst.cxur; o.cuu = cst.cuu;
+        }
+    };
+    auto writeout = [&](int sidx, const Q4Out &o) __attribute__((always_inline)) {
+        wV[smat(sidx)] = o.Vn;
+        wK[wKs * sidx] = (c == 0) ? o.Kc : o.vx;
+        const double sv = (c == 0) ? o.kk : ((c == 1 || !GPS) ? o.Quu : ddp_rcp_nr(o.Quu));       // Quui_i = inv(Quu_i) (:283, :344)
+        wS[sreal ? ssca(sidx) : 0] = sv;
+    };
+
+    Q4State s;
+    s.kprev = 0.0; s.dV0 = 0.0; s.dV1 = 0.0; s.diverge = 0;
+    // NBUF images: chunk ch lives in image (NC - 1 - ch) % NBUF and is requested NBUF - 1 chunks ahead.  With three images the wait
+    // at the end of a chunk is COUNTED: vmcnt(NLD) leaves the loads of the chunk after next and the result stores of the last two
+    // chunks in flight — at most NLD operations outstanding means at least the OLDER half of the 2 NLD loads has landed, whatever
+    // the stores do (loads return in order among themselves; stores may pass them).  With vmcnt(0) and two images a chunk of four
+    // steps (~4 us) waited for its predecessor's result stores to reach memory: 0.13 of 0.58 ms (DDP_Q4_EXP, C5).
+    constexpr int NBUF = L::NBUF;
+    constexpr unsigned long long SENT = 0x7FF4DDA5C0DEF00Dull;
+    constexpr int SENT_CELL = L::I_SCA + 128 * (L::LD_SCA - 1);   // first double of the first piece of the last load of a batch (trajectory 0 of the wave: always fetched)
+    dma(NC - 1, lin[0]);
+    if (NC > 1) dma(NC - 2, lin[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NBUF > 2 && NC > 2) dma(NC - 3, lin[2]);
+    Q4In in;
+    Q4Out prev;
+    readin(lin[0], CH - 1, in, true);
+    int ib = 0;                                                 // image of the current chunk
+    for (int ch = NC - 1; ch >= 0; --ch) {
+        const double *cur = lin[ib];
+        const int inx = ib + 1 < NBUF ? ib + 1 : 0, ipv = ib > 0 ? ib - 1 : NBUF - 1;
+        const double *nxt = lin[inx];
+        // while this chunk is worked on, the image of the chunk before it (free since that chunk ended) takes the chunk NBUF - 1 further
+        // on — its loads are SPREAD over the steps CH-1 .. 1 (a burst of NLD loads + NST stores at the end of a chunk cost 0.10 ms of
+        // 0.56 at C5: a vector-memory instruction issued into a busy queue costs a lone wave 100-200 cycles instead of ~60)
+        const int tgt = ch + 1 - NBUF;
+        const bool fetch = tgt >= 0 && ch <= NC - 2 && !(EXP & 2);
+        const bool sent_on = NBUF > 2 && ch + 1 <= NC - 2;      // the next chunk's image came by a batch issued in the loop (with its sentinel)
+#pragma unroll
+        for (int sidx = CH - 1; sidx >= 0; --sidx) {
+            Q4In nx;
+            if (sidx > 0) readin(cur, sidx - 1, nx, false);
+            else {
+                // The image of the next chunk was requested a chunk ago; since then this wave has issued the NST result stores of the
+                // chunk before and the NLD loads of this chunk.  vmcnt(NLD + NST) lets exactly those stay in flight — waiting for the
+                // stores as well (vmcnt(NLD): they are the oldest of the newest) stalled every chunk for their trip to memory, 0.09 of
+                // 0.55 ms at C5.  The counter retires loads in order among themselves; whether a STORE may retire ahead of an older
+                // load is not something to rest correctness on, so the last load of the batch is checked by content: its first cell
+                // held a sentinel (a NaN payload no operand carries) when the batch was issued.
+                if (fetch && sent_on) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NLD + L::NST) : "memory");
+                    const volatile unsigned long long *cell = (const volatile unsigned long long *)(nxt + SENT_CELL);
+                    while (*cell == SENT) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                } else if (fetch || (NBUF > 2 && ch == NC - 1 && NC > 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NLD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                readin(nxt, CH - 1, nx, false);
+            }
+            Q4Out o;
+            if (sidx == CH - 1 && ch == NC - 1) {
+                // terminal step (backward_pass.jl:21-23 / :234-236 / :281-283), see back_pass_q4_kernel
+                s.V = in.cxx; s.VT = in.cxxT; s.vxc = in.cx;
+                o.Vn = s.V; o.Kc = 0.0; o.vx = in.cx; o.kk = 0.0; o.Quu = in.cuu;
+            } else if (sidx == CH - 1)
+                q4_step<LIMS, REG2, 0, Q4NoMid, GPS>(CH * ch + sidx, in, s, o, par);
+            else {
+                auto mid = [&]() __attribute__((always_inline)) { writeout(sidx + 1, prev); };
+                q4_step<LIMS, REG2, 0, decltype(mid), GPS>(CH * ch + sidx, in, s, o, par, mid);
+            }
+            if (sidx == 0) { writeout(0, o); }
+            if (sidx > 0 && fetch) {                           // this step's share of the NLD loads
+                constexpr int lo = (CH - 1 - sidx) * L::NLD / (CH - 1), hi = (CH - sidx) * L::NLD / (CH - 1);
+                if (sidx == CH - 1 && NBUF > 2) {              // the sentinel of the batch (lane 0's piece of the LAST load; the other lanes write a dump cell)
+                    unsigned long long *sc = (unsigned long long *)(lane == 0 ? lin[ipv] + SENT_CELL : lout + L::O_DUMP + lane);
+                    *sc = SENT;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int i = lo; i < hi; ++i) dma_one(tgt, lin[ipv], i);
+            }
+            prev = o;
+            in = nx;
+        }
+        if (!(EXP & 1)) drain(ch);
+        ib = inx;
+    }
+    if (s.diverge && act) {
+        q4_zero_fill(a, b, q16, s.diverge);
+        if (GPS) for (size_t t = q16; t < (size_t)s.diverge; t += 16) a.Quui[(size_t)N * b + t] = 0.0;       // :344 is not reached at and below the failing step
+    }
+    if (act && q16 == 0) { a.dV[2 * b] = s.dV0; a.dV[2 * b + 1] = s.dV1; a.diverge[b] = s.diverge; }
+}
+
+
 // ---- back_pass_gps for n = 4, m = 1 on the same kernel (backward_pass.jl:259-350).  c̃• = c•/η + c•kl for every step but the last,
 // where the reference takes Vx[:,N] = cx[:,N], Vxx[:,:,N] = cxx[:,:,N] as they are and Quu[:,:,N] = cuu/η + cuukl (:281-283).
 struct GpsCombine {
@@ -652,12 +933,26 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
     const char *lv = ddp_env(h, ENV_Q4_LDS);                     // 0 / 1: never / whenever possible the LDS-group kernel (A/B, tests)
     // the LDS-group kernel is the latency kernel: 24 KB of LDS per wave let 6 of them share a CU, and from two waves per SIMD on the
     // pair kernel hides its issue gaps behind the other wave (B = 8192: 0.66 ms against 0.90 ms; B = 6144: 0.61 against 0.53, B = 4096: 0.44 against 0.39)
-    const bool few = lv ? lv[0] == '1' : d->B <= 6144;
-    const bool chunked = paired && d->fx_tv && (d->N % Q4L_CH == 0) && d->N >= 2 * Q4L_CH && exp == 0 && few;
-    if (chunked) {
+    const bool few = lv ? (lv[0] == '1' || lv[0] == 'o') : d->B <= 6144;
+    const bool c3exp = exp >= 11 && exp <= 13 && d->has_lims && d->regType == 2;      // DDP_Q4_EXP=11|12|13: removal experiments of the chunked kernel (C3 shape)
+    const bool chunked = paired && d->fx_tv && (d->N % Q4L_CH == 0) && d->N >= 2 * Q4L_CH && (exp == 0 || c3exp) && few;
+    a.eta = nullptr; a.Quui = nullptr;
+    if (chunked && lv && lv[0] == 'o') {                        // DDP_Q4_LDS=o: the first chunked layout (A/B timing against q4c)
 #define Q4L(L_, R_) hipLaunchKernelGGL((back_pass_q4l_kernel<L_, R_>), grid, block, 0, h->stream, a)
         if (d->has_lims && reg2) Q4L(true, true); else if (d->has_lims) Q4L(true, false); else if (reg2) Q4L(false, true); else Q4L(false, false);
 #undef Q4L
+    } else if (chunked) {
+        const ddp_kl_cost_terms nokl = {};
+        if (c3exp) {
+            if (exp == 11) hipLaunchKernelGGL((back_pass_q4c_kernel<true, true, false, 8, 1>), grid, block, 0, h->stream, a, nokl);
+            else if (exp == 12) hipLaunchKernelGGL((back_pass_q4c_kernel<true, true, false, 8, 2>), grid, block, 0, h->stream, a, nokl);
+            else hipLaunchKernelGGL((back_pass_q4c_kernel<true, true, false, 8, 3>), grid, block, 0, h->stream, a, nokl);
+            DDP_HIP(hipGetLastError());
+            return 0;
+        }
+#define Q4C_(L_, R_) hipLaunchKernelGGL((back_pass_q4c_kernel<L_, R_, false, 8>), grid, block, 0, h->stream, a, nokl)
+        if (d->has_lims && reg2) Q4C_(true, true); else if (d->has_lims) Q4C_(true, false); else if (reg2) Q4C_(false, true); else Q4C_(false, false);
+#undef Q4C_
     } else if (paired) {
         if (d->has_lims && reg2) {
             switch (exp) {
@@ -694,6 +989,34 @@ int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double
     const char *q4e = ddp_env(h, ENV_GPS_Q4);                      // 0: never (the lane-per-trajectory kernel instead; A/B timing, tests)
     if (q4e && q4e[0] == '0') return 1;
     const long N = d->N, B = d->B, NB = N * B;
+    {   // chunks of four steps through the LDS with c̃• = c•/η + c•kl formed in the kernel (back_pass_q4c_kernel): ONE launch, no c̃• buffers.
+        // DDP_GPS_Q4L=0: the prepass + one-step kernel below (A/B timing, cross-check in the tests); =o: prepass + the first chunked kernel
+        const char *le0 = ddp_env(h, ENV_GPS_Q4L);
+        const bool al16f = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)cx | (uintptr_t)cu | (uintptr_t)cxx | (uintptr_t)cxu | (uintptr_t)cuu | (uintptr_t)kl->cx |
+                              (uintptr_t)kl->cu | (uintptr_t)kl->cxx | (uintptr_t)kl->cxu | (uintptr_t)kl->cuu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu |
+                              (uintptr_t)Quui | (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)(d->has_lims ? u : fx)) & 15) == 0);
+        if (!le0 && d->N % 4 == 0 && d->N >= 8 && al16f && h->sink != nullptr && d->B <= 6144 && Quui) {
+            Q4Args a;
+            a.N = d->N; a.B = d->B; a.regType = 1;
+            a.fx_t = 16; a.fx_b = d->fx_batched ? 16 * N : 0;
+            a.fu_t = 4; a.fu_b = d->fx_batched ? 4 * N : 0;
+            a.cxx_t = 16; a.cxx_b = d->cost_batched ? 16 * N : 0; a.cxu_t = 4; a.cxu_b = d->cost_batched ? 4 * N : 0; a.cuu_t = 1; a.cuu_b = d->cost_batched ? N : 0;
+            a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = nullptr; a.lims = lims;
+            a.u = u; a.active = active;
+            a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+            a.eta = kl->eta; a.Quui = Quui; a.sink = (double *)h->sink;
+            const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
+            const char *ex = ddp_env(h, ENV_Q4_EXP);            // removal experiments (profiles/q4_exp.sh): 1 no result stores, 2 no operand loads after the first two chunks
+            const int exp = ex ? atoi(ex) : 0;
+            if (d->has_lims && exp == 1) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4, 1>), grid, block, 0, h->stream, a, *kl);
+            else if (d->has_lims && exp == 2) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4, 2>), grid, block, 0, h->stream, a, *kl);
+            else if (d->has_lims && exp == 3) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4, 3>), grid, block, 0, h->stream, a, *kl);
+            else if (d->has_lims) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4>), grid, block, 0, h->stream, a, *kl);
+            else hipLaunchKernelGGL((back_pass_q4c_kernel<false, false, true, 4>), grid, block, 0, h->stream, a, *kl);
+            DDP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     auto al = [](size_t b_) { return (b_ + 255) & ~(size_t)255; };
     const size_t s4 = al((size_t)4 * NB * 8), s1 = al((size_t)NB * 8), s16 = al((size_t)16 * NB * 8), bytes = 2 * s4 + 2 * s1 + s16;
     if (bytes > h->pad_bytes) {
@@ -721,7 +1044,7 @@ int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double
     a.cx = c.ox; a.cu = c.ou; a.cxx = c.oxx; a.cxu = c.oxu; a.cuu = c.ouu; a.fx = fx; a.fu = fu; a.lambda = nullptr; a.lims = lims;
     a.u = u; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
-    a.eta = kl->eta; a.sink = (double *)h->sink;
+    a.eta = kl->eta; a.Quui = nullptr; a.sink = (double *)h->sink;
     const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
     // chunks of eight steps through the LDS (the q4l scheme, here with the time-varying c̃xx, c̃xu, c̃uu in the image): 13 direct-to-LDS loads
     // and 7 stores per 8 steps instead of 10 + 2 vector-memory instructions per step.  DDP_GPS_Q4L=0: the one-step kernel (A/B, tests)
