@@ -780,8 +780,6 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4c_kernel(Q4Args a, const
     // the stores do (loads return in order among themselves; stores may pass them).  With vmcnt(0) and two images a chunk of four
     // steps (~4 us) waited for its predecessor's result stores to reach memory: 0.13 of 0.58 ms (DDP_Q4_EXP, C5).
     constexpr int NBUF = L::NBUF;
-    constexpr unsigned long long SENT = 0x7FF4DDA5C0DEF00Dull;
-    constexpr int SENT_CELL = L::I_SCA + 128 * (L::LD_SCA - 1);   // first double of the first piece of the last load of a batch (trajectory 0 of the wave: always fetched)
     dma(NC - 1, lin[0]);
     if (NC > 1) dma(NC - 2, lin[1]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -792,32 +790,18 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4c_kernel(Q4Args a, const
     int ib = 0;                                                 // image of the current chunk
     for (int ch = NC - 1; ch >= 0; --ch) {
         const double *cur = lin[ib];
-        const int inx = ib + 1 < NBUF ? ib + 1 : 0, ipv = ib > 0 ? ib - 1 : NBUF - 1;
+        const int inx = ib + 1 < NBUF ? ib + 1 : 0;
         const double *nxt = lin[inx];
-        // while this chunk is worked on, the image of the chunk before it (free since that chunk ended) takes the chunk NBUF - 1 further
-        // on — its loads are SPREAD over the steps CH-1 .. 1 (a burst of NLD loads + NST stores at the end of a chunk cost 0.10 ms of
-        // 0.56 at C5: a vector-memory instruction issued into a busy queue costs a lone wave 100-200 cycles instead of ~60)
-        const int tgt = ch + 1 - NBUF;
-        const bool fetch = tgt >= 0 && ch <= NC - 2 && !(EXP & 2);
-        const bool sent_on = NBUF > 2 && ch + 1 <= NC - 2;      // the next chunk's image came by a batch issued in the loop (with its sentinel)
 #pragma unroll
         for (int sidx = CH - 1; sidx >= 0; --sidx) {
             Q4In nx;
             if (sidx > 0) readin(cur, sidx - 1, nx, false);
             else {
-                // The image of the next chunk was requested a chunk ago; since then this wave has issued the NST result stores of the
-                // chunk before and the NLD loads of this chunk.  vmcnt(NLD + NST) lets exactly those stay in flight — waiting for the
-                // stores as well (vmcnt(NLD): they are the oldest of the newest) stalled every chunk for their trip to memory, 0.09 of
-                // 0.55 ms at C5.  The counter retires loads in order among themselves; whether a STORE may retire ahead of an older
-                // load is not something to rest correctness on, so the last load of the batch is checked by content: its first cell
-                // held a sentinel (a NaN payload no operand carries) when the batch was issued.
-                if (fetch && sent_on) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NLD + L::NST) : "memory");
-                    const volatile unsigned long long *cell = (const volatile unsigned long long *)(nxt + SENT_CELL);
-                    while (*cell == SENT) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");
-                } else if (fetch || (NBUF > 2 && ch == NC - 1 && NC > 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NLD) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // three images: the loads of the chunk after next (the newest NLD loads) may stay in flight.  (Tried and dropped, C5:
+                // vmcnt(NLD + NST) with a content check of the last load so that the newest stores stay in flight too, and the loads
+                // spread over the steps of a chunk instead of one burst at its end: 0.56 -> 0.65 ms.)
+                if (NBUF > 2) { if (ch >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NLD) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next chunk was requested a whole chunk ago
                 readin(nxt, CH - 1, nx, false);
             }
             Q4Out o;
@@ -832,19 +816,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_q4c_kernel(Q4Args a, const
                 q4_step<LIMS, REG2, 0, decltype(mid), GPS>(CH * ch + sidx, in, s, o, par, mid);
             }
             if (sidx == 0) { writeout(0, o); }
-            if (sidx > 0 && fetch) {                           // this step's share of the NLD loads
-                constexpr int lo = (CH - 1 - sidx) * L::NLD / (CH - 1), hi = (CH - sidx) * L::NLD / (CH - 1);
-                if (sidx == CH - 1 && NBUF > 2) {              // the sentinel of the batch (lane 0's piece of the LAST load; the other lanes write a dump cell)
-                    unsigned long long *sc = (unsigned long long *)(lane == 0 ? lin[ipv] + SENT_CELL : lout + L::O_DUMP + lane);
-                    *sc = SENT;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-#pragma unroll
-                for (int i = lo; i < hi; ++i) dma_one(tgt, lin[ipv], i);
-            }
             prev = o;
             in = nx;
         }
+        // the image of this chunk is free: it takes the chunk NBUF further on
+        if (ch >= NBUF && !(EXP & 2)) dma(ch - NBUF, lin[ib]);
         if (!(EXP & 1)) drain(ch);
         ib = inx;
     }

@@ -63,7 +63,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
     h->device = device;
     h->scratch = nullptr;
     h->scratch_bytes = 0;
-    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr; h->sh = nullptr; h->sh_bytes = 0; h->sh_attr = false; h->ncu = 0; h->sched_aux = nullptr; h->last_kernel[0] = h->last_kernel[1] = nullptr; ddp_reload_env(h);
+    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr; h->sh = nullptr; h->sh_bytes = 0; h->sh_attr = false; h->ncu = 0; h->sched_aux = nullptr; h->diag_next = 0; h->diag_skip = 0; for (auto &e : h->diag_cache) { e.Q = e.R = nullptr; e.n = e.m = e.ok = 0; } h->last_kernel[0] = h->last_kernel[1] = nullptr; ddp_reload_env(h);
     h->h_pinned = nullptr;
     h->timing = nullptr; h->timing_cap = 0; h->tev_ok = false;
     h->owns_stream = !adopt;
@@ -348,6 +348,8 @@ int ddp_forward_pass_f64(ddp_handle h, const ddp_problem *p, const double *K, co
     if (rc) return rc;
     ddp_problem pd = *p;
     if (p->kind == DDP_PROBLEM_LQ) { pd.A = A.in(p->A, n * n * dc); pd.Bm = A.in(p->Bm, n * m * dc); }
+    { const int rd_ = ddp_check_cost_diag_host(p); if (rd_) return rd_; }
+    DiagVerified diag_verified_(h);                          // Q, R were tested on the host; the staged copies need no second test
     pd.Q = A.in(p->Q, n * n); pd.R = A.in(p->R, m * m);
     const double *dK = A.in(K, m * n * N * B), *dk = A.in(k, m * N * B), *dx0 = A.in(x0, n * B), *du = A.in(u, m * N * B),
                  *dx = A.in(x, n * N * B), *dl = A.in(lims, 2 * m);

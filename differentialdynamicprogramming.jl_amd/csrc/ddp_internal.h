@@ -28,6 +28,9 @@ struct ddp_handle_s {
     size_t       sh_bytes;
     bool         sh_attr;         // its dynamic-LDS attribute has been set on this device
     int          ncu;             // compute units of the device (0: not asked yet)
+    struct { const void *Q, *R; int n, m, ok; } diag_cache[8];      // verdicts of ddp_check_cost_diag (forward_pass.hip)
+    int          diag_next;
+    int          diag_skip;       // > 0: a host-pointer flavour has verified Q, R on the host and staged them itself (addresses recycle)
     hipStream_t  sched_aux;       // ilqg.hip, slot scheduler: side stream of the initial rollouts + its two events (created on first use)
     hipEvent_t   sched_ev[2];
     char         envv[ENV_COUNT][24];
@@ -71,6 +74,14 @@ static inline const char *ddp_env(ddp_handle h, int id) { return h->envset[id] ?
 
 // grows the handle's scratch to at least `bytes` (contents not preserved)
 int ddp_scratch(ddp_handle h, size_t bytes, void **out);
+
+// ddp_problem::cost_diag = 1 declares Q and R diagonal (the fused rollout cost reads only the diagonals): verified on the first call
+// with a (Q, R) pointer pair — one small device-to-host copy — and cached per handle; 0 ok, < 0 refused
+int ddp_check_cost_diag(ddp_handle h, const ddp_problem *p);
+// the same test on HOST copies of Q, R (the host-pointer flavours, before they stage the problem); while a DiagVerified lives the
+// device-side test is skipped for this handle (the staging addresses are recycled from call to call: a pointer-keyed verdict would go stale)
+int ddp_check_cost_diag_host(const ddp_problem *p);
+struct DiagVerified { ddp_handle h; explicit DiagVerified(ddp_handle h_) : h(h_) { ++h->diag_skip; } ~DiagVerified() { --h->diag_skip; } };
 
 // kernel launchers (each in its own .hip)
 int ddp_launch_back_pass(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,

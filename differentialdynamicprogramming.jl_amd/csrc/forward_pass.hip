@@ -15,6 +15,7 @@
 // step i computes.  The time loop is a strict dependency chain: throughput comes from the
 // (trajectory, α) batch, not from the horizon.
 #include <stdlib.h>
+#include <vector>
 #include "ddp_internal.h"
 
 namespace {
@@ -249,6 +250,39 @@ int launch_fp(ddp_handle h, const FPArgs &a)
 
 int ddp_cost_len(const ddp_problem *p) { return p->kind == DDP_PROBLEM_PENDCART ? p->N + 1 : p->N; }
 
+int ddp_check_cost_diag_host(const ddp_problem *p)
+{
+    if (!p->cost_diag || !p->Q || !p->R) return 0;
+    const int n = p->n, m = p->m;
+    int ok = 1;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) if (i != j && p->Q[i + (size_t)n * j] != 0.0) ok = 0;
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) if (i != j && p->R[i + (size_t)m * j] != 0.0) ok = 0;
+    DDP_CHECK(ok, "ddp_problem.cost_diag = 1 but Q or R has a non-zero off-diagonal entry (the fused rollout cost would drop it); set cost_diag = 0");
+    return 0;
+}
+
+int ddp_check_cost_diag(ddp_handle h, const ddp_problem *p)
+{
+    if (h->diag_skip > 0) return 0;
+    for (const auto &e : h->diag_cache)
+        if (e.Q == p->Q && e.R == p->R && e.n == p->n && e.m == p->m && e.Q) {
+            DDP_CHECK(e.ok, "forward_pass: ddp_problem.cost_diag = 1 but Q or R has a non-zero off-diagonal entry (the fused rollout cost would drop it); set cost_diag = 0");
+            return 0;
+        }
+    const int n = p->n, m = p->m;
+    std::vector<double> q((size_t)n * n), r((size_t)m * m);
+    DDP_HIP(hipMemcpyAsync(q.data(), p->Q, q.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DDP_HIP(hipMemcpyAsync(r.data(), p->R, r.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    int ok = 1;
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) if (i != j && q[i + (size_t)n * j] != 0.0) ok = 0;
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) if (i != j && r[i + (size_t)m * j] != 0.0) ok = 0;
+    auto &e = h->diag_cache[h->diag_next++ % 8];
+    e.Q = p->Q; e.R = p->R; e.n = n; e.m = m; e.ok = ok;
+    DDP_CHECK(ok, "forward_pass: ddp_problem.cost_diag = 1 but Q or R has a non-zero off-diagonal entry (the fused rollout cost would drop it); set cost_diag = 0");
+    return 0;
+}
+
 int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K, const double *k,
                              const double *x0, const double *u, const double *x, const double *alpha,
                              int nalpha, const double *lims, const int32_t *active, double *xnew,
@@ -263,7 +297,8 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     // the trailing field of ddp_problem (library 0.2.0): a caller built against the older layout, or one that does not zero the struct,
     // hands over garbage here — anything but 0 / 1 is refused instead of silently selecting the diagonal-cost rollout
     DDP_CHECK(p->cost_diag == 0 || p->cost_diag == 1, "forward_pass: ddp_problem.cost_diag = %d (0 or 1; zero-initialise the struct)", p->cost_diag);
-    // diff_fun with wrapped coordinates: only the run-time-sized kernel below implements it
+    if (p->cost_diag) { const int rd = ddp_check_cost_diag(h, p); if (rd) return rd; }
+    // diff_fun with wrapped coordinates: the pendulum's row / lane kernels and the run-time-sized kernel below implement it
     DDP_CHECK(p->diff_wrap == 0 || (p->n <= DDP_MAX_N_GENERIC && (p->n >= 32 || (p->diff_wrap >> p->n) == 0)),
               "forward_pass: ddp_problem.diff_wrap = 0x%x needs n <= %d and no bits at or above n = %d (zero-initialise the struct)", p->diff_wrap, DDP_MAX_N_GENERIC, p->n);
     if (p->n > DDP_MAX_N_GENERIC || (p->diff_wrap == 0 && ddp_env(h, ENV_FORWARD) && ddp_env(h, ENV_FORWARD)[0] == 'b')) {   // large states
@@ -273,8 +308,12 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     }
     // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
     const char *fwd_env = ddp_env(h, ENV_FORWARD);               // read per call so tests can switch paths
-    const bool force_group = (fwd_env && fwd_env[0] == 103) || p->diff_wrap != 0;
-    if (!force_group) {
+    const bool force_group = (fwd_env && fwd_env[0] == 103);
+    if (!force_group && p->diff_wrap != 0) {                     // diff_fun with wrapped coordinates: the pendulum's row / lane kernels have it
+        const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
+        if (rc <= 0) { h->last_kernel[1] = "forward_dpp_kernel"; return rc; }
+    }
+    if (!force_group && p->diff_wrap == 0) {
         const int rp = ddp_launch_forward_pipe(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rp <= 0) { h->last_kernel[1] = "forward_pipe_kernel"; return rp; }
         const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);

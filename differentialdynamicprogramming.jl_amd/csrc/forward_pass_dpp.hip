@@ -28,11 +28,20 @@ struct FDArgs {
     double goal[4];
     double *cnew, *csum;
     double *sink;               // >= 64 x 8 B that lanes without an output write to (stores carry no exec-mask branch); NULL: masked stores
+    unsigned wrap;              // ddp_problem::diff_wrap: coordinates whose difference x̂ - x is wrapped to [-π, π] (pendulum kernels)
 };
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #include "pend_math.h"
+
+// diff_fun for an angle coordinate (src/forward_pass.jl:19 `K*diff_fun(x̂, x)`; ddp_problem::diff_wrap): d - 2π·rint(d / 2π) with 2π in
+// two parts — the arithmetic of the run-time-sized kernel (forward_pass.hip: wrap_pi), one v_rndne_f64 + 2 multiply-adds on the chain
+__device__ __forceinline__ double wrap_pi2(double d)
+{
+    const double q = rint(d * 0x1.45f306dc9c883p-3);
+    return fma(-q, 0x1.1a62633145c07p-52, fma(-q, 0x1.921fb54442d18p+2, d));
+}
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_dpp_kernel(FDArgs a)
 // sincos (and only 5 of them carry state): with the 6-11 step sizes of a line search there are enough rollouts to give every
 // lane its own — 16x fewer wave-instructions per rollout.  Same arithmetic (system_pendcart.jl:83-89, forward_pass.jl:17-24;
 // K·dx summed in index order).  Operands are prefetched DL steps ahead (a lane's loads are its own 32-byte pieces).
-template <bool POLICY, bool LIMS, bool FUSE>
+template <bool POLICY, bool LIMS, bool FUSE, bool WRAP = false>
 __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs a)
 {
     constexpr int n = 4, DL = 4;
@@ -401,11 +410,18 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_lane_pendcart_kernel(FDArgs 
         double uu = o.u;
         if (POLICY) {
             uu += o.k * alpha;                                           // unew .+= k*α
-            double s = o.K0.x * (x0v - o.x0.x);
-            s += o.K0.y * (x1v - o.x0.y);
-            s += o.K1.x * (x2v - o.x1.x);
-            s += o.K1.y * (x3v - o.x1.y);
-            uu += s;                                                     // unew .+= K*dx
+            double e0 = x0v - o.x0.x, e1 = x1v - o.x0.y, e2 = x2v - o.x1.x, e3 = x3v - o.x1.y;
+            if (WRAP) {                                                  // diff_fun: the named coordinates wrapped to [-π, π] (wave-uniform tests)
+                if (a.wrap & 1u) e0 = wrap_pi2(e0);
+                if (a.wrap & 2u) e1 = wrap_pi2(e1);
+                if (a.wrap & 4u) e2 = wrap_pi2(e2);
+                if (a.wrap & 8u) e3 = wrap_pi2(e3);
+            }
+            double s = o.K0.x * e0;
+            s += o.K0.y * e1;
+            s += o.K1.x * e2;
+            s += o.K1.y * e3;
+            uu += s;                                                     // unew .+= K*diff_fun(x̂, x)
         }
         if (LIMS) uu = clampd(uu, lo, hi);
         if (uu != uu) uu = 0.0;
@@ -481,10 +497,11 @@ __device__ __forceinline__ double row_bcast_all(double x)
     asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(x), "n"(L));
     return d;
 }
-template <bool POLICY, bool LIMS, bool FUSE>
+template <bool POLICY, bool LIMS, bool FUSE, bool WRAP = false>
 __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
 {
     constexpr int n = 4, G = 16, GPW = DDP_WAVE / G, TS = 17, D = 8;
+    const bool wrapj = WRAP && (((a.wrap >> (threadIdx.x & 3)) & 1u) != 0) && (threadIdx.x % G) < n;      // this lane's coordinate is an angle
     __shared__ double ctile[FUSE ? GPW * 16 * TS : 1];
     const int N = a.N, B = a.B;
     const int lane = threadIdx.x, grp = lane / G, j = lane % G;
@@ -551,7 +568,9 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
         double uu = row_bcast_all<8>(ld);                                // ū_i  (ld comes from memory: no VALU -> DPP hazard)
         if (POLICY) {
             const double xi = __builtin_amdgcn_update_dpp(0.0, ld, 0x104, 0xf, 0xf, true);      // row_shl:4: x_i[j] from lane j + 4
-            double pr = ld * (xh - xi);                                  // K_i[j] (x̂_j - x_j) in lanes 0-3
+            double dxj = xh - xi;
+            if (WRAP) dxj = wrapj ? wrap_pi2(dxj) : dxj;                 // diff_fun (forward_pass.jl:19)
+            double pr = ld * dxj;                                        // K_i[j] diff(x̂_j, x_j) in lanes 0-3
             fmac_bc<9>(uu, ld, alpha);                                   // unew .+= k*α
             dpp_fence(pr);
             double s1 = 0.0;
@@ -723,6 +742,12 @@ int launch_pend_row(ddp_handle h, const FDArgs &a)
     const long total = (long)a.B * a.nalpha;
     const dim3 grid((unsigned)((total + 3) / 4)), block(DDP_WAVE);
     const int key = (a.has_policy ? 2 : 0) | (a.has_lims ? 1 : 0);
+    if (a.wrap != 0 && a.has_policy) {                          // diff_fun with wrapped coordinates (only a policy has a difference to wrap)
+        if (a.has_lims) hipLaunchKernelGGL((forward_pend_row_kernel<true, true, FUSE, true>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((forward_pend_row_kernel<true, false, FUSE, true>), grid, block, 0, h->stream, a);
+        DDP_HIP(hipGetLastError());
+        return 0;
+    }
     switch (key) {
     case 0: hipLaunchKernelGGL((forward_pend_row_kernel<false, false, FUSE>), grid, block, 0, h->stream, a); break;
     case 1: hipLaunchKernelGGL((forward_pend_row_kernel<false, true, FUSE>), grid, block, 0, h->stream, a); break;
@@ -748,7 +773,9 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
     a.A = p->A; a.Bm = p->Bm; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.lims = lims; a.active = active;
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
-    a.xnew = xnew; a.unew = unew; a.sink = (double *)h->sink;
+    a.xnew = xnew; a.unew = unew; a.sink = (double *)h->sink; a.wrap = p->diff_wrap;
+    // wrapped differences exist in the pendulum's own kernels only (row and lane); everything else goes to the run-time-sized kernel
+    if (p->diff_wrap != 0 && (lq || !a.sink || (ddp_env(h, ENV_FORWARD_PEND) && ddp_env(h, ENV_FORWARD_PEND)[0] == '0'))) return 1;
     const char *fuse_env = ddp_env(h, ENV_FORWARD_FUSE);           // 0: keep the separate cost kernel (A/B timing, tests)
     const bool fuse = p->cost_diag != 0 && !(fuse_env && fuse_env[0] == '0');     // Q, R declared diagonal: cost inside the rollout kernel
     a.Q = p->Q; a.R = p->R; a.cnew = cnew; a.csum = csum;
@@ -765,6 +792,12 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
         if (fuse) hipLaunchKernelGGL((forward_lane_pendcart_kernel<P_, L_, true>), grid, block, 0, h->stream, a);     \
         else hipLaunchKernelGGL((forward_lane_pendcart_kernel<P_, L_, false>), grid, block, 0, h->stream, a);         \
     } while (0)
+        if (a.wrap != 0 && a.has_policy) {                          // diff_fun with wrapped coordinates
+            if (a.has_lims && fuse) hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, true, true, true>), grid, block, 0, h->stream, a);
+            else if (a.has_lims) hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, true, false, true>), grid, block, 0, h->stream, a);
+            else if (fuse) hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, false, true, true>), grid, block, 0, h->stream, a);
+            else hipLaunchKernelGGL((forward_lane_pendcart_kernel<true, false, false, true>), grid, block, 0, h->stream, a);
+        } else
         switch (key) {
         case 0: DDP_LANE(false, false); break;
         case 1: DDP_LANE(false, true); break;

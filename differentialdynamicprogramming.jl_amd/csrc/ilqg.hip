@@ -998,6 +998,9 @@ static int ilqg_host(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o,
     const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p);
     const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? B : 1);
     // the driver uses the handle's scratch itself, so the host flavour owns separate allocations
+    // cost_diag = 1 is a declaration about Q, R: verified here, on the host copies, before anything is staged
+    { const int rd_ = ddp_check_cost_diag_host(p); if (rd_) return rd_; }
+    DiagVerified diag_verified_(h);                          // Q, R were tested on the host; the staged copies need no second test
     struct Buf { void *d; void *hdst; size_t bytes; };
     std::vector<Buf> bufs;
     bool failed = false;
@@ -1065,6 +1068,9 @@ static int sched_host(ddp_handle h, const ddp_problem *p, const ddp_ilqg_opts *o
     DDP_CHECK(h && p && x0 && u0, "ilqg_sched: null argument");
     const size_t n = p->n, m = p->m, N = p->N, P = p->B, CL = ddp_cost_len(p);
     const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? P : 1);
+    // cost_diag = 1 is a declaration about Q, R: verified here, on the host copies, before anything is staged
+    { const int rd_ = ddp_check_cost_diag_host(p); if (rd_) return rd_; }
+    DiagVerified diag_verified_(h);                          // Q, R were tested on the host; the staged copies need no second test
     struct Buf { void *d; void *hdst; size_t bytes; };
     std::vector<Buf> bufs;
     bool failed = false;

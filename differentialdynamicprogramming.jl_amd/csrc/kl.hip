@@ -904,6 +904,9 @@ int ddp_ilqgkl_f64(ddp_handle h, const ddp_problem *p, const ddp_ilqgkl_opts *o,
     DDP_CHECK(p && x0 && Kp && kp && Sp && Sip && model_fx && R1, "ilqgkl: null argument");
     const size_t n = p->n, m = p->m, N = p->N, B = p->B, CL = ddp_cost_len(p), NB = N * B;
     const size_t dc = (p->dyn_tv ? N : 1) * (p->dyn_batched ? B : 1);
+    // cost_diag = 1 is a declaration about Q, R: verified here, on the host copies, before anything is staged
+    { const int rd_ = ddp_check_cost_diag_host(p); if (rd_) return rd_; }
+    DiagVerified diag_verified_(h);                          // Q, R were tested on the host; the staged copies need no second test
     struct Buf { void *d; void *hdst; size_t bytes; };
     std::vector<Buf> bufs;
     bool failed = false;
