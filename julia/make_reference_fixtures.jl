@@ -17,6 +17,10 @@
 #   df_pendcart the `df` closure of demo_pendcart (restated below from src/system_pendcart.jl:125-154)
 #   ilqg_*      iLQG(f,costfun,df,x0,u0; ...)                                                            src/iLQG.jl:143
 #   kl_gps_*    ∇kl, back_pass_gps, forward_covariance, kl_div_wiki       src/klutils.jl:8,70; backward_pass.jl:259; forward_pass.jl:37
+#               + calc_η on the fixture's own divergence (four step sizes around its mean)               src/klutils.jl:110-133
+#   kl_ilqgkl_* iLQGkl(dynamics,costfun,derivs,x0,traj_prev,model; kl_step, cost, ...)                    src/iLQGkl.jl:25-178
+#   ilqg_warm_* iLQG with a PRE-ROLLED x0[n,N] and its cost (the warm start of an MPC loop)               src/iLQG.jl:193-197
+#   ilqg_trace_* iLQG + every per-iteration trace key (:λ :dλ :α :improvement :cost :reduce_ratio :grad_norm)  src/iLQG.jl:257,325-330
 using LinearAlgebra, Printf
 using DifferentialDynamicProgramming
 const DDP = DifferentialDynamicProgramming
@@ -186,6 +190,49 @@ function run_ilqg(w, f, costfun, df, x0, u0; kwargs...)
     emit(w, "Vx", Vx); emit(w, "Vxx", Vxx); emit(w, "cost", cost isa Number ? [cost] : vec(cost))
     its, tc = get(trace, :cost)
     emit(w, "tr_cost", collect(Float64, tc)); emit(w, "iter", length(tc) + 1)
+    # the other per-iteration keys (iLQG.jl:257 :grad_norm, :325-330); a key that a given version of the reference does not push is skipped
+    for (sym, key) in ((:λ, "tr_lambda"), (:dλ, "tr_dlambda"), (:α, "tr_alpha"), (:improvement, "tr_improvement"),
+                       (:reduce_ratio, "tr_reduce_ratio"), (:grad_norm, "tr_grad_norm"))
+        try
+            _, v = get(trace, sym)
+            emit(w, key, collect(Float64, v))
+        catch err
+            @warn "trace key $sym not recorded" err
+        end
+    end
+end
+
+# the model argument of iLQGkl / forward_covariance: LinearTimeVaryingModelsBase is un-vendored (SURVEY §8c); a fixture model that hands
+# back given arrays pins the arithmetic of everything downstream of it
+function define_fixture_model()
+    @eval import LinearTimeVaryingModelsBase
+    @eval LinearTimeVaryingModelsBase.df(mo::FixtureModel, x, u) = (mo.fx, mo.fu, [], [], [])
+    @eval LinearTimeVaryingModelsBase.covariance(mo::FixtureModel, x, u) = mo.R1
+end
+
+function run_ilqgkl(w, c)
+    A, B, Q, R = c["A"], c["B"], c["Q"], c["R"]
+    n, m = size(B); T = size(c["u"], 2)
+    f, costfun, costvec, _ = lq_closures(A, B, Q, R)
+    fx = repeat(A, 1, 1, T); fu = repeat(B, 1, 1, T)
+    cxx = repeat(Q, 1, 1, T); cuu = repeat(R, 1, 1, T); cxu = zeros(n, m, T)
+    derivs(x, u) = (fx, fu, [], [], [], Q * x, R * u, cxx, cxu, cuu)                 # the 10-tuple of iLQGkl.jl:88
+    eyeT = repeat(Matrix{Float64}(I, m, m), 1, 1, T)
+    prev = GaussianPolicy(T, n, m, zeros(m, n, T), copy(c["u"]), copy(eyeT), copy(eyeT))
+    define_fixture_model()
+    model = FixtureModel(fx, fu, c["R1"])
+    r = Base.invokelatest(iLQGkl, f, costvec, derivs, c["x"], prev, model; kl_step=c["kl_step"], cost=c["cost0"], max_iter=50, verbosity=0)
+    x, u, L, Vx, Vxx, cost, trace = r
+    emit(w, "xnew", x); emit(w, "unew", u); emit(w, "K", L.K); emit(w, "S", L.Σ); emit(w, "Si", L.Σi)
+    emit(w, "Vx", Vx); emit(w, "Vxx", Vxx); emit(w, "cost", cost isa Number ? [cost] : vec(cost))
+    for (sym, key) in ((:η, "eta_trace"), (:divergence, "divergence_trace"))
+        try
+            _, v = get(trace, sym)
+            emit(w, key, collect(Float64, v))
+        catch err
+            @warn "trace key $sym not recorded" err
+        end
+    end
 end
 
 # forward_covariance asks the model for df(model,x,u) and covariance(model,x,u) (LinearTimeVaryingModelsBase, un-vendored): a
@@ -219,6 +266,17 @@ function run_gps(w, c)
         emit(w, "sigmanew", sig)
         kld = DDP.kl_div_wiki(c["xnew"], c["x"], sig, traj, prev)
         emit(w, "kldiv", kld isa Number ? fill(Float64(kld), N) : kld)
+        # calc_η (klutils.jl:110-133), scalar kl_step, on this divergence: η too big / converged / η too small / just outside the 10 % band
+        if ndims(etab) == 1
+            dbar = sum(kld) / length(kld)
+            steps = [2.0, 1.0, 0.5, 1.0 / 0.85] .* dbar
+            eo = zeros(3, length(steps)); sat = zeros(Int, length(steps)); dv = zeros(length(steps))
+            for (j, st) in enumerate(steps)
+                e2, s2, d2 = DDP.calc_η(c["xnew"], c["x"], sig, copy(vec(etab)), traj, prev, st)
+                eo[:, j] = e2; sat[j] = s2 ? 1 : 0; dv[j] = d2
+            end
+            emit(w, "eta_kl_steps", steps); emit(w, "eta_out", eo); emit(w, "eta_satisfied", sat); emit(w, "eta_divergence", dv)
+        end
     catch err
         @warn "forward_covariance / kl_div_wiki skipped" err
     end
@@ -261,6 +319,14 @@ function main()
                          α=exp10.(range(0.2, stop=-3, length=6)), λmax=1e15, tol_fun=1e-8, tol_grad=1e-8, max_iter=1000)   # system_pendcart.jl:197-206
             elseif startswith(case, "kl_gps_")
                 run_gps(w, c)
+            elseif startswith(case, "kl_ilqgkl_")
+                run_ilqgkl(w, c)
+            elseif case == "ilqg_trace_lq"
+                f, costfun, costvec, df = lq_closures(c["A"], c["B"], c["Q"], c["R"])
+                run_ilqg(w, f, costvec, df, reshape(c["x0"], :, 1), c["u0"])
+            elseif case == "ilqg_warm_lq"
+                f, costfun, costvec, df = lq_closures(c["A"], c["B"], c["Q"], c["R"])
+                run_ilqg(w, f, costvec, df, c["x0"], c["u0"]; cost=c["cost0"])          # size(x0, 2) == N: pre-rolled (iLQG.jl:193-197)
             else
                 @warn "no runner for case $case"
             end

@@ -64,6 +64,16 @@ def ref_back_pass(bp, c, b):
               c["lims"], None, c["u"][..., b])
 
 
+COND_CAP = 1e-6                 # restatements further apart than this cannot judge a draw (it is counted, cross-checked on the device, bounded)
+# committed ceilings of the escapes per 1 000 cases of their kind (the slice of tests/test_gpu_fuzz_slice.py, seed 31, stays well below)
+MAX_ILL_PER_1000, MAX_UNJUDGED_PER_1000, MAX_KNIFE_PER_1000 = 8.0, 1.0, 30.0
+
+
+def escape_counts():
+    return dict(ill_conditioned=getattr(one_case, "ill_conditioned", 0), unjudged=getattr(one_case, "unjudged", 0),
+                knife_edge=getattr(ilqg_case, "knife_edge", 0), exploded_kl_draws=getattr(gps_case, "skipped", 0))
+
+
 def one_case(ddp, oc, rng, case):
     c = gen_case(rng)
     n, m, N, B, lims = c["n"], c["m"], c["N"], c["B"], c["lims"]
@@ -94,10 +104,25 @@ def one_case(ddp, oc, rng, case):
                 # restatements are 3.2e-8 / 6.7e-8 / 4.6e-8 apart (n = 4, m = 1, regType 2, horizons of 200-300 steps), 2.9e-6 on one with limits
                 # whose restatements are 2e-4 apart (seed 113, case 7195).  A defect shows on
                 # well-conditioned draws, where this branch changes nothing.
+                # Round 4 (ADVICE): the escape is bounded.  Restatements up to COND_CAP = 1e-6 apart: the draw is judged at 3x their distance
+                # and counted in `ill_conditioned`.  Further apart than that (seed 113, case 7195: 2e-4) the restatements cannot decide
+                # anything: the draw is counted in `unjudged` and the kernel under test is held against the run-time-sized reference kernel
+                # instead (DDP_BACKPASS=g, other arithmetic, same device): a defect of ONE kernel still shows.  The callers (the slice in
+                # tests/test_gpu_fuzz_slice.py, main below) fail when either count passes its committed ceiling.
                 if cond is None:
                     cond = draw_conditioning(c)
-                assert cond[name] <= 1e-3 and e <= 3.0 * cond[name], (name, e, "C vs NumPy restatement over the draw: %.3g" % cond[name], tag, "trajectory %d" % b)
-                one_case.ill_conditioned = getattr(one_case, "ill_conditioned", 0) + 1
+                assert e <= 3.0 * cond[name], (name, e, "C vs NumPy restatement over the draw: %.3g" % cond[name], tag, "trajectory %d" % b)
+                if cond[name] <= COND_CAP:
+                    one_case.ill_conditioned = getattr(one_case, "ill_conditioned", 0) + 1
+                else:
+                    assert cond[name] <= 1e-3, (name, e, "restatements %.3g apart: nothing can be concluded" % cond[name], tag)
+                    if c["impl"] != "g":
+                        os.environ["DDP_BACKPASS"] = "g"
+                        gen = ddp.back_pass(c["cx"], c["cu"], c["cxx"], c["cxu"], c["cuu"], c["fx"], c["fu"], c["lam"], c["regType"], lims, None, c["u"])
+                        os.environ.pop("DDP_BACKPASS", None)
+                        gref = {"K": gen[1].K, "k": gen[1].k, "Vx": gen[2], "Vxx": gen[3], "dV": gen[4]}[name][..., b]
+                        assert relerr(got, gref) <= 3.0 * cond[name], (name, "against the run-time-sized kernel", relerr(got, gref), cond[name], tag)
+                    one_case.unjudged = getattr(one_case, "unjudged", 0) + 1
                 continue
             worst = max(worst, e)
     # forward rollout with the gains just computed (LQ family), two step sizes
@@ -340,6 +365,11 @@ def main():
     for c in range(cases // 4):
         worst = max(worst, gps_case(ddp, oc, np.random.default_rng([seed, 200000 + c]), c))
     print("fuzz: %d KL-path cases passed (%d exploded draws not compared), worst relative error %.3g" % (cases // 4, getattr(gps_case, "skipped", 0), worst))
+    n = escape_counts()
+    print("fuzz escapes: %s (ceilings per 1 000: ill-conditioned %.0f, unjudged %.0f; knife edge %.0f per 1 000 solves)" % (n, MAX_ILL_PER_1000, MAX_UNJUDGED_PER_1000, MAX_KNIFE_PER_1000))
+    assert n["ill_conditioned"] <= max(2.0, MAX_ILL_PER_1000 * cases / 1000.0), n
+    assert n["unjudged"] <= max(1.0, MAX_UNJUDGED_PER_1000 * cases / 1000.0), n
+    assert n["knife_edge"] <= max(2.0, MAX_KNIFE_PER_1000 * (cases // 10) / 1000.0), n
 
 
 def main_ilqg(solves, seed):

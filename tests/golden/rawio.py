@@ -23,9 +23,15 @@ OUTPUTS = {
     "boxqp": {"x", "result", "free", "Hfree"},
     "fwd_": {"xnew", "unew", "cnew"},
     "df_": {"fx", "fu", "cx", "cu"},
-    "ilqg_": {"x", "u", "K", "k", "Quu", "Vx", "Vxx", "cost", "status", "iter", "lam", "n_backpass", "n_forward", "tr_cost"},
-    "kl_gps_": {"cxkl", "cukl", "cxxkl", "cxukl", "cuukl", "diverge", "K", "k", "Quui", "Quu", "Vx", "Vxx", "dV", "sigmanew", "kldiv"},
-    "kl_ilqgkl_": None,        # needs LinearTimeVaryingModelsBase (un-vendored, parity unpinned): not exported
+    "ilqg_": {"x", "u", "K", "k", "Quu", "Vx", "Vxx", "cost", "status", "iter", "lam", "n_backpass", "n_forward", "tr_cost", "tr_lambda", "tr_dlambda",
+              "tr_alpha", "tr_improvement", "tr_reduce_ratio", "tr_grad_norm"},
+    "kl_gps_": {"cxkl", "cukl", "cxxkl", "cxukl", "cuukl", "diverge", "K", "k", "Quui", "Quu", "Vx", "Vxx", "dV", "sigmanew", "kldiv",
+                # calc_η (src/klutils.jl:110-133) on the fixture's own divergence: written by the Julia script only (the step sizes are
+                # chosen around ITS mean divergence), compared in tests/test_julia_fixtures.py when present
+                "eta_kl_steps", "eta_out", "eta_satisfied", "eta_divergence"},
+    # the whole KL-constrained solve (src/iLQGkl.jl:25-178).  forward_covariance needs df / covariance of the un-vendored
+    # LinearTimeVaryingModelsBase: the Julia script supplies a fixture model with the given fx, R1 (as for kl_gps_*)
+    "kl_ilqgkl_": {"xnew", "unew", "K", "S", "Si", "Vx", "Vxx", "cost", "status", "iter", "eta", "divergence", "n_backpass"},
 }
 
 

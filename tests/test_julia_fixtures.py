@@ -74,6 +74,34 @@ class OracleImpl:
             x, u, (K, k, Quu), Vx, Vxx, cost, info = oc.ilqg(p, g["x0"], np.zeros((1, T)), lims=5.0 * np.array([[-1.0, 1.0]]), **_pend_kw_oracle())
         return dict(x=x, u=u, K=K, k=k, Quu=Quu, Vx=Vx, Vxx=Vxx, cost=cost, tr_cost=np.asarray(info["trace"]["cost"]))
 
+    def ilqg_warm(self, g):
+        n, m, N = g["A"].shape[0], g["B"].shape[1], g["u0"].shape[1]
+        p = self.oc.make_problem("lq", n, m, N, A=g["A"], B=g["B"], Q=g["Q"], R=g["R"])
+        x, u, (K, k, Quu), Vx, Vxx, cost, info = self.oc.ilqg_prerolled(p, g["x0"], g["u0"], cost0=g["cost0"])
+        return dict(x=x, u=u, K=K, k=k, Quu=Quu, Vx=Vx, Vxx=Vxx, cost=cost, iter=info["iter"])
+
+    def ilqg_trace(self, g):
+        n, m, N = g["A"].shape[0], g["B"].shape[1], g["u0"].shape[1]
+        p = self.oc.make_problem("lq", n, m, N, A=g["A"], B=g["B"], Q=g["Q"], R=g["R"])
+        x, u, (K, k, Quu), Vx, Vxx, cost, info = self.oc.ilqg_trace7(p, g["x0"], g["u0"])
+        out = dict(x=x, u=u, K=K, Vx=Vx, Vxx=Vxx, cost=cost, iter=info["iter"])
+        out.update({"tr_" + TRACE_KEYS[key]: v for key, v in info["history"].items()})
+        return out
+
+    def calc_eta(self, etab, dbar, kl_step):
+        return self.oc.calc_eta(etab, dbar, kl_step)
+
+    def ilqgkl(self, g):
+        oc = self.oc
+        n, m, T = g["A"].shape[0], g["B"].shape[1], g["u"].shape[1]
+        p = oc.make_problem("lq", n, m, T, A=g["A"], B=g["B"], Q=g["Q"], R=g["R"])
+        eye = np.repeat(np.eye(m)[:, :, None], T, 2)
+        prev = dict(K=np.zeros((m, n, T)), k=g["u"].copy(), S=eye.copy(), Si=eye.copy())
+        model = dict(fx=np.repeat(g["A"][:, :, None], T, 2), R1=g["R1"])
+        x, u, pol, Vx, Vxx, cost, info = oc.ilqgkl(p, g["x"], float(g["cost0"]), prev, model, kl_step=float(g["kl_step"]), max_iter=50)
+        return dict(xnew=x, unew=u, K=pol["K"], S=pol["S"], Si=pol["Si"], Vx=Vx, Vxx=Vxx, cost=cost, status=info["status"], iter=info["iter"],
+                    eta=info["eta"], divergence=info["divergence"])
+
     def gps(self, g):
         oc = self.oc
         terms = oc.kl_terms(g["Kp"], g["kp"], g["Sip"])
@@ -129,6 +157,35 @@ class HipImpl:
                                                     max_iter=1000)
         return dict(x=x, u=u, K=pol.K, k=pol.k, Quu=pol.Σi, Vx=Vx, Vxx=Vxx, cost=cost, tr_cost=tr["cost"])
 
+    def ilqg_warm(self, g):
+        ddp = self.ddp
+        x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(ddp.LQProblem(g["A"], g["B"], g["Q"], g["R"]), g["x0"], g["u0"], cost=g["cost0"])
+        return dict(x=x, u=u, K=pol.K, k=pol.k, Quu=pol.Σi, Vx=Vx, Vxx=Vxx, cost=cost, iter=int(tr["iter"]) if np.ndim(tr["iter"]) == 0 else int(tr["iter"][0]))
+
+    def ilqg_trace(self, g):
+        ddp = self.ddp
+        x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(ddp.LQProblem(g["A"], g["B"], g["Q"], g["R"]), g["x0"], g["u0"])
+        out = dict(x=x, u=u, K=pol.K, Vx=Vx, Vxx=Vxx, cost=cost, iter=int(tr["iter"]) if np.ndim(tr["iter"]) == 0 else int(tr["iter"][0]))
+        out.update({"tr_" + TRACE_KEYS[key]: np.asarray(v) for key, v in tr["history"].items()})
+        return out
+
+    def calc_eta(self, etab, dbar, kl_step):
+        # the host mirror's calc_η (klutils.jl:112-133) on a given mean divergence (the device loop's dual update, ddp_kl_dual_update_f64_dev,
+        # is the same arithmetic and is pinned through the whole-solve fixtures kl_ilqgkl_*)
+        e, sat, _ = self.kl.calc_η(None, None, None, np.array(etab, dtype=float), None, None, float(kl_step), _mean=float(dbar))
+        return e, sat
+
+    def ilqgkl(self, g):
+        ddp, kl = self.ddp, self.kl
+        n, m, T = g["A"].shape[0], g["B"].shape[1], g["u"].shape[1]
+        eye = np.repeat(np.eye(m)[:, :, None], T, 2)
+        prev = ddp.GaussianPolicy(T, n, m, np.zeros((m, n, T)), g["u"].copy(), eye.copy(), eye.copy())
+        fx, fu = np.repeat(g["A"][:, :, None], T, 2), np.repeat(g["B"][:, :, None], T, 2)
+        x, u, pol, Vx, Vxx, cost, tr = kl.iLQGkl(ddp.LQProblem(g["A"], g["B"], g["Q"], g["R"]), g["x"], prev, kl.Model(fx, fu, g["R1"]),
+                                                 kl_step=float(g["kl_step"]), cost=float(g["cost0"]), max_iter=50)
+        return dict(xnew=x, unew=u, K=pol.K, S=pol.Σ, Si=pol.Σi, Vx=Vx, Vxx=Vxx, cost=cost, status=int(np.ravel(tr["status"])[0]),
+                    iter=int(np.ravel(tr["iter"])[0]), eta=np.ravel(tr["η"]), divergence=float(np.ravel(tr["divergence"])[0]))
+
     def gps(self, g):
         ddp, kl = self.ddp, self.kl
         N, n, m = g["kp"].shape[1], g["Kp"].shape[1], g["Kp"].shape[0]
@@ -142,6 +199,10 @@ class HipImpl:
             out["sigmanew"] = kl.forward_covariance(kl.Model(g["fx"], g["fu"], g["R1"]), g["x"], g["u"], pol)
             out["kldiv"] = kl.kl_div_wiki(g["xnew"], g["x"], out["sigmanew"], pol, prev)
         return out
+
+
+TRACE_KEYS = {"λ": "lambda", "dλ": "dlambda", "α": "alpha", "improvement": "improvement", "cost": "cost", "reduce_ratio": "reduce_ratio",
+              "grad_norm": "grad_norm"}
 
 
 def _lims(g):
@@ -192,6 +253,39 @@ def compare(case, impl, ref):
         out = impl.df_pendcart(g)
         for key in ("fx", "fu", "cx", "cu"):
             _close(out[key], ref[key], (case, key))
+    elif case == "ilqg_warm_lq":
+        out = impl.ilqg_warm(g)                                     # pre-rolled x0[n,N] + cost (iLQG.jl:193-197)
+        assert abs(np.sum(out["cost"]) - np.sum(ref["cost"])) <= 1e-8 * abs(np.sum(ref["cost"]))
+        assert int(out["iter"]) == int(ref["iter"])
+        for key in ("x", "u", "Vx", "Vxx", "K"):
+            _close(out[key], ref[key], (case, key))
+    elif case == "ilqg_trace_lq":
+        out = impl.ilqg_trace(g)                                    # every per-iteration trace key (iLQG.jl:257,325-330)
+        assert int(out["iter"]) == int(ref["iter"])
+        for key in ("x", "u", "Vx", "Vxx", "K"):
+            _close(out[key], ref[key], (case, key))
+        for key in ("tr_lambda", "tr_dlambda", "tr_alpha", "tr_improvement", "tr_cost", "tr_reduce_ratio", "tr_grad_norm"):
+            if key not in ref:
+                continue                                            # a key this version of the reference does not record
+            r = np.ravel(np.asarray(ref[key], dtype=float))
+            o = np.ravel(np.asarray(out[key], dtype=float))[: len(r)]
+            assert len(o) == len(r), (case, key, len(o), len(r))
+            ok = np.isfinite(r)
+            assert np.array_equal(np.isfinite(o), ok), (case, key)
+            # improvement and reduce_ratio of the last iterations are differences at the rounding floor of sum(cost)
+            tol = 1e-9 if key in ("tr_lambda", "tr_dlambda", "tr_alpha", "tr_cost") else 1e-5
+            assert np.all(np.abs(o[ok] - r[ok]) <= tol * np.maximum(np.abs(r[ok]), 1e-12) + (1e-9 if tol > 1e-8 else 0.0)), (case, key)
+    elif case.startswith("kl_ilqgkl_"):
+        out = impl.ilqgkl(g)                                        # the whole KL-constrained solve (iLQGkl.jl:25-178)
+        if "status" in ref:
+            assert int(out["status"]) == int(ref["status"]) and int(out["iter"]) == int(ref["iter"])
+        for key in ("xnew", "unew", "K", "S", "Si", "Vx", "Vxx"):
+            _close(out[key], ref[key], (case, key), 1e-7)
+        assert abs(np.sum(out["cost"]) - np.sum(ref["cost"])) <= 1e-8 * abs(np.sum(ref["cost"]))
+        if "eta" in ref:
+            _close(np.asarray(out["eta"])[:3], np.asarray(ref["eta"])[:3], (case, "η bracket"), 1e-7)
+        elif "eta_trace" in ref:                                    # Julia: the η of every iteration; the last one is the solve's
+            assert abs(np.asarray(out["eta"])[1] - np.ravel(ref["eta_trace"])[-1]) <= 1e-7 * abs(np.ravel(ref["eta_trace"])[-1])
     elif case.startswith("ilqg_"):
         kind = "lq" if case == "ilqg_lq_n10m2" else "pendcart"
         out = impl.ilqg(kind, g)
@@ -214,6 +308,12 @@ def compare(case, impl, ref):
             for key in ("Quui", "Quu", "sigmanew", "kldiv"):
                 if key in ref:
                     _close(out[key], ref[key], (case, key))
+            if "eta_kl_steps" in ref:                               # calc_η (klutils.jl:110-133) on the implementation's own mean divergence
+                dbar = float(np.mean(out["kldiv"]))
+                for j, st in enumerate(np.ravel(ref["eta_kl_steps"])):
+                    e, sat = impl.calc_eta(np.ravel(g["etab"]).copy(), dbar, float(st))
+                    assert bool(sat) == bool(np.ravel(ref["eta_satisfied"])[j]), (case, "calc_η satisfied", j)
+                    _close(np.asarray(e), np.asarray(ref["eta_out"])[:, j], (case, "calc_η bracket", j), 1e-9)
     else:
         raise AssertionError("no comparison for " + case)
 
