@@ -562,3 +562,9 @@ def iLQG_mpc(problem, x0, u0, steps, *, zero_tail=False, lims=None, α=DEFAULT_A
     _lib.check(_lib.lib().ddp_ilqg_mpc_f64(h.raw, _C.byref(dp.struct), _C.byref(o), steps, int(bool(zero_tail)), _lib.ptr(x0), _lib.ptr(u0),
                                            _lib.ptr(L), *map(_lib.ptr, (xcl, ucl, scl, x, u)), _C.byref(git)))
     return xcl, ucl, scl, x, u, git.value
+
+
+def runtime_info():
+    """which HIP runtime the process ended up with and why (``_lib._share_torch_hip``), the library version, the devices it sees"""
+    L = _lib.lib()
+    return dict(version=L.ddp_version().decode(), devices=int(L.ddp_device_count()), hip_runtime=_lib.hip_runtime_note)

@@ -72,6 +72,7 @@ class ILQGKLOpts(C.Structure):
 ILQGKL_NSTATS = 12
 
 _lib = None
+hip_runtime_note = "library not loaded yet"
 
 
 class DDPError(RuntimeError):
@@ -82,20 +83,53 @@ def _share_torch_hip():
     """ONE HIP runtime per process: a PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64 (torch/lib), libddp_amd.so is
     linked against the system ROCm.  Whoever loads first decides which copy the other binds to; with the system copy first, a later
     `import torch` finds "No HIP GPUs".  If torch is installed but not imported yet, its bundled runtime is loaded (globally) before the
-    library, which is what happens anyway when torch is imported first (bench.py, the tests).  DDP_AMD_SHARE_TORCH_HIP=0 switches this off."""
+    library, which is what happens anyway when torch is imported first (bench.py, the tests).  DDP_AMD_SHARE_TORCH_HIP=0 switches this off.
+    The preload only happens when the bundled runtime has the SAME major version as the ROCm the library was linked against (the soname
+    of its DT_NEEDED libamdhip64.so.N): a torch wheel built for another ROCm major is left alone (the library then runs on the system
+    runtime and a later `import torch` may not see the GPU — that combination needs torch imported first).  What was done is recorded in
+    `hip_runtime_note` (shown by `ddp_amd.runtime_info()`)."""
+    global hip_runtime_note
     import sys
-    if "torch" in sys.modules or os.environ.get("DDP_AMD_SHARE_TORCH_HIP", "1") == "0":
+    if "torch" in sys.modules:
+        hip_runtime_note = "torch was imported first: its HIP runtime is the process's"
+        return
+    if os.environ.get("DDP_AMD_SHARE_TORCH_HIP", "1") == "0":
+        hip_runtime_note = "DDP_AMD_SHARE_TORCH_HIP=0: system ROCm runtime"
         return
     try:
+        import glob
         import importlib.util
+        import re
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
+            hip_runtime_note = "torch not installed: system ROCm runtime"
             return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except (OSError, ImportError, ValueError):
-        pass
+        tlib = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        cand = os.path.join(tlib, "libamdhip64.so")
+        if not os.path.exists(cand):
+            hip_runtime_note = "torch has no bundled libamdhip64: system ROCm runtime"
+            return
+        # major version of the runtime the library wants (its DT_NEEDED entry) and of the one torch bundles (versioned file next to it)
+        want = None
+        with open(LIB_PATH, "rb") as f:
+            m_ = re.search(rb"libamdhip64\.so\.(\d+)", f.read())
+            want = int(m_.group(1)) if m_ else None
+        have = None
+        for fn in glob.glob(cand + ".*"):
+            m2 = re.search(r"libamdhip64\.so\.(\d+)", os.path.basename(fn))
+            if m2:
+                have = int(m2.group(1))
+        real = os.path.basename(os.path.realpath(cand))
+        m3 = re.search(r"libamdhip64\.so\.(\d+)", real)
+        if m3:
+            have = int(m3.group(1))
+        if want is not None and have is not None and want != have:
+            hip_runtime_note = "torch bundles libamdhip64.so.%d, libddp_amd.so wants .so.%d: NOT preloaded (import torch first if both are needed)" % (have, want)
+            return
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        hip_runtime_note = "preloaded torch's bundled HIP runtime (%s) so that a later `import torch` shares it" % real
+    except (OSError, ImportError, ValueError) as exc:
+        hip_runtime_note = "preload of torch's HIP runtime failed (%s): system ROCm runtime" % exc
 
 
 def lib():

@@ -126,7 +126,7 @@ int ddp_free(ddp_handle h, void *dptr)
 }
 // ---- page-locked host memory for results (ddp_amd.h).  Process-wide cache of freed blocks, keyed by their (2 MB-rounded) size: a host
 // that calls the same entry point again and again gets the same blocks back, so neither the pinning nor the first touch of fresh pages
-// is paid per call.  DDP_PINNED_CACHE_MB bounds the bytes kept in the cache (default 8192).
+// is paid per call.  DDP_PINNED_CACHE_MB bounds the bytes kept in the cache (default 2048, read once).
 namespace {
 struct PinnedPool {
     std::mutex mu;
@@ -135,8 +135,16 @@ struct PinnedPool {
     size_t cached = 0;
     size_t cap()
     {
-        const char *e = getenv("DDP_PINNED_CACHE_MB");
-        return (size_t)(e ? atol(e) : 8192) << 20;
+        // bytes of FREED blocks kept for reuse: DDP_PINNED_CACHE_MB, clamped to [0, 64 GB] (a negative or garbled value used to shift into
+        // an enormous cap); default 2 048 — enough for the result arrays of a C2 pass (1.2 GB).  Blocks in use are the caller's arrays and
+        // are not bounded here: every result of >= 1 MB that the ctypes / Julia hosts return lives in page-locked memory until collected.
+        static const size_t cap_bytes = [] {
+            const char *e = getenv("DDP_PINNED_CACHE_MB");
+            long mb = 2048;
+            if (e && *e) { char *end = nullptr; const long v = strtol(e, &end, 10); if (end != e && v >= 0) mb = v < 65536 ? v : 65536; }
+            return (size_t)mb << 20;
+        }();
+        return cap_bytes;
     }
 };
 PinnedPool &pinned_pool() { static PinnedPool p; return p; }

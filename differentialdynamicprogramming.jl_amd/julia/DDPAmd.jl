@@ -461,6 +461,61 @@ Rebinds the three linear-system `back_pass` methods of the loaded reference pack
 `DDPAmd.back_pass`, so that the reference's own `iLQG(f,costfun,df,x0,u0; ...)` — arbitrary Julia closures, its own line search,
 trace and printing — runs STEP 2 (iLQG.jl:235-251) on the GPU.  Returns policies of the reference's own `GaussianPolicy` type.
 """
+    iLQG_queue(problem, x0[n,P], u0[m,N,P]; slots=0, lims=[], α, tol_fun, ...) -> x, u, traj_new, Vx, Vxx, cost, trace
+
+`P` independent solves of `iLQG` through `slots` resident trajectories (`ddp_ilqg_queue_f64`): a slot whose solve has ended is flushed
+and armed with the next problem ON THE DEVICE, in the global iteration in which it ended, instead of idling until the slowest
+trajectory of a lock-step batch has ended (32 768 pendulum solves: 0.70 s against 1.43 s as eight batches of 4 096).  Every solve is the
+solve `iLQG` performs at batch size `slots`.  `trace[:stats]` is `stats[8,P]`.
+"""
+function iLQG_queue(problem::RegisteredProblem, x0::AbstractMatrix, u0::AbstractArray{<:Real,3}; slots::Integer=0, lims=[], α=DEFAULT_ALPHA,
+                    tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0, λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1,
+                    reduce_ratio_min=0, diff_fun=-, handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
+    m, N, P_ = size(u0); n = size(x0, 1)
+    size(x0, 2) == P_ || error("iLQG_queue: x0[n,P], u0[m,N,P]")
+    P = cproblem(problem, N, P_; diff=diff_fun)
+    CL = cost_len(problem, N)
+    o = _opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
+    x = result_array(n, N, P_); u = result_array(m, N, P_); K = result_array(m, n, N, P_); k = result_array(m, N, P_)
+    Quu = result_array(m, m, N, P_); Vx = result_array(n, N, P_); Vxx = result_array(n, n, N, P_); costo = result_array(CL, P_)
+    stats = zeros(8, P_); git = Ref{Cint}(0)
+    x0h = _f64(x0); u0h = _f64(u0); limsp = _lims(lims)
+    GC.@preserve problem x0h u0h limsp x u K k Quu Vx Vxx costo stats begin
+        check(@ccall libddp.ddp_ilqg_queue_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGOpts}, slots::Cint,
+            x0h::Ptr{Float64}, u0h::Ptr{Float64}, _ptr_or_null(limsp)::Ptr{Float64},
+            x::Ptr{Float64}, u::Ptr{Float64}, K::Ptr{Float64}, k::Ptr{Float64}, Quu::Ptr{Float64}, Vx::Ptr{Float64}, Vxx::Ptr{Float64},
+            costo::Ptr{Float64}, stats::Ptr{Float64}, git::Ptr{Cint})::Cint)
+    end
+    trace = Dict{Symbol,Any}(:stats => stats, :status => Int.(stats[1, :]), :iter => Int.(stats[2, :]), :global_iters => Int(git[]))
+    return x, u, policy(N, n, m, K, k, zeros(m, m, N, P_), Quu), Vx, Vxx, costo, trace
+end
+
+"""
+    iLQG_mpc(problem, x0[n,B], u0[m,N,B], steps; zero_tail=false, lims=[], ...) -> xcl[n,steps+1,B], ucl[m,steps,B], stats[8,steps,B], xplan, uplan
+
+Closed loop on the device (`ddp_ilqg_mpc_f64`): every trajectory is solved `steps` times; after each solve its first control is applied
+(the model is the plant: the next initial state is `x[:,2]` of the solution), the control sequence is shifted by one step and the problem
+is solved again without returning to the host — the receding-horizon use of the warm-start hook of the reference (iLQG.jl:193-197).
+"""
+function iLQG_mpc(problem::RegisteredProblem, x0::AbstractMatrix, u0::AbstractArray{<:Real,3}, steps::Integer; zero_tail::Bool=false, lims=[],
+                  α=DEFAULT_ALPHA, tol_fun=1e-7, tol_grad=1e-4, max_iter=500, λ=1.0, dλ=1.0, λfactor=1.6, λmax=1e10, λmin=1e-6, regType=1,
+                  reduce_ratio_min=0, diff_fun=-, handle::Handle=default_handle())
+    m, N, B = size(u0); n = size(x0, 1)
+    size(x0, 2) == B || error("iLQG_mpc: x0[n,B], u0[m,N,B]")
+    P = cproblem(problem, N, B; diff=diff_fun)
+    o = _opts(α, tol_fun, tol_grad, max_iter, λ, dλ, λfactor, λmax, λmin, regType, reduce_ratio_min)
+    xcl = zeros(n, steps + 1, B); ucl = zeros(m, steps, B); scl = zeros(8, steps, B)
+    x = result_array(n, N, B); u = result_array(m, N, B); git = Ref{Cint}(0)
+    x0h = _f64(x0); u0h = _f64(u0); limsp = _lims(lims)
+    GC.@preserve problem x0h u0h limsp xcl ucl scl x u begin
+        check(@ccall libddp.ddp_ilqg_mpc_f64(handle.ptr::Ptr{Cvoid}, Ref(P)::Ptr{CProblem}, Ref(o)::Ptr{ILQGOpts}, steps::Cint,
+            (zero_tail ? 1 : 0)::Cint, x0h::Ptr{Float64}, u0h::Ptr{Float64}, _ptr_or_null(limsp)::Ptr{Float64},
+            xcl::Ptr{Float64}, ucl::Ptr{Float64}, scl::Ptr{Float64}, x::Ptr{Float64}, u::Ptr{Float64}, git::Ptr{Cint})::Cint)
+    end
+    return xcl, ucl, scl, x, u
+end
+
+"""
 function install!(ref::Module=getfield(Main, :DifferentialDynamicProgramming))
     pol(N, n, m, K, k, Σ, Σi) = ref.GaussianPolicy(N, n, m, K, k, Σ, Σi)
     bp(args...) = back_pass(args...; policy=pol)

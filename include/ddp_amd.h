@@ -55,7 +55,8 @@ int  ddp_memset(ddp_handle h, void *dst, int value, size_t bytes);             /
 /* Page-locked host memory for the RESULT arrays of the host-pointer entry points.  The link moves 56 GB/s into pinned or already-touched
  * pages; what a host-pointer call used to pay for is the first touch of freshly allocated pageable result arrays (1.2 GB per C2 pass:
  * 8-13 k passes/s against a link bound of ~46 k).  Blocks freed with ddp_host_free are kept in a process-wide cache (same size -> same
- * block on the next call: no pinning, no page faults), bounded by DDP_PINNED_CACHE_MB (default 8192); ddp_host_trim empties the cache.
+ * block on the next call: no pinning, no page faults), bounded by DDP_PINNED_CACHE_MB (default 2048, clamped to [0, 65536]); ddp_host_trim
+ * empties the cache.  Blocks that are in use (the arrays the hosts returned) are page-locked for as long as the caller keeps them.
  * Any host pointer still works everywhere — this is an allocator the hosts (ctypes mirror, DDPAmd.jl) use for what they return.       */
 int  ddp_host_alloc(size_t bytes, void **hptr);
 int  ddp_host_free(void *hptr);
