@@ -136,21 +136,37 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
     if (tid < SH_GMAX) cursor[tid] = 0;
     if (tid == 0) nfb = 0;
     __syncthreads();
-    // pass 1: distinct values and their populations; the slot of a trajectory is parked in perm[]
-    for (int b = tid; b < B; b += blockDim.x) {
-        int slot = -1;
-        if (!a.active || a.active[b] != 0) {
-            const unsigned long long key = (unsigned long long)__double_as_longlong(a.lambda[b]);
-            slot = -2;
-            if (key != EMPTY) {
-                unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 58);
-                for (int t = 0; t < SH_TAB; ++t, h = (h + 1) % SH_TAB) {
-                    const unsigned long long old = atomicCAS(&keys[h], EMPTY, key);
-                    if (old == EMPTY || old == key) { atomicAdd(&cnt[h], 1); slot = (int)h; break; }
-                }
-            }
+    // pass 1: distinct values and their populations; the slot of a trajectory is parked in perm[].  A wave whose active lanes all carry
+    // the same λ (the usual case: one λ for the batch, or a few values in runs) inserts ONCE and adds its population once — per-lane
+    // atomics on one LDS word serialise (18 us at B = 1 024, 158 us at B = 32 768 before this).
+    auto insert = [&](unsigned long long key, int n_) -> int {
+        unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 58);
+        for (int t = 0; t < SH_TAB; ++t, h = (h + 1) % SH_TAB) {
+            const unsigned long long old = atomicCAS(&keys[h], EMPTY, key);
+            if (old == EMPTY || old == key) { atomicAdd(&cnt[h], n_); return (int)h; }
         }
-        a.perm[b] = slot;                            // -1 inactive, -2 no slot, else the slot
+        return -2;
+    };
+    for (int b0 = 0; b0 < B; b0 += blockDim.x) {
+        const int b = b0 + tid;
+        const bool inb = b < B;
+        const bool on = inb && (!a.active || a.active[b] != 0);
+        const unsigned long long key = on ? (unsigned long long)__double_as_longlong(a.lambda[b]) : EMPTY;
+        const unsigned long long live = __ballot(on && key != EMPTY);
+        int slot = on ? -2 : -1;
+        // peel the wave value by value: the lanes that share the leader's λ insert once, with their head count
+        unsigned long long rest = live;
+        while (rest) {
+            const int lead = __ffsll((long long)rest) - 1;
+            const unsigned long long k0 = __shfl(key, lead);
+            const unsigned long long same = __ballot(on && key == k0) & rest;
+            int s0 = 0;
+            if ((int)(threadIdx.x & 63) == lead) s0 = insert(k0, __popcll(same));
+            s0 = __shfl(s0, lead);
+            if ((same >> (threadIdx.x & 63)) & 1ull) slot = s0;
+            rest &= ~same;
+        }
+        if (inb) a.perm[b] = slot;                   // -1 inactive, -2 no slot, else the slot
     }
     __syncthreads();
     if (tid == 0) {   // the SH_GMAX most populated values with at least two trajectories become groups
@@ -186,13 +202,27 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
     // written, before their own thread has picked them up — the sorted area may overlap unread slots, so park them in fb_active first)
     for (int b = tid; b < B; b += blockDim.x) a.fb_active[b] = a.perm[b];
     __syncthreads();
-    for (int b = tid; b < B; b += blockDim.x) {
-        const int slot = a.fb_active[b];
+    for (int b0 = 0; b0 < B; b0 += blockDim.x) {
+        const int b = b0 + tid;
+        const bool inb = b < B;
+        const int slot = inb ? a.fb_active[b] : -1;
         const int g = slot >= 0 ? gof[slot] : -1;
-        int fb = 0;
-        if (g >= 0) a.perm[gst[g] + atomicAdd(&cursor[g], 1)] = b;
-        else if (slot != -1) { fb = 1; atomicAdd(&nfb, 1); }
-        a.fb_active[b] = fb;
+        const bool fbk = inb && g < 0 && slot != -1;
+        // positions: one atomic per wave and group when the wave is uniform, per lane otherwise
+        unsigned long long rest = __ballot(g >= 0);
+        while (rest) {                                          // one atomic per wave and group present in it
+            const int lead = __ffsll((long long)rest) - 1;
+            const int g0 = __shfl(g, lead);
+            const unsigned long long same = __ballot(g == g0) & rest;
+            int base = 0;
+            if ((int)(threadIdx.x & 63) == lead) base = atomicAdd(&cursor[g0], __popcll(same));
+            base = __shfl(base, lead);
+            if ((same >> (threadIdx.x & 63)) & 1ull) a.perm[gst[g0] + base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull))] = b;
+            rest &= ~same;
+        }
+        const unsigned long long fbm = __ballot(fbk);
+        if (fbm && (int)(threadIdx.x & 63) == __ffsll((long long)fbm) - 1) atomicAdd(&nfb, __popcll(fbm));
+        if (inb) a.fb_active[b] = fbk ? 1 : 0;
     }
     __syncthreads();
     if (tid == 0) a.ctl->nfb = nfb;
