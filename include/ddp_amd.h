@@ -151,9 +151,11 @@ typedef struct {
     double goal[4];
     /* 1: the caller declares Q and R DIAGONAL (true for the reference's demos: Q = h·I, R = 0.1h·I, Q = diag(10,1,2,1)); the rollout
      * kernels of the n = 10 / m = 2 and pendcart shapes then evaluate the cost themselves from the values they hold instead of a
-     * second kernel re-reading xnew, unew (only the diagonals are read).  0: general Q, R.  The declaration is NOT verified (Q, R are
-     * device memory in the _dev entry points): a wrong 1 gives the cost of diag(Q), diag(R).  Any other value is refused, so a struct that
-     * was not zero-initialised — or a caller built against the 0.1.0 layout, which ended at goal[] — fails loudly.               */
+     * second kernel re-reading xnew, unew (only the diagonals are read).  0: general Q, R.  The declaration IS verified: the host-pointer
+     * entry points test the host copies; the _dev entry points look at Q, R once per (Q, R) address pair and handle (one small
+     * device-to-host copy, the verdict is cached — a caller that rewrites Q or R in place must keep the flag honest; ddp_reload_env
+     * does not clear the cache, a new handle does).  A full Q or R with cost_diag = 1 is refused (< 0).  Any value but 0 / 1 is refused,
+     * so a struct that was not zero-initialised — or a caller built against the 0.1.0 layout, which ended at goal[] — fails loudly.   */
     int cost_diag;
     /* diff_fun (src/forward_pass.jl:19, iLQG.jl:160: `K*diff_fun(x̂, x)`; default `-`).  A closure cannot cross the C ABI; what stands in
      * is subtraction with the coordinates named in this bit mask (bit j = state j, n <= 32) wrapped to [-π, π]:
