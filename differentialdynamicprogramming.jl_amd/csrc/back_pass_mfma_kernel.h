@@ -66,6 +66,10 @@ constexpr int oVs = 0, oFs = oVs + n * LDV, oWT = oFs + PP * LDK, ovs = oWT + n 
 #define MFP_PRINT
 #endif
 
+#define MF_SB __builtin_amdgcn_sched_barrier(0)
+#ifndef C4_EXP
+#define C4_EXP 0          // timing experiments (profiles/ab_c4.sh): bit 0 no operand fetch in the phase-2 products, bit 1 no global traffic there
+#endif
 __device__ __forceinline__ d4 mf(double x, double y, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); }
 
 // NTL MFMA chains that share one operand (A if SHA, else B): 1 + NTL LDS reads per k-step instead of 2·NTL — with all four
@@ -82,18 +86,21 @@ __device__ __forceinline__ void mfma_chain_shared(const double *sp, const double
     }
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
-        if (kk + PF < NK) {
-            const int j = (kk + PF) % (PF + 1);
-            r[j][0] = sp[SS * (kk + PF)];
+        // each product is followed by one piece of the fetch PF k-steps ahead: it issues in the product's shadow
+        const int q = kk % (PF + 1), j = (kk + PF) % (PF + 1);
+        const bool pf = kk + PF < NK;
 #pragma unroll
-            for (int u = 0; u < NTL; ++u) r[j][1 + u] = op[u][SO * (kk + PF)];
+        for (int u = 0; u < NTL; ++u) {
+            MF_SB;
+            c[u] = SHA ? mf(r[q][0], r[q][1 + u], c[u]) : mf(r[q][1 + u], r[q][0], c[u]);
+            MF_SB;
+            if (pf && !(C4_EXP & 4)) {
+                if (u == 0) r[j][0] = sp[SS * (kk + PF)];
+                r[j][1 + u] = op[u][SO * (kk + PF)];
+            }
         }
-        const int q = kk % (PF + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) c[u] = SHA ? mf(r[q][0], r[q][1 + u], c[u]) : mf(r[q][1 + u], r[q][0], c[u]);
-        __builtin_amdgcn_sched_barrier(0);
     }
+    MF_SB;
 }
 
 template <bool LIMS, bool CTV>
@@ -220,8 +227,11 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             d4 accU = d4{0.0, 0.0, 0.0, 0.0}, acc0 = d4{0.0, 0.0, 0.0, 0.0};
             const double *ap = Vs + 16 * wv + l15 + LDV * l4;          // A[i][k] = Vxx[16w+i, k]
             const double *bp = Fs + l4 + LDK * l15;                   // B[k][j] = F[k, 16c+j]
-            double a0 = ap[0], bU0 = bp[LDK * 64], b00 = bp[0];
-            // Global traffic rides in the MFMA shadow, at most one instruction per k-step: the address unit takes ~16 cycles per
+            constexpr int PF1 = 2;                                    // operands fetched two k-steps ahead
+            double av[PF1 + 1], bUv[PF1 + 1], b0v[PF1 + 1];
+#pragma unroll
+            for (int j = 0; j < PF1; ++j) { av[j] = ap[LDV * 4 * j]; bUv[j] = bp[LDK * 64 + 4 * j]; b0v[j] = bp[4 * j]; }
+            // Global traffic rides in the MFMA shadow, at most one instruction per product: the address unit takes ~16 cycles per
             // wave instruction and all four waves share it (a burst at the top of the step costs ~2k cycles).  Here: columns
             // 0..31 of Vxx_{i+1} (:72 of step i+1; the rest goes out in phase 2), wave 0's share of the next Jacobian.
             const double *vout = Vs + lane + LDV * wv;
@@ -229,21 +239,26 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             double vprev = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                if (kk & 1) gout[NT * (kk >> 1)] = vprev;
+                const int c = kk % (PF1 + 1), j = (kk + PF1) % (PF1 + 1);
+                const bool pf = kk + PF1 < 16;
+                MF_SB;
+                accU = mf(av[c], bUv[c], accU);
+                MF_SB;
+                if (pf && !(C4_EXP & 8)) { av[j] = ap[LDV * 4 * (kk + PF1)]; bUv[j] = bp[LDK * 64 + 4 * (kk + PF1)]; }
+                if (C4_EXP & 16) { }
+                else if (kk & 1) gout[NT * (kk >> 1)] = vprev;
                 else vprev = vout[LDV * 4 * (kk >> 1)];
-                if (wv == 0) {
+                MF_SB;
+                acc0 = mf(av[c], b0v[c], acc0);
+                MF_SB;
+                if (pf && !(C4_EXP & 8)) b0v[j] = bp[4 * (kk + PF1)];
+                if (wv == 0 && !(C4_EXP & 16)) {
                     if (kk == 0) gxc = cx[(size_t)n * i + lane];
                     else if (kk < 3) { if (l15 == m) gu[kk - 1] = cu[(size_t)m * i + l4 + 4 * (kk - 1)]; }
                     else if (kk < 3 + RF) { if (ldF) pfF[kk - 3] = load_F1(i - 1, kk - 3); }
                 }
-                double a1 = 0.0, bU1 = 0.0, b01 = 0.0;
-                if (kk < 15) { a1 = ap[LDV * 4 * (kk + 1)]; bU1 = bp[LDK * 64 + 4 * (kk + 1)]; b01 = bp[4 * (kk + 1)]; }
-                __builtin_amdgcn_sched_barrier(0);                    // fetches of step kk+1 stay in front of the products of step kk
-                accU = mf(a0, bU0, accU);
-                acc0 = mf(a0, b00, acc0);
-                __builtin_amdgcn_sched_barrier(0);
-                a0 = a1; bU0 = bU1; b00 = b01;
             }
+            MF_SB;
             MFP(8);
             {                                                         // D[row = l4 + 4r][col = l15] -> WT[col + LD*row]
                 double *wp = WT + l15 + LD * (16 * wv + l4);
@@ -261,14 +276,14 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             for (int ti = 0; ti < 5; ++ti) fa[ti] = fp[LDK * 16 * ti];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (r < 3) {
 #pragma unroll
-                    for (int ti = 0; ti < 5; ++ti) fb[ti] = fp[LDK * 16 * ti + 4 * (r + 1)];
+                for (int ti = 0; ti < 5; ++ti) {
+                    MF_SB;
+                    pg[ti] = mf(fa[ti], bu[r], pg[ti]);
+                    MF_SB;
+                    if (r < 3 && !(C4_EXP & 8)) fb[ti] = fp[LDK * 16 * ti + 4 * (r + 1)];
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ti = 0; ti < 5; ++ti) pg[ti] = mf(fa[ti], bu[r], pg[ti]);
-                __builtin_amdgcn_sched_barrier(0);
+                MF_SB;
 #pragma unroll
                 for (int ti = 0; ti < 5; ++ti) fa[ti] = fb[ti];
             }
@@ -468,21 +483,31 @@ __global__ __launch_bounds__(NT) void back_pass_mfma_kernel(BPMArgs a)
             double vprev = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                if (kk >= 1 && kk <= 11 && (kk < 11 || wv < 3)) gout[n * 3 * (kk - 1)] = vprev;
-                if (kk < 11 && (kk < 10 || wv < 3)) vprev = vout[LDV * 3 * kk];
-                if (kk >= 7 && ldF) pfF[kk - 7] = load_F1(i - 1, kk - 7);
-                if (kk + PF < 16) {
-                    const int j = (kk + PF) % (PF + 1);
-                    bq[j] = bp[4 * (kk + PF)];
-#pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) aq_[j][rb] = ap[16 * rb + LDV * 4 * (kk + PF)];
-                }
-                const int c = kk % (PF + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) acc[rb] = mf(aq_[c][rb], bq[c], acc[rb]);
-                __builtin_amdgcn_sched_barrier(0);
+                // one MFMA, then the pieces of traffic that issue in its 64-cycle shadow: the wave issues in order, so fetches and
+                // stores bunched in front of the four products of a k-step leave the matrix pipe idle while they issue
+                const int c = kk % (PF + 1), j = (kk + PF) % (PF + 1);
+                const bool pf = kk + PF < 16;
+                MF_SB;
+                acc[0] = mf(aq_[c][0], bq[c], acc[0]);
+                MF_SB;
+                if (pf && !(C4_EXP & 1)) { bq[j] = bp[4 * (kk + PF)]; aq_[j][0] = ap[LDV * 4 * (kk + PF)]; }
+                MF_SB;
+                acc[1] = mf(aq_[c][1], bq[c], acc[1]);
+                MF_SB;
+                if (pf && !(C4_EXP & 1)) aq_[j][1] = ap[16 + LDV * 4 * (kk + PF)];
+                if (!(C4_EXP & 2) && kk >= 1 && kk <= 11 && (kk < 11 || wv < 3)) gout[n * 3 * (kk - 1)] = vprev;
+                MF_SB;
+                acc[2] = mf(aq_[c][2], bq[c], acc[2]);
+                MF_SB;
+                if (pf && !(C4_EXP & 1)) aq_[j][2] = ap[32 + LDV * 4 * (kk + PF)];
+                if (!(C4_EXP & 2) && kk < 11 && (kk < 10 || wv < 3)) vprev = vout[LDV * 3 * kk];
+                MF_SB;
+                acc[3] = mf(aq_[c][3], bq[c], acc[3]);
+                MF_SB;
+                if (pf && !(C4_EXP & 1)) aq_[j][3] = ap[48 + LDV * 4 * (kk + PF)];
+                if (!(C4_EXP & 2) && kk >= 7 && ldF) pfF[kk - 7] = load_F1(i - 1, kk - 7);
             }
+            MF_SB;
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
                 double *wp = WT + 16 * wv + l15 + LD * (16 * rb + l4);
