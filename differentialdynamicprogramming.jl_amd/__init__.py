@@ -27,7 +27,7 @@ import numpy as np
 from . import _lib
 from ._lib import DDPError, Handle, default_handle  # noqa: F401
 
-__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing", "mpc_shift", "demo_linear", "demo_pendcart",
+__all__ = ["GaussianPolicy", "LQProblem", "PendcartProblem", "back_pass", "boxQP", "forward_pass", "iLQG", "print_timing", "mpc_shift", "demo_linear", "demo_pendcart", "demoQP",
            "df", "Handle", "DDPError", "DEFAULT_ALPHA", "WrappedDiff"]
 
 DEFAULT_ALPHA = 10.0 ** np.linspace(0, -3, 11)     # iLQG.jl:145
@@ -235,6 +235,18 @@ def boxQP(H, g, lower, upper, x0, *, maxIter=100, minGrad=1e-8, minRelImprove=1e
         nf = int(free.sum())
         return x[:, 0], int(res[0]), Hf[:nf, :nf, 0], free
     return x, res, Hf, fr.astype(bool)
+
+
+def demoQP(*, n=500, rng=None, **kwargs):
+    """``demoQP(;kwargs...)`` (src/boxQP.jl:190-199): ``H = M·M'`` with ``M = randn(n,n)``, ``g = randn(n)``, bounds ±1, a random
+    start; returns ``boxQP``'s tuple and the wall time of the call in seconds."""
+    import time as _time
+    rng = rng if rng is not None else np.random.default_rng()
+    M = rng.standard_normal((n, n))
+    H, g = M @ M.T, rng.standard_normal(n)
+    t0 = _time.perf_counter()
+    out = boxQP(H, g, -np.ones(n), np.ones(n), rng.standard_normal(n), **kwargs)
+    return out + (_time.perf_counter() - t0,)
 
 
 # ------------------------------------------------------------------------------- demos (problem generators + solver settings)

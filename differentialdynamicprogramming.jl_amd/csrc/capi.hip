@@ -431,10 +431,11 @@ int ddp_boxqp_f64_dev(ddp_handle h, int m, int count, const double *H, const dou
 {
     DDP_DEVICE(h);
     DDP_CHECK(h, "boxqp: null handle");
-    DDP_CHECK(m >= 1 && m <= DDP_MAX_M, "boxqp: m=%d out of [1,%d]", m, DDP_MAX_M);
+    DDP_CHECK(m >= 1 && m <= DDP_QP_MAX_M, "boxqp: m=%d out of [1,%d]", m, DDP_QP_MAX_M);
     DDP_CHECK(count >= 1, "boxqp: count=%d", count);
     QPOptsDev o = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};
     if (opts) o = {opts->maxIter, opts->minGrad, opts->minRelImprove, opts->stepDec, opts->minStep, opts->Armijo};
+    if (m > DDP_MAX_M) return ddp_launch_boxqp_big(h, m, count, H, g, lower, upper, x0, o, x, result, Hfree, free_out);   // one work-group per problem
     const dim3 grid((count + DDP_WAVE - 1) / DDP_WAVE), block(DDP_WAVE);
 #define DDP_QP_CASE(M_)                                                                                           \
     case M_:                                                                                                      \

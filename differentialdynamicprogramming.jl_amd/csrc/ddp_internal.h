@@ -150,6 +150,9 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
                             const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);
 
 // LQ n=10/m=2 rollout as a producer/consumer pipeline of one work-group per 4 rollouts (forward_pass_pipe.hip); 1 = not applicable
+struct QPOptsDev;
+int ddp_launch_boxqp_big(ddp_handle h, int m, int count, const double *H, const double *g, const double *lower, const double *upper,
+                         const double *x0, const QPOptsDev &o, double *x, int32_t *result, double *Hfree, uint8_t *free_out);   // boxqp_big.hip
 int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
                             const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
                             const int32_t *active, double *xnew, double *unew, double *cnew, double *csum);

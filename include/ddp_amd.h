@@ -106,11 +106,13 @@ int ddp_back_pass_f64(ddp_handle h, const ddp_bp_desc *d,
 
 /* ---- boxQP — replaces boxQP(H,g,lower,upper,x0) ------------------------------------------------
  * reference: src/boxQP.jl:29-188, called from src/backward_pass.jl:49.
- * `count` independent problems of dimension m (m <= DDP_MAX_M):
+ * `count` independent problems of dimension m <= DDP_QP_MAX_M (m <= DDP_MAX_M, the sizes the backward pass uses: one
+ * lane per problem; larger m — upstream's demoQP runs m = 500, boxQP.jl:190-199 — one work-group per problem):
  * H[m,m,count] g/lower/upper/x0[m,count] -> x[m,count] result int32[count]
- * Hfree[m,m,count] (leading nfree x nfree block = upper Cholesky factor of H[free,free])
+ * Hfree[m,m,count] (leading nfree x nfree block = upper Cholesky factor of H[free,free], zero elsewhere)
  * free uint8[m,count].                                                                             */
 #define DDP_MAX_M 8
+#define DDP_QP_MAX_M 1024
 typedef struct {
     int    maxIter;        /* 100   */
     double minGrad;        /* 1e-8  */
