@@ -336,6 +336,17 @@ function boxQP(H, g, lower, upper, x0::AbstractVecOrMat; maxIter=100, minGrad=1e
 end
 
 """
+    demoQP(; n=500, kwargs...)
+
+src/boxQP.jl:190-199: `H = M*M'` with `M = randn(n,n)`, `g = randn(n)`, bounds ±1, a random start, timed (one work-group per problem
+for m > 8, csrc/boxqp_big.hip).
+"""
+function demoQP(; n=500, kwargs...)
+    g = randn(n); M = randn(n, n); H = M * M'
+    @time boxQP(H, g, -ones(n), ones(n), randn(n); kwargs...)
+end
+
+"""
     forward_pass(traj_new, x0, u, x, α, problem, lims) -> xnew, unew, cnew
 
 `problem` (LQProblem / PendcartProblem) replaces the closures `f`, `costfun` of src/forward_pass.jl:9; `diff` is `-` or a `WrappedDiff`.
