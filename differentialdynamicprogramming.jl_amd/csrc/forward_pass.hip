@@ -315,7 +315,7 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
     }
     if (!force_group && p->diff_wrap == 0) {
         const int rp = ddp_launch_forward_pipe(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
-        if (rp <= 0) { h->last_kernel[1] = "forward_pipe_kernel"; return rp; }
+        if (rp <= 0) return rp;                             // (the launcher names the kernel)
         const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rc <= 0) { h->last_kernel[1] = "forward_dpp_kernel"; return rc; }
     }

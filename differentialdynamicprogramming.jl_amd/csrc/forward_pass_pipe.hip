@@ -126,6 +126,82 @@ __device__ __forceinline__ void spread_pair(double v, double &q0, double &q1)
     q1 = __hiloint2double((int)f.y, (int)e.y);
 }
 
+// A NaN control somewhere (u[isnan.(u)] .= 0 inside f, demo_linear.jl:43): the rollouts concerned are recomputed step by step with the
+// reference's statements, one 16-lane row per rollout of the work-group (called by one wave)
+template <bool FUSE, bool TV>
+__device__ __forceinline__ void pipe_redo(const FPipeArgs &a, const int *nanflag, const int lane)
+{
+    constexpr int n = PN, m = PM;
+    constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    const int N = a.N, B = a.B;
+    const long total = (long)B * a.nalpha;
+    auto roll = [&](int r, int &b, int &ai, bool &act) {
+        long lin = (long)blockIdx.x * R4 + r;
+        const bool valid = lin < total;
+        if (!valid) lin = total - 1;
+        b = (int)(lin / a.nalpha); ai = (int)(lin % a.nalpha);
+        act = valid && !(a.active && a.active[b] == 0);
+    };
+    const int row = lane / 16, j = lane % 16;
+    const bool redo = nanflag[row] != 0;
+    if (!__any(redo)) return;
+    const bool inx = j < n;
+    const int jx = inx ? j : 0;
+    int b, ai; bool act; roll(row, b, ai, act);
+    const bool wr = act && redo;
+    const double alpha = a.alpha[ai];
+    const double z = inx ? 1.0 : 0.0;
+    const double *Ab = a.A + (a.dyn_batched ? nn * (TV ? N : 1) * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * (TV ? N : 1) * b : 0);
+    const double *ug = a.u + (size_t)m * N * b, *xg = a.x + (size_t)n * N * b, *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b;
+    double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai), *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
+    double *co = FUSE ? a.cnew + (size_t)N * ((size_t)b + (size_t)B * ai) : nullptr;
+    double Arow[n], Brow[m];
+#pragma unroll
+    for (int l = 0; l < n; ++l) Arow[l] = z * Ab[jx + n * l];
+#pragma unroll
+    for (int q = 0; q < m; ++q) Brow[q] = z * Bb[jx + n * q];
+    double one = 1.0;
+    asm volatile("" : "+v"(one));
+    double cw = 0.0;
+    if (FUSE) cw = inx ? 0.5 * a.Q[jx + n * jx] : (j < n + m ? 0.5 * a.R[(j - n) + m * (j - n)] : 0.0);
+    double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0, cacc = 0.0;
+    for (int i = 0; i < N; ++i) {
+        if (TV) {
+#pragma unroll
+            for (int l = 0; l < n; ++l) Arow[l] = z * Ab[nn * i + jx + n * l];
+#pragma unroll
+            for (int q = 0; q < m; ++q) Brow[q] = z * Bb[nm * i + jx + n * q];
+        }
+        const d2 Kc = *(const d2 *)(Kg + nm * i + m * jx), uc = *(const d2 *)(ug + (size_t)m * i), kc = *(const d2 *)(kg + (size_t)m * i);
+        const double dx = xh - xg[(size_t)n * i + jx];
+        double pr0 = Kc.x * dx, pr1 = Kc.y * dx;
+        dpp_fence(pr0, pr1);
+        double s0 = fma(kc.x, alpha, uc.x), s1 = 0.0, t0 = fma(kc.y, alpha, uc.y), t1 = 0.0;
+        RowSum<n>::run(s0, s1, pr0, one);
+        RowSum<n>::run(t0, t1, pr1, one);
+        double uu0 = s0 + s1, uu1 = t0 + t1;
+        if (uu0 != uu0) uu0 = 0.0;
+        if (uu1 != uu1) uu1 = 0.0;
+        const double v = inx ? xh : (j == n ? uu0 : (j == n + 1 ? uu1 : 0.0));
+        if (wr && inx) xo[(size_t)n * i + j] = v;
+        if (wr && j >= n && j < n + m) uo[(size_t)m * i + (j - n)] = v;
+        if (FUSE) {
+            double pc = (cw * v) * v, c0 = 0.0, c1 = 0.0;
+            dpp_fence(pc);
+            RowSum<n + m>::run(c0, c1, pc, one);
+            const double cs = c0 + c1;
+            if (wr && j == 0) co[i] = cs;
+            cacc += cs;
+        }
+        double x0a = 0.0, x1a = 0.0;
+        dpp_fence(xh);
+        RowDot<n>::run(x0a, x1a, xh, Arow);
+        xh = fma(Brow[1], uu1, fma(Brow[0], uu0, x0a + x1a));
+        dpp_fence(xh);
+    }
+    if (FUSE && wr && j == 0) a.csum[(size_t)b + (size_t)B * ai] = cacc;
+}
+
 // LDS map (bytes).  Raw image of a chunk, per rollout, in 16-byte slots: K (10 per step) | x (5 per step) | ū (1) | k (1) and, for
 // time-varying dynamics (TV), A_i (50 per step) | B_i (10 per step): 1 232 bytes per step and rollout instead of 272
 template <int G, bool TV = false>
@@ -411,68 +487,372 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
         for (int t = 0; t < G; ++t) s += *(const double *)(smem + L::CF_OFF + (r * G + t) * 8);
         if (act && nanflag[r] == 0) a.csum[(size_t)b + (size_t)B * ai] = s;
     }
-    // ---- a NaN control somewhere: the rollouts concerned are recomputed step by step with the reference's statements
     if (wave != 2) return;
+    pipe_redo<FUSE, TV>(a, nanflag, lane);
+}
+
+
+// =====================================================================================================================================
+// forward_pipe4_kernel — time-invariant dynamics: ONE 16-LANE ROW PER ROLLOUT, one chain wave for the four rollouts of the work-group.
+// The chain keeps dx_i = x̂_i − x_i.  Lane j < 10 of a row holds row j of A, lanes 10, 11 hold K_i[h, :] (fresh every step, from a
+// transposed copy of the LDS image), so ONE run of ten v_fmac_f64_dpp row_newbcast over dx gives A·dx_i in the lanes j < 10 and
+// K_i·dx_i in the lanes 10, 11 at once; started from (A·x_i)_j and ū_i[h] + α k_i[h] (a helper wave prepares both) the lanes hold
+// A·x̂_i and the controls u_i, and two more broadcast-FMAs (lanes 10, 11 → all) add B·u_i:
+//      x̂_{i+1} = (A x_i + A dx_i) + B_0 u_0 + B_1 u_1,     u_i = (ū_i + α k_i) + K_i dx_i           (forward_pass.jl:17-24)
+// — the reference's sums with A·x̂_i split as A·x_i + A·(x̂_i − x_i): differences of rounding order.  15 vector instructions per step on
+// the chain instead of 34 on each of two chain waves.  Waves: 0 output, 1 DMA (chunk c+4 in flight; transposes K of chunk c+1),
+// 2 the chain, 3 preparation (A·x_i, ū_i + α k_i of chunk c+1).  One s_barrier per chunk of G4 steps.
+constexpr int G4 = 8;
+struct L4 {
+    static constexpr int RAW_PER_ROLL = G4 * 17;                                // 16-byte slots: K (10 per step) | x (5) | ū (1) | k (1)
+    static constexpr int RAW_K = 0, RAW_X = G4 * 10, RAW_U = G4 * 15, RAW_KV = G4 * 16;
+    static constexpr int RAW_SLOTS = (R4 * RAW_PER_ROLL + 63) / 64 * 64, RAW_INSTR = RAW_SLOTS / 64, RAW_BUF = RAW_SLOTS * 16, NRAW = 5;
+    static constexpr int RAW_OFF = 0;
+    // coefficient blocks, one per step: rows 0..9 of A (80 B each, the same in every block) | K_i[h, :] of rollout r at (2r + h) | a zero row
+    static constexpr int CF_OFF = RAW_OFF + NRAW * RAW_BUF;
+    static constexpr int CF_A = 0, CF_K = 800, CF_Z = 800 + 8 * 80, CF_BLK = CF_Z + 80, CF_BUF = G4 * CF_BLK;
+    // start values, one block per step: (r, j < 12) pairs {start value, x_{i+1}[j]} | a pair of zeros
+    static constexpr int INI_OFF = CF_OFF + 2 * CF_BUF;
+    static constexpr int INI_Z = R4 * 192, INI_BLK = INI_Z + 16, INI_BUF = G4 * INI_BLK;
+    // x̂ and u of the chain: three regions of G4 + 1 slots; slot s of region c%3 holds x̂ of step s of chunk c (slot G4: step 0 of chunk
+    // c + 1) in the lanes j < 10 of its four rows; u of step s sits in the lanes 10, 11 of slot s (written one slot behind x̂)
+    static constexpr int XH_OFF = INI_OFF + 2 * INI_BUF;
+    static constexpr int XH_ROLL = 16 * 8 + 8, XH_SLOT = R4 * XH_ROLL + 16, XH_REG = (G4 + 1) * XH_SLOT;
+    static constexpr int DUMP_OFF = XH_OFF + 3 * XH_REG;
+    static constexpr int CF_SUM = DUMP_OFF + 64 * 8;                            // per-lane parts of sum(cnew)
+    static constexpr int FLAG_OFF = CF_SUM + 64 * 8;
+    static constexpr int TOTAL = FLAG_OFF + 16;
+};
+
+template <bool FUSE>
+__global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe4_kernel(FPipeArgs a)
+{
+    constexpr int n = PN, m = PM, G = G4;
+    using L = L4;
+    static_assert(R4 * G <= 64 && L::TOTAL <= 160 * 1024, "chunk size");
+    __shared__ __attribute__((aligned(16))) char smem[L::TOTAL];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const int N = a.N, B = a.B;
+    const int wave = threadIdx.x / DDP_WAVE, lane = threadIdx.x % DDP_WAVE;
+    const long total = (long)B * a.nalpha;
+    constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    auto roll = [&](int r, int &b, int &ai, bool &act) {
+        long lin = (long)blockIdx.x * R4 + r;
+        const bool valid = lin < total;
+        if (!valid) lin = total - 1;
+        b = (int)(lin / a.nalpha); ai = (int)(lin % a.nalpha);
+        act = valid && !(a.active && a.active[b] == 0);
+    };
     {
-        const int row = lane / 16, j = lane % 16;
-        const bool redo = nanflag[row] != 0;
-        if (!__any(redo)) return;
-        const bool inx = j < n;
-        const int jx = inx ? j : 0;
-        int b, ai; bool act; roll(row, b, ai, act);
-        const bool wr = act && redo;
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R4; ++r) { int b, ai; bool act; roll(r, b, ai, act); any = any || act; }
+        if (!any) return;
+    }
+    const int NC = (N + G - 1) / G;
+    int *nanflag = (int *)(smem + L::FLAG_OFF);
+    if (threadIdx.x < R4) nanflag[threadIdx.x] = 0;
+    // periods q = -2 .. NC, one barrier each: DMA issues chunk q+4 and transposes K of chunk q+1, preparation works on chunk q+1,
+    // the chain on chunk q, the output wave on chunk q-1
+
+    if (wave == 2) {
+        // ================================================ the chain =====================================================
+        const int r = lane / 16, j = lane % 16;
+        const bool inx = j < n, isu = j >= n && j < n + m;
+        int b, ai; bool act; roll(r, b, ai, act);
+        const double *Bb = a.Bm + (a.dyn_batched ? nm * b : 0);
+        const double B0 = inx ? Bb[j] : 0.0, B1 = inx ? Bb[j + n] : 0.0;
+        // per-lane addresses inside a step block
+        const unsigned cf_l = inx ? L::CF_A + j * 80 : (isu ? L::CF_K + (2 * r + (j - n)) * 80 : L::CF_Z);
+        const unsigned ini_l = j < n + m ? (r * 12 + j) * 16 : L::INI_Z;
+        const unsigned xn_l = (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + (inx ? j : n - 1) * 8;           // x_i[j] in a raw image
+        // where this lane's value of a step goes: x̂_{i+1}[j] into slot t+1, u_i[h] into slot t (lanes 10, 11), the rest to a dump
+        // (lanes 12..15: the unused positions of their row in slot t)
+        const unsigned w_l = inx ? L::XH_SLOT + r * L::XH_ROLL + j * 8 : r * L::XH_ROLL + j * 8;
+        {   // x̂ of step 0: slot G of region 2 ("chunk -1")
+            const double xh0 = inx ? a.x0[(size_t)n * b + j] : 0.0;
+            if (inx) *(double *)(smem + L::XH_OFF + 2 * L::XH_REG + G * L::XH_SLOT + r * L::XH_ROLL + j * 8) = xh0;
+        }
+        pipe_barrier();                                         // q = -2: the raw image of chunk 0 is there
+        double dx;
+        {   // dx of step 0 (in period -1: the image's buffer is rewritten from period 0 on)
+            const double x00 = *(const double *)(smem + L::RAW_OFF + xn_l);
+            dx = (inx ? a.x0[(size_t)n * b + j] : 0.0) - x00;
+            dpp_fence(dx);
+        }
+        pipe_barrier();                                         // q = -1: coefficients and start values of chunk 0 are there
+        PROF_DECL
+        for (int p = 0; p < NC; ++p) {
+            const char *pCF = smem + L::CF_OFF + (p & 1) * L::CF_BUF + cf_l;
+            const char *pIN = smem + L::INI_OFF + (p & 1) * L::INI_BUF + ini_l;
+            char *pW = smem + L::XH_OFF + (unsigned)(p % 3) * L::XH_REG + w_l;
+            d2 cf[2][5], ini[2];                                 // ini: {start value, x_{i+1}[j]}
+#pragma unroll
+            for (int q = 0; q < 5; ++q) cf[0][q] = *(const d2 *)(pCF + q * 16);
+            ini[0] = *(const d2 *)pIN;
+            static_for<0, G>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value, cu = t & 1, nx = cu ^ 1;
+                if constexpr (t + 1 < G) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) cf[nx][q] = *(const d2 *)(pCF + (t + 1) * L::CF_BLK + q * 16);
+                    ini[nx] = *(const d2 *)(pIN + (t + 1) * L::INI_BLK);
+                }
+                double a0 = ini[cu].x, a1 = 0.0;
+                asm volatile("" : "+v"(a1));
+                fmac_bc<0>(a0, dx, cf[cu][0].x); fmac_bc<1>(a1, dx, cf[cu][0].y);
+                fmac_bc<2>(a0, dx, cf[cu][1].x); fmac_bc<3>(a1, dx, cf[cu][1].y);
+                fmac_bc<4>(a0, dx, cf[cu][2].x); fmac_bc<5>(a1, dx, cf[cu][2].y);
+                fmac_bc<6>(a0, dx, cf[cu][3].x); fmac_bc<7>(a1, dx, cf[cu][3].y);
+                fmac_bc<8>(a0, dx, cf[cu][4].x); fmac_bc<9>(a1, dx, cf[cu][4].y);
+                double s = a0 + a1;                             // lanes < 10: (A x̂_i)_j; lanes 10, 11: u_i[h]
+                dpp_fence(s);
+                fmac_bc<10>(s, s, B0);                          // + B[:,0] u_0 (B0 = B1 = 0 in the lanes >= 10: they keep u)
+                dpp_fence(s);
+                fmac_bc<11>(s, s, B1);
+                *(double *)(pW + t * L::XH_SLOT) = s;           // x̂_{i+1} | u_i
+                dx = s - ini[cu].y;
+                dpp_fence(dx);
+            });
+            PROF(0);
+            pipe_barrier();
+            PROF(1);
+        }
+        PROF_DUMP(2);
+        pipe_barrier();                                         // q = NC
+    } else if (wave == 1) {
+        // ================================================ the DMA wave ==================================================
+        const char *src[L::RAW_INSTR];
+        unsigned stepb[L::RAW_INSTR], tau0[L::RAW_INSTR];
+#pragma unroll
+        for (int k = 0; k < L::RAW_INSTR; ++k) {
+            int s = k * 64 + lane;
+            if (s >= R4 * L::RAW_PER_ROLL) s = R4 * L::RAW_PER_ROLL - 1;
+            const int r = s / L::RAW_PER_ROLL, w = s % L::RAW_PER_ROLL;
+            int b, ai; bool act; roll(r, b, ai, act);
+            if (w < L::RAW_X) { src[k] = (const char *)(a.K + nm * N * b) + 16 * w; stepb[k] = 160; tau0[k] = w / 10; }
+            else if (w < L::RAW_U) { src[k] = (const char *)(a.x + (size_t)n * N * b) + 16 * (w - L::RAW_X); stepb[k] = 80; tau0[k] = (w - L::RAW_X) / 5; }
+            else if (w < L::RAW_KV) { src[k] = (const char *)(a.u + (size_t)m * N * b) + 16 * (w - L::RAW_U); stepb[k] = 16; tau0[k] = w - L::RAW_U; }
+            else { src[k] = (const char *)(a.k + (size_t)m * N * b) + 16 * (w - L::RAW_KV); stepb[k] = 16; tau0[k] = w - L::RAW_KV; }
+        }
+        // chunks are issued in order: every slot keeps the pointer of the next chunk to issue (no 64-bit multiply per instruction)
+        unsigned inc[L::RAW_INSTR];
+#pragma unroll
+        for (int k = 0; k < L::RAW_INSTR; ++k) inc[k] = G * stepb[k];
+        auto dma_chunk = [&](int c) __attribute__((always_inline)) {
+            const unsigned base = lds0 + L::RAW_OFF + (unsigned)(c % L::NRAW) * L::RAW_BUF;
+            if (__builtin_expect((c + 1) * G > N, 0)) {          // the last chunk may reach past the horizon: such slots re-read its first step
+#pragma unroll
+                for (int k = 0; k < L::RAW_INSTR; ++k) {
+                    const char *g = src[k];
+                    if (c * G + (int)tau0[k] >= N) g -= (size_t)tau0[k] * stepb[k];
+                    dma16(g, base + k * 1024);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < L::RAW_INSTR; ++k) { dma16(src[k], base + k * 1024); src[k] += inc[k]; }
+            }
+        };
+        // K_i of chunk c, both rows, from the image (16-byte column slots) to the coefficient blocks (80-byte rows): item (r, t, l)
+        constexpr int TKP = (R4 * G * n + 63) / 64;
+        static_assert(R4 * G * n % 64 == 0, "whole wave instructions");
+        unsigned tk_src[TKP], tk_dst[TKP];
+#pragma unroll
+        for (int q = 0; q < TKP; ++q) {
+            int e = 64 * q + lane;
+            const bool in = e < R4 * G * n;
+            e = in ? e : 0;
+            const int r = e / (G * n), t = (e % (G * n)) / n, l = e % n;
+            tk_src[q] = (r * L::RAW_PER_ROLL + L::RAW_K + t * 10 + l) * 16;
+            tk_dst[q] = L::CF_OFF + L::CF_K + t * L::CF_BLK + (2 * r) * 80 + l * 8;
+        }
+        auto transpose_k = [&](int c) __attribute__((always_inline)) {
+            const char *raw = smem + L::RAW_OFF + (unsigned)(c % L::NRAW) * L::RAW_BUF;
+            char *cfb = smem + (c & 1) * L::CF_BUF;
+            d2 kc[TKP];
+#pragma unroll
+            for (int q = 0; q < TKP; ++q) kc[q] = *(const d2 *)(raw + tk_src[q]);
+#pragma unroll
+            for (int q = 0; q < TKP; ++q) {
+                *(double *)(cfb + tk_dst[q]) = kc[q].x;
+                *(double *)(cfb + tk_dst[q] + 80) = kc[q].y;
+            }
+        };
+        dma_chunk(0);
+        if (1 < NC) dma_chunk(1);
+        if (2 < NC) dma_chunk(2);
+        PROF_DECL
+        for (int q = -2; q <= NC; ++q) {
+            if (q + 1 >= 0 && q + 1 < NC) transpose_k(q + 1);    // arrived two periods ago
+            PROF(3);
+            if (q + 5 < NC) {
+                dma_chunk(q + 5);
+                PROF(2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L::RAW_INSTR) : "memory");      // chunks <= q + 3 are in the LDS
+            } else if (q + 4 < NC) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::RAW_INSTR) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PROF(0);
+            pipe_barrier();
+            PROF(1);
+        }
+        PROF_DUMP(1);
+    } else if (wave == 3) {
+        // ================================================ preparation ===================================================
+        const int r = lane / 16, j = lane % 16;
+        const bool inx = j < n, isu = j >= n && j < n + m;
+        int b, ai; bool act; roll(r, b, ai, act);
         const double alpha = a.alpha[ai];
-        const double z = inx ? 1.0 : 0.0;
-        const double *Ab = a.A + (a.dyn_batched ? nn * (TV ? N : 1) * b : 0), *Bb = a.Bm + (a.dyn_batched ? nm * (TV ? N : 1) * b : 0);
-        const double *ug = a.u + (size_t)m * N * b, *xg = a.x + (size_t)n * N * b, *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b;
-        double *xo = a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai), *uo = a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai);
-        double *co = FUSE ? a.cnew + (size_t)N * ((size_t)b + (size_t)B * ai) : nullptr;
-        double Arow[n], Brow[m];
+        const double *Ab = a.A + (a.dyn_batched ? nn * b : 0);
+        double Arow[n];
 #pragma unroll
-        for (int l = 0; l < n; ++l) Arow[l] = z * Ab[jx + n * l];
-#pragma unroll
-        for (int q = 0; q < m; ++q) Brow[q] = z * Bb[jx + n * q];
+        for (int l = 0; l < n; ++l) Arow[l] = inx ? Ab[j + n * l] : 0.0;
+        // the constant parts of the coefficient / start-value blocks: rows of A (of THIS row's rollout when the dynamics are per
+        // trajectory: see the launcher — shared dynamics only), zero rows, zero start value
+        for (int e = lane; e < 2 * G * (L::CF_BLK / 8); e += DDP_WAVE) {
+            const int blk = e / (L::CF_BLK / 8), w = e % (L::CF_BLK / 8);
+            double v = 0.0;
+            if (w < 100) v = a.A[(w / 10) + n * (w % 10)];       // row w/10, entry w%10
+            if (w < 100 || w >= L::CF_Z / 8) *(double *)(smem + L::CF_OFF + blk * L::CF_BLK + w * 8) = v;
+        }
+        for (int e = lane; e < 2 * G * 2; e += DDP_WAVE) *(double *)(smem + L::INI_OFF + (e / 2) * L::INI_BLK + L::INI_Z + (e % 2) * 8) = 0.0;
         double one = 1.0;
         asm volatile("" : "+v"(one));
-        double cw = 0.0;
-        if (FUSE) cw = inx ? 0.5 * a.Q[jx + n * jx] : (j < n + m ? 0.5 * a.R[(j - n) + m * (j - n)] : 0.0);
-        double xh = inx ? a.x0[(size_t)n * b + jx] : 0.0, cacc = 0.0;
-        for (int i = 0; i < N; ++i) {
-            if (TV) {
+        auto prep = [&](int c) __attribute__((always_inline)) {
+            const char *raw = smem + L::RAW_OFF + (unsigned)(c % L::NRAW) * L::RAW_BUF;
+            const char *pX = raw + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + (inx ? j : n - 1) * 8;
+            const char *pU = raw + (r * L::RAW_PER_ROLL + L::RAW_U) * 16 + (isu ? j - n : 0) * 8;
+            const char *pV = raw + (r * L::RAW_PER_ROLL + L::RAW_KV) * 16 + (isu ? j - n : 0) * 8;
+            const char *pXn = smem + L::RAW_OFF + (unsigned)((c + 1) % L::NRAW) * L::RAW_BUF + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + (inx ? j : n - 1) * 8;
+            char *pO = j < n + m ? smem + L::INI_OFF + (c & 1) * L::INI_BUF + (r * 12 + j) * 16 : smem + L::DUMP_OFF + (lane & 31) * 16;
+            const unsigned ostep = j < n + m ? L::INI_BLK : 0;
+            double xv[G + 1], uv[G], kv[G];                      // every operand of the chunk first: no LDS round trip inside the loop
 #pragma unroll
-                for (int l = 0; l < n; ++l) Arow[l] = z * Ab[nn * i + jx + n * l];
+            for (int t = 0; t < G; ++t) { xv[t] = *(const double *)(pX + t * 80); uv[t] = *(const double *)(pU + t * 16); kv[t] = *(const double *)(pV + t * 16); }
+            xv[G] = *(const double *)pXn;                        // x of step 0 of the next chunk
 #pragma unroll
-                for (int q = 0; q < m; ++q) Brow[q] = z * Bb[nm * i + jx + n * q];
+            for (int t = 0; t < G; ++t) {
+                dpp_fence(xv[t]);
+                double a0 = 0.0, a1 = 0.0;
+                asm volatile("" : "+v"(a0), "+v"(a1));
+                RowDot<n>::run(a0, a1, xv[t], Arow);
+                const double ax = a0 + a1, uk = fma(kv[t], alpha, uv[t]);      // (A x_i)_j | ū_i[h] + α k_i[h]  (forward_pass.jl:18)
+                d2 o2;
+                o2.x = inx ? ax : uk; o2.y = xv[t + 1];
+                *(d2 *)(pO + t * ostep) = o2;
             }
-            const d2 Kc = *(const d2 *)(Kg + nm * i + m * jx), uc = *(const d2 *)(ug + (size_t)m * i), kc = *(const d2 *)(kg + (size_t)m * i);
-            const double dx = xh - xg[(size_t)n * i + jx];
-            double pr0 = Kc.x * dx, pr1 = Kc.y * dx;
-            dpp_fence(pr0, pr1);
-            double s0 = fma(kc.x, alpha, uc.x), s1 = 0.0, t0 = fma(kc.y, alpha, uc.y), t1 = 0.0;
-            RowSum<n>::run(s0, s1, pr0, one);
-            RowSum<n>::run(t0, t1, pr1, one);
-            double uu0 = s0 + s1, uu1 = t0 + t1;
-            if (uu0 != uu0) uu0 = 0.0;
-            if (uu1 != uu1) uu1 = 0.0;
-            const double v = inx ? xh : (j == n ? uu0 : (j == n + 1 ? uu1 : 0.0));
-            if (wr && inx) xo[(size_t)n * i + j] = v;
-            if (wr && j >= n && j < n + m) uo[(size_t)m * i + (j - n)] = v;
-            if (FUSE) {
-                double pc = (cw * v) * v, c0 = 0.0, c1 = 0.0;
-                dpp_fence(pc);
-                RowSum<n + m>::run(c0, c1, pc, one);
-                const double cs = c0 + c1;
-                if (wr && j == 0) co[i] = cs;
-                cacc += cs;
-            }
-            double x0a = 0.0, x1a = 0.0;
-            dpp_fence(xh);
-            RowDot<n>::run(x0a, x1a, xh, Arow);
-            xh = fma(Brow[1], uu1, fma(Brow[0], uu0, x0a + x1a));
-            dpp_fence(xh);
+        };
+        pipe_barrier();                                         // q = -2
+        PROF_DECL
+        for (int q = -1; q <= NC; ++q) {
+            if (q + 1 < NC) prep(q + 1);
+            PROF(0);
+            pipe_barrier();
+            PROF(1);
         }
-        if (FUSE && wr && j == 0) a.csum[(size_t)b + (size_t)B * ai] = cacc;
+        PROF_DUMP(3);
+    } else {
+        // ================================================ the output wave ===============================================
+        char *sink = (char *)(a.sink + lane);
+        constexpr int XI = R4 * G * n, XPASS = (XI + 63) / 64;
+        unsigned x_rd[XPASS], x_tau[XPASS];
+        char *x_dst[XPASS];
+        bool x_on[XPASS];
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            int e = 64 * q + lane;
+            const bool in = e < XI;
+            e = in ? e : XI - 1;
+            const int r = e / (G * n), tau = (e % (G * n)) / n, j = e % n;
+            int b, ai; bool act; roll(r, b, ai, act);
+            x_rd[q] = tau * L::XH_SLOT + r * L::XH_ROLL + j * 8;          // (tau = 0: slot G of the region before, see xbase below)
+            x_tau[q] = tau;
+            x_on[q] = in && act;
+            x_dst[q] = (char *)(a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai) + (size_t)tau * n + j);
+        }
+        constexpr int UI = R4 * G * m, UPASS = (UI + 63) / 64;
+        unsigned u_rd[UPASS], u_tau[UPASS];
+        char *u_dst[UPASS];
+        bool u_on[UPASS];
+#pragma unroll
+        for (int q = 0; q < UPASS; ++q) {
+            int e = 64 * q + lane;
+            const bool in = e < UI;
+            e = in ? e : UI - 1;
+            const int r = e / (G * m), tau = (e % (G * m)) / m, qq = e % m;
+            int b, ai; bool act; roll(r, b, ai, act);
+            u_rd[q] = tau * L::XH_SLOT + r * L::XH_ROLL + (n + qq) * 8;
+            u_tau[q] = tau;
+            u_on[q] = in && act;
+            u_dst[q] = (char *)(a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai) + (size_t)tau * m + qq);
+        }
+        const int ce = lane < R4 * G ? lane : R4 * G - 1, cr_ = ce / G, ctau = ce % G;
+        int cb, cai; bool cact; roll(cr_, cb, cai, cact);
+        const bool c_on = lane < R4 * G && cact;
+        const unsigned c_rx = ctau * L::XH_SLOT + cr_ * L::XH_ROLL;
+        char *c_dst = FUSE ? (char *)(a.cnew + (size_t)N * ((size_t)cb + (size_t)B * cai) + ctau) : nullptr;
+        double cq[n], cr0 = 0.0, cr1 = 0.0;
+        if (FUSE) {
+#pragma unroll
+            for (int l = 0; l < n; ++l) cq[l] = 0.5 * a.Q[l + n * l];
+            cr0 = 0.5 * a.R[0]; cr1 = 0.5 * a.R[1 + m];
+        }
+        double cacc = 0.0;
+        auto output = [&](int c) __attribute__((always_inline)) {
+            // x̂ of step tau of chunk c: slot tau of region c%3, step 0: slot G of region (c-1)%3; u of step tau: slot tau of region c%3
+            const unsigned reg = L::XH_OFF + (unsigned)(c % 3) * L::XH_REG, regp = L::XH_OFF + (unsigned)((c + 2) % 3) * L::XH_REG + G * L::XH_SLOT;
+            const bool tail = (c + 1) * G > N;
+            {
+                d2 uv;
+                uv.x = *(const double *)(smem + reg + c_rx + n * 8); uv.y = *(const double *)(smem + reg + c_rx + n * 8 + 8);
+                if (uv.x != uv.x || uv.y != uv.y) nanflag[cr_] = 1;
+                if (FUSE) {
+                    const unsigned xb = ctau == 0 ? regp + cr_ * L::XH_ROLL : reg + c_rx;
+                    double q0 = 0.0;
+#pragma unroll
+                    for (int l = 0; l < n; ++l) { const double xv = *(const double *)(smem + xb + l * 8); q0 += (cq[l] * xv) * xv; }
+                    const double ci = (q0 + (cr0 * uv.x) * uv.x) + (cr1 * uv.y) * uv.y;
+                    const bool on = c_on && (!tail || c * G + ctau < N);
+                    store_untracked(on ? c_dst + (size_t)c * (G * 8) : sink, ci);
+                    cacc += on ? ci : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UPASS; ++q) {
+                const double v = *(const double *)(smem + reg + u_rd[q]);
+                const bool on = u_on[q] && (!tail || c * G + (int)u_tau[q] < N);
+                store_untracked(on ? u_dst[q] + (size_t)c * (G * m * 8) : sink, v);
+            }
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) {
+                const unsigned ad = x_tau[q] == 0 ? regp + (x_rd[q] - 0u) : reg + x_rd[q];
+                const double v = *(const double *)(smem + ad);
+                const bool on = x_on[q] && (!tail || c * G + (int)x_tau[q] < N);
+                store_untracked(on ? x_dst[q] + (size_t)c * (G * n * 8) : sink, v);
+            }
+        };
+        PROF_DECL
+        for (int q = -2; q <= NC; ++q) {
+            if (q - 1 >= 0) output(q - 1);
+            PROF(0);
+            pipe_barrier();
+            PROF(1);
+        }
+        PROF_DUMP(0);
+        *(double *)(smem + L::CF_SUM + lane * 8) = cacc;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (FUSE && threadIdx.x < R4) {
+        const int r = threadIdx.x;
+        int b, ai; bool act; roll(r, b, ai, act);
+        double s = 0.0;
+        for (int t = 0; t < G; ++t) s += *(const double *)(smem + L::CF_SUM + (r * G + t) * 8);
+        if (act && nanflag[r] == 0) a.csum[(size_t)b + (size_t)B * ai] = s;
+    }
+    if (wave != 2) return;
+    pipe_redo<FUSE, false>(a, nanflag, lane);
 }
 
 }   // namespace
@@ -490,7 +870,7 @@ int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K,
     const long total = (long)p->B * nalpha;
     // one work-group (4 rollouts) per CU: with two the chain waves share their SIMDs and the pass is no faster than the row kernel
     // (2 048 rollouts: 0.215 against 0.201 ms)
-    if (!(env && env[0] == '1') && total > 1024) return 1;
+    if (!(env && (env[0] == '1' || env[0] == '2')) && total > 1024) return 1;
     if ((((uintptr_t)K | (uintptr_t)k | (uintptr_t)u | (uintptr_t)x) & 15) != 0) return 1;   // 16-byte pieces of K_i, x_i, k_i, ū_i for the DMA
     if (p->dyn_tv && (((uintptr_t)p->A | (uintptr_t)p->Bm) & 15) != 0) return 1;
     FPipeArgs a;
@@ -501,8 +881,12 @@ int ddp_launch_forward_pipe(ddp_handle h, const ddp_problem *p, const double *K,
     const dim3 grid((unsigned)((total + 3) / 4));
     // time-varying dynamics: A_i, B_i (960 of the 1 232 bytes per step and rollout) come through the same image; chunks of 8 steps keep
     // three images (120 KB) in the LDS
+    h->last_kernel[1] = "forward_pipe_kernel";
     if (p->dyn_tv) hipLaunchKernelGGL((forward_pipe_kernel<8, true, true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
-    else hipLaunchKernelGGL((forward_pipe_kernel<12, true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
+    else if (!p->dyn_batched && !(env && env[0] == '2')) {       // shared time-invariant dynamics: one row per rollout (DDP_FORWARD_PIPE=2: the two-row kernel)
+        hipLaunchKernelGGL((forward_pipe4_kernel<true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
+        h->last_kernel[1] = "forward_pipe4_kernel";
+    } else hipLaunchKernelGGL((forward_pipe_kernel<12, true>), grid, dim3(DDP_WAVE * 4), 0, h->stream, a);
     DDP_HIP(hipGetLastError());
     return 0;
 }

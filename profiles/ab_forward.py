@@ -33,7 +33,7 @@ def main():
     torch.cuda.synchronize()
     n, m = 10, 2
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "2", "1"):
         os.environ["DDP_FORWARD_PIPE"] = mode
         xn = torch.zeros(n * N * B, dtype=torch.float64, device=dev)
         un = torch.zeros(m * N * B, dtype=torch.float64, device=dev)
@@ -53,6 +53,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         out[mode] = (xn.cpu().numpy(), un.cpu().numpy(), cn.cpu().numpy(), cs.cpu().numpy(), e0.elapsed_time(e1) / reps)
+    print("two-row pipe kernel  %.4f ms per launch" % out["2"][4])
     a, b = out["0"], out["1"]
     for name, x, y in zip(("xnew", "unew", "cnew", "csum"), a[:4], b[:4]):
         d = np.max(np.abs(x - y)) / max(np.max(np.abs(x)), 1e-300)
@@ -61,11 +62,11 @@ def main():
         try:
             buf = (C.c_longlong * 40)()
             L.ddp_debug_pipe_prof(buf)
-            NCH = (N + 11) // 12
-            names = ["output", "dma", "chain0", "chain1", "-"]
-            for w in range(5):
+            NCH = (N + 7) // 8                                   # the last launch was forward_pipe4_kernel: chunks of 8 steps
+            names = ["output", "dma", "chain", "prep", "-"]
+            for w in range(4):
                 v = [buf[8 * w + q] / NCH for q in range(5)]
-                print("  %-8s per period (s_memtime ticks): work %7.1f  barrier %7.1f  dma issue %7.1f" % (names[w], v[0], v[1], v[2]))
+                print("  %-8s per period of 8 steps (s_memtime ticks): work %7.1f  barrier %7.1f  dma issue %7.1f  K transposition %7.1f" % (names[w], v[0], v[1], v[2], v[3]))
         except Exception as exc:
             print("no phase profile:", exc)
     print("row kernel   %.4f ms per launch" % a[4])

@@ -10,7 +10,7 @@ import os
 import sys
 
 root, tag = sys.argv[1], sys.argv[2]
-KERNELS = ("sh_back_kernel", "sh_group_kernel", "back_pass_mx2_kernel", "forward_pipe_kernel", "back_pass_mx_kernel", "back_pass_fast_kernel", "back_pass_dppw_kernel", "back_pass_dpp_kernel", "back_pass_q4p_kernel", "back_pass_q4_kernel", "back_pass_kernel", "forward_dpp_kernel", "cost_kernel", "forward_pass_kernel")
+KERNELS = ("sh_back_kernel", "sh_group_kernel", "back_pass_mx2_kernel", "forward_pipe4_kernel", "forward_pipe_kernel", "back_pass_mx_kernel", "back_pass_fast_kernel", "back_pass_dppw_kernel", "back_pass_dpp_kernel", "back_pass_q4p_kernel", "back_pass_q4_kernel", "back_pass_kernel", "forward_dpp_kernel", "cost_kernel", "forward_pass_kernel")
 
 
 def short(name):

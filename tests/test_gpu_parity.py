@@ -248,7 +248,7 @@ def test_full_size_c2_the_timed_step(ddp):
     div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, P["Q"], np.zeros((n, m)), P["R"], P["A"], P["B"], 1.0, 1, None, x, u)
     assert _lib.default_handle().last_kernel(0) == "sh_back_kernel"
     xn, un, cn = ddp.forward_pass(pol, x0, u, x, 1.0, prob, None)
-    assert _lib.default_handle().last_kernel(1) == "forward_pipe_kernel"
+    assert _lib.default_handle().last_kernel(1) == "forward_pipe4_kernel"
     assert not div.any()
     assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2, 3)))
     p = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=P["Q"], R=P["R"])

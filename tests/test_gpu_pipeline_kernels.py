@@ -36,8 +36,10 @@ def _rollout_case(rng, N, B, batched_dyn=False):
 
 @pytest.mark.parametrize("B,N,na", [(1, 1, 1), (1, 2, 1), (3, 11, 1), (4, 12, 1), (5, 13, 2), (9, 24, 3), (7, 25, 1), (6, 100, 11), (17, 37, 1),
                                     (2, 36, 16)])
-def test_forward_pipe_vs_row_kernel_and_oracle(ddp, monkeypatch, B, N, na):
-    """same statements and summation order as the row kernel for x̂ and u: bit-identical xnew / unew; cost to rounding; oracle 1e-8"""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_forward_pipe_vs_row_kernel_and_oracle(ddp, monkeypatch, B, N, na, mode):
+    """mode 2 (two rows per rollout): same statements and summation order as the row kernel for x̂ and u: bit-identical xnew / unew;
+    mode 1 (one row per rollout, forward_pipe4_kernel: A x̂ formed as A x + A (x̂ - x)): to rounding; cost to rounding; oracle 1e-8"""
     from oracle import oracle_ctypes as oc
     rng = np.random.default_rng(1000 * B + N)
     P, A, Bm, x0, u, K, k = _rollout_case(rng, N, B)
@@ -48,9 +50,14 @@ def test_forward_pipe_vs_row_kernel_and_oracle(ddp, monkeypatch, B, N, na):
     xnom = xnom.reshape(10, N, B)
     alphas = 10.0 ** np.linspace(0, -3, na) if na > 1 else 1.0
     row = ddp.forward_pass(pol, x0, u, xnom, alphas, prob, None)
-    monkeypatch.setenv("DDP_FORWARD_PIPE", "1")
+    monkeypatch.setenv("DDP_FORWARD_PIPE", mode)
     pipe = ddp.forward_pass(pol, x0, u, xnom, alphas, prob, None)
-    assert np.array_equal(pipe[0], row[0]) and np.array_equal(pipe[1], row[1])
+    from ddp_amd import _lib
+    assert _lib.default_handle().last_kernel(1) == ("forward_pipe4_kernel" if mode == "1" else "forward_pipe_kernel")
+    if mode == "2":
+        assert np.array_equal(pipe[0], row[0]) and np.array_equal(pipe[1], row[1])
+    else:
+        assert relerr(pipe[0], row[0]) < 1e-13 and relerr(pipe[1], row[1]) < 1e-13
     assert relerr(pipe[2], row[2]) < 1e-13
     p = oc.make_problem("lq", 10, 2, N, A=A, B=Bm, Q=P["Q"], R=P["R"])
     al = np.atleast_1d(alphas)
