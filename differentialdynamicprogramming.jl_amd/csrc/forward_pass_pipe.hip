@@ -502,7 +502,10 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe_kernel(FPipeArgs a)
 // — the reference's sums with A·x̂_i split as A·x_i + A·(x̂_i − x_i): differences of rounding order.  15 vector instructions per step on
 // the chain instead of 34 on each of two chain waves.  Waves: 0 output, 1 DMA (chunk c+4 in flight; transposes K of chunk c+1),
 // 2 the chain, 3 preparation (A·x_i, ū_i + α k_i of chunk c+1).  One s_barrier per chunk of G4 steps.
-constexpr int G4 = 8;
+#ifndef PIPE4_G
+#define PIPE4_G 8
+#endif
+constexpr int G4 = PIPE4_G;
 struct L4 {
     static constexpr int RAW_PER_ROLL = G4 * 17;                                // 16-byte slots: K (10 per step) | x (5) | ū (1) | k (1)
     static constexpr int RAW_K = 0, RAW_X = G4 * 10, RAW_U = G4 * 15, RAW_KV = G4 * 16;
@@ -511,7 +514,7 @@ struct L4 {
     // coefficient blocks, one per step: rows 0..9 of A (80 B each, the same in every block) | K_i[h, :] of rollout r at (2r + h) | a zero row
     static constexpr int CF_OFF = RAW_OFF + NRAW * RAW_BUF;
     static constexpr int CF_A = 0, CF_K = 800, CF_Z = 800 + 8 * 80, CF_BLK = CF_Z + 80, CF_BUF = G4 * CF_BLK;
-    // start values, one block per step: (r, j < 12) pairs {start value, x_{i+1}[j]} | a pair of zeros
+    // start values, one block per step: (r, j < 12) pairs {start value, x_{i+1}[j] (0 for the controls)} | a pair of zeros
     static constexpr int INI_OFF = CF_OFF + 2 * CF_BUF;
     static constexpr int INI_Z = R4 * 192, INI_BLK = INI_Z + 16, INI_BUF = G4 * INI_BLK;
     // x̂ and u of the chain: three regions of G4 + 1 slots; slot s of region c%3 holds x̂ of step s of chunk c (slot G4: step 0 of chunk
@@ -519,7 +522,8 @@ struct L4 {
     static constexpr int XH_OFF = INI_OFF + 2 * INI_BUF;
     static constexpr int XH_ROLL = 16 * 8 + 8, XH_SLOT = R4 * XH_ROLL + 16, XH_REG = (G4 + 1) * XH_SLOT;
     static constexpr int DUMP_OFF = XH_OFF + 3 * XH_REG;
-    static constexpr int CF_SUM = DUMP_OFF + 64 * 8;                            // per-lane parts of sum(cnew)
+    static constexpr int ZERO_OFF = DUMP_OFF + 64 * 8;                          // 768 zero bytes: operands of the lanes without one
+    static constexpr int CF_SUM = ZERO_OFF + 768;                               // per-lane parts of sum(cnew)
     static constexpr int FLAG_OFF = CF_SUM + 64 * 8;
     static constexpr int TOTAL = FLAG_OFF + 16;
 };
@@ -654,13 +658,12 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe4_kernel(FPipeArgs a
         };
         // K_i of chunk c, both rows, from the image (16-byte column slots) to the coefficient blocks (80-byte rows): item (r, t, l)
         constexpr int TKP = (R4 * G * n + 63) / 64;
-        static_assert(R4 * G * n % 64 == 0, "whole wave instructions");
         unsigned tk_src[TKP], tk_dst[TKP];
 #pragma unroll
         for (int q = 0; q < TKP; ++q) {
             int e = 64 * q + lane;
             const bool in = e < R4 * G * n;
-            e = in ? e : 0;
+            e = in ? e : 0;                                      // (lanes past the end repeat item 0: the same value to the same place)
             const int r = e / (G * n), t = (e % (G * n)) / n, l = e % n;
             tk_src[q] = (r * L::RAW_PER_ROLL + L::RAW_K + t * 10 + l) * 16;
             tk_dst[q] = L::CF_OFF + L::CF_K + t * L::CF_BLK + (2 * r) * 80 + l * 8;
@@ -717,14 +720,17 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe4_kernel(FPipeArgs a
             if (w < 100 || w >= L::CF_Z / 8) *(double *)(smem + L::CF_OFF + blk * L::CF_BLK + w * 8) = v;
         }
         for (int e = lane; e < 2 * G * 2; e += DDP_WAVE) *(double *)(smem + L::INI_OFF + (e / 2) * L::INI_BLK + L::INI_Z + (e % 2) * 8) = 0.0;
+        for (int e = lane; e < 96; e += DDP_WAVE) *(double *)(smem + L::ZERO_OFF + e * 8) = 0.0;
         double one = 1.0;
         asm volatile("" : "+v"(one));
         auto prep = [&](int c) __attribute__((always_inline)) {
             const char *raw = smem + L::RAW_OFF + (unsigned)(c % L::NRAW) * L::RAW_BUF;
-            const char *pX = raw + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + (inx ? j : n - 1) * 8;
-            const char *pU = raw + (r * L::RAW_PER_ROLL + L::RAW_U) * 16 + (isu ? j - n : 0) * 8;
-            const char *pV = raw + (r * L::RAW_PER_ROLL + L::RAW_KV) * 16 + (isu ? j - n : 0) * 8;
-            const char *pXn = smem + L::RAW_OFF + (unsigned)((c + 1) % L::NRAW) * L::RAW_BUF + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + (inx ? j : n - 1) * 8;
+            // lanes without an operand read zeros: no select in the loop
+            const char *zero = smem + L::ZERO_OFF;
+            const char *pX = inx ? raw + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + j * 8 : zero;
+            const char *pU = isu ? raw + (r * L::RAW_PER_ROLL + L::RAW_U) * 16 + (j - n) * 8 : zero;
+            const char *pV = isu ? raw + (r * L::RAW_PER_ROLL + L::RAW_KV) * 16 + (j - n) * 8 : zero;
+            const char *pXn = inx ? smem + L::RAW_OFF + (unsigned)((c + 1) % L::NRAW) * L::RAW_BUF + (r * L::RAW_PER_ROLL + L::RAW_X) * 16 + j * 8 : zero;
             char *pO = j < n + m ? smem + L::INI_OFF + (c & 1) * L::INI_BUF + (r * 12 + j) * 16 : smem + L::DUMP_OFF + (lane & 31) * 16;
             const unsigned ostep = j < n + m ? L::INI_BLK : 0;
             double xv[G + 1], uv[G], kv[G];                      // every operand of the chunk first: no LDS round trip inside the loop
@@ -733,13 +739,11 @@ __global__ __launch_bounds__(DDP_WAVE * 4) void forward_pipe4_kernel(FPipeArgs a
             xv[G] = *(const double *)pXn;                        // x of step 0 of the next chunk
 #pragma unroll
             for (int t = 0; t < G; ++t) {
-                dpp_fence(xv[t]);
-                double a0 = 0.0, a1 = 0.0;
-                asm volatile("" : "+v"(a0), "+v"(a1));
-                RowDot<n>::run(a0, a1, xv[t], Arow);
-                const double ax = a0 + a1, uk = fma(kv[t], alpha, uv[t]);      // (A x_i)_j | ū_i[h] + α k_i[h]  (forward_pass.jl:18)
+                double a0 = fma(kv[t], alpha, uv[t]), a1 = 0.0;  // ū_i[h] + α k_i[h] in the control lanes (forward_pass.jl:18), 0 elsewhere
+                asm volatile("" : "+v"(a1));
+                RowDot<n>::run(a0, a1, xv[t], Arow);             // + (A x_i)_j in the state lanes (zero rows of A elsewhere)
                 d2 o2;
-                o2.x = inx ? ax : uk; o2.y = xv[t + 1];
+                o2.x = a0 + a1; o2.y = xv[t + 1];
                 *(d2 *)(pO + t * ostep) = o2;
             }
         };
