@@ -126,19 +126,25 @@ __device__ __forceinline__ void store16_nt(void *p, d2 v)
 }
 
 // =============================================================== grouping ====================================================
+// REGS: every thread keeps the table slots of its (at most 8) trajectories in registers between the two passes; otherwise they are parked
+// in global memory (perm[], then fb_active[]).  The kernel is a chain of dependent steps on ONE work-group in front of the whole backward
+// pass: every global round trip in it (~1-2 us) is time the 256 CUs wait.
+template <bool REGS>
 __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
 {
     __shared__ unsigned long long keys[SH_TAB];
-    __shared__ int cnt[SH_TAB], gof[SH_TAB], cursor[SH_GMAX], gst[SH_GMAX], gcn[SH_GMAX], Gs, nfb;
+    __shared__ int cnt[SH_TAB], gof[SH_TAB], cursor[SH_GMAX], gst[SH_GMAX], gcn[SH_GMAX], gtile[SH_GMAX + 1], Gs, Ts, nfb;
     const unsigned long long EMPTY = ~0ull;
-    const int tid = threadIdx.x, B = a.B;
+    const int tid = threadIdx.x, B = a.B, lane = tid & 63;
+    constexpr int NPT = 8;
+    int slotr[NPT];
     if (tid < SH_TAB) { keys[tid] = EMPTY; cnt[tid] = 0; gof[tid] = -1; }
     if (tid < SH_GMAX) cursor[tid] = 0;
     if (tid == 0) nfb = 0;
     __syncthreads();
-    // pass 1: distinct values and their populations; the slot of a trajectory is parked in perm[].  A wave whose active lanes all carry
-    // the same λ (the usual case: one λ for the batch, or a few values in runs) inserts ONCE and adds its population once — per-lane
-    // atomics on one LDS word serialise (18 us at B = 1 024, 158 us at B = 32 768 before this).
+    // pass 1: distinct values and their populations.  A wave whose active lanes all carry the same λ (the usual case: one λ for the
+    // batch, or a few values in runs) inserts ONCE and adds its population once — per-lane atomics on one LDS word serialise (18 us at
+    // B = 1 024, 158 us at B = 32 768 before this).
     auto insert = [&](unsigned long long key, int n_) -> int {
         unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 58);
         for (int t = 0; t < SH_TAB; ++t, h = (h + 1) % SH_TAB) {
@@ -147,8 +153,7 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
         }
         return -2;
     };
-    for (int b0 = 0; b0 < B; b0 += blockDim.x) {
-        const int b = b0 + tid;
+    auto pass1 = [&](int b) -> int {
         const bool inb = b < B;
         const bool on = inb && (!a.active || a.active[b] != 0);
         const unsigned long long key = on ? (unsigned long long)__double_as_longlong(a.lambda[b]) : EMPTY;
@@ -161,68 +166,95 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
             const unsigned long long k0 = __shfl(key, lead);
             const unsigned long long same = __ballot(on && key == k0) & rest;
             int s0 = 0;
-            if ((int)(threadIdx.x & 63) == lead) s0 = insert(k0, __popcll(same));
+            if (lane == lead) s0 = insert(k0, __popcll(same));
             s0 = __shfl(s0, lead);
-            if ((same >> (threadIdx.x & 63)) & 1ull) slot = s0;
+            if ((same >> lane) & 1ull) slot = s0;
             rest &= ~same;
         }
-        if (inb) a.perm[b] = slot;                   // -1 inactive, -2 no slot, else the slot
+        return slot;                                 // -1 inactive, -2 no slot, else the slot
+    };
+    if (REGS) {
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) slotr[q] = (q * 1024 < B) ? pass1(q * 1024 + tid) : -1;      // (block-uniform condition)
+    } else {
+        for (int b0 = 0; b0 < B; b0 += blockDim.x) { const int sl = pass1(b0 + tid); if (b0 + tid < B) a.perm[b0 + tid] = sl; }
     }
     __syncthreads();
-    if (tid == 0) {   // the SH_GMAX most populated values with at least two trajectories become groups
-        int G = 0, start = 0, W = 0;
+    if (tid < 64) {   // the SH_GMAX most populated values with at least two trajectories become groups (wave 0: an arg-max per group)
+        int mine = cnt[tid] > 1 ? (cnt[tid] << 8) | (SH_TAB - 1 - tid) : 0;      // ties: the lowest slot
+        int G = 0, start = 0;
         for (; G < SH_GMAX; ++G) {
-            int best = -1, bc = 1;
-            for (int s = 0; s < SH_TAB; ++s) if (gof[s] < 0 && cnt[s] > bc) { best = s; bc = cnt[s]; }
-            if (best < 0) break;
-            gof[best] = G; gst[G] = start; gcn[G] = bc;
-            a.ctl->glam[G] = __longlong_as_double((long long)keys[best]);
-            a.ctl->gcount[G] = bc; a.ctl->gstart[G] = start;
+            int best = mine;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+            if (best == 0) break;
+            const int sb = SH_TAB - 1 - (best & 0xff), bc = best >> 8;
+            if (tid == sb) { mine = 0; gof[sb] = G; }
+            if (tid == 0) {
+                gst[G] = start; gcn[G] = bc;
+                a.ctl->glam[G] = __longlong_as_double((long long)keys[sb]);
+                a.ctl->gcount[G] = bc; a.ctl->gstart[G] = start;
+            }
             start += bc;
         }
         // Tile size: one work-group per CU is resident (LDS), the G producers hold a CU each while the chain runs.  R rounds of
         // (ncu - G) tiles of equal size, no tile more than TMAX trajectories: every CU is busy until the end, nobody queues behind a
         // full machine for a lone last tile.  (The host sized the grid for the smallest tile this can choose.)
-        int T = 4;
-        if (G > 0) {
-            const int slots = a.ncu - G > 8 ? a.ncu - G : 8;
-            const int R = (start + slots * TMAX - 1) / (slots * TMAX);
-            T = (start + R * slots - 1) / (R * slots);
-            T = T < 4 ? 4 : T;
-            for (; T < TMAX; ++T) { int w = 0; for (int g = 0; g < G; ++g) w += (gcn[g] + T - 1) / T; if (w <= R * slots) break; }
+        if (tid == 0) {
+            int T = 4, W = 0;
+            if (G > 0) {
+                const int slots = a.ncu - G > 8 ? a.ncu - G : 8;
+                const int R = (start + slots * TMAX - 1) / (slots * TMAX);
+                T = (start + R * slots - 1) / (R * slots);
+                T = T < 4 ? 4 : T;
+                for (; T < TMAX; ++T) { int w = 0; for (int g = 0; g < G; ++g) w += (gcn[g] + T - 1) / T; if (w <= R * slots) break; }
+            }
+            for (int g = 0; g < G; ++g) { gtile[g] = W; W += (gcn[g] + T - 1) / T; }
+            gtile[G] = W;
+            Gs = G; Ts = T;
+            a.ctl->G = G; a.ctl->W = W; a.ctl->ticket = 0; a.ctl->error = 0;
         }
-        for (int g = 0; g < G; ++g)
-            for (int t0 = 0; t0 < gcn[g]; t0 += T) a.items[W++] = make_int4(g, gst[g] + t0, gcn[g] - t0 < T ? gcn[g] - t0 : T, 0);
-        Gs = G;
-        a.ctl->G = G; a.ctl->W = W; a.ctl->ticket = 0; a.ctl->error = 0;
     }
     if (tid < SH_GMAX) { a.ctl->progress[16 * tid] = 0; a.ctl->gdiverge[tid] = 0; }
     __syncthreads();
-    // pass 2: counting sort into perm (the slot of b was parked at perm[b]; positions >= the sorted prefix are only read, never
-    // written, before their own thread has picked them up — the sorted area may overlap unread slots, so park them in fb_active first)
-    for (int b = tid; b < B; b += blockDim.x) a.fb_active[b] = a.perm[b];
-    __syncthreads();
-    for (int b0 = 0; b0 < B; b0 += blockDim.x) {
-        const int b = b0 + tid;
+    {   // the tiles, one per thread
+        const int G = Gs, T = Ts, W = gtile[G];
+        for (int w = tid; w < W; w += blockDim.x) {
+            int g = 0;
+            while (g + 1 < G && gtile[g + 1] <= w) ++g;
+            const int t0 = (w - gtile[g]) * T;
+            a.items[w] = make_int4(g, gst[g] + t0, gcn[g] - t0 < T ? gcn[g] - t0 : T, 0);
+        }
+    }
+    // pass 2: counting sort into perm
+    auto pass2 = [&](int b, int slot) {
         const bool inb = b < B;
-        const int slot = inb ? a.fb_active[b] : -1;
         const int g = slot >= 0 ? gof[slot] : -1;
         const bool fbk = inb && g < 0 && slot != -1;
-        // positions: one atomic per wave and group when the wave is uniform, per lane otherwise
         unsigned long long rest = __ballot(g >= 0);
         while (rest) {                                          // one atomic per wave and group present in it
             const int lead = __ffsll((long long)rest) - 1;
             const int g0 = __shfl(g, lead);
             const unsigned long long same = __ballot(g == g0) & rest;
             int base = 0;
-            if ((int)(threadIdx.x & 63) == lead) base = atomicAdd(&cursor[g0], __popcll(same));
+            if (lane == lead) base = atomicAdd(&cursor[g0], __popcll(same));
             base = __shfl(base, lead);
-            if ((same >> (threadIdx.x & 63)) & 1ull) a.perm[gst[g0] + base + __popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull))] = b;
+            if ((same >> lane) & 1ull) a.perm[gst[g0] + base + __popcll(same & ((1ull << lane) - 1ull))] = b;
             rest &= ~same;
         }
         const unsigned long long fbm = __ballot(fbk);
-        if (fbm && (int)(threadIdx.x & 63) == __ffsll((long long)fbm) - 1) atomicAdd(&nfb, __popcll(fbm));
+        if (fbm && lane == __ffsll((long long)fbm) - 1) atomicAdd(&nfb, __popcll(fbm));
         if (inb) a.fb_active[b] = fbk ? 1 : 0;
+    };
+    if (REGS) {
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) if (q * 1024 < B) pass2(q * 1024 + tid, slotr[q]);
+    } else {
+        // (the slot of b was parked at perm[b]; positions >= the sorted prefix are only read, never written, before their own thread has
+        // picked them up — the sorted area may overlap unread slots, so park them in fb_active first)
+        for (int b = tid; b < B; b += blockDim.x) a.fb_active[b] = a.perm[b];
+        __syncthreads();
+        for (int b0 = 0; b0 < B; b0 += blockDim.x) { const int b = b0 + tid; pass2(b, b < B ? a.fb_active[b] : -1); }
     }
     __syncthreads();
     if (tid == 0) a.ctl->nfb = nfb;
@@ -807,7 +839,8 @@ int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     a.ctl = (ShCtl *)base; a.items = (int4 *)(base + o_items); a.perm = (int *)(base + o_perm); a.fb_active = (int32_t *)(base + o_fb);
     a.rec = (double *)(base + o_rec);
-    hipLaunchKernelGGL(sh_group_kernel, dim3(1), dim3(1024), 0, h->stream, a);
+    if (a.B <= 8 * 1024) hipLaunchKernelGGL(sh_group_kernel<true>, dim3(1), dim3(1024), 0, h->stream, a);
+    else hipLaunchKernelGGL(sh_group_kernel<false>, dim3(1), dim3(1024), 0, h->stream, a);
     if (!h->sh_attr) {
         DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
         DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
