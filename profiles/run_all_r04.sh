@@ -6,7 +6,7 @@ set -u
 mkdir -p gpurun_out
 bash profiles/run_profile.sh r04 > gpurun_out/r04_run_profile.log 2>&1
 bash profiles/pmc_config.sh r04_c3 c3 back_pass_q4c,forward_pend_row_kernel,df_pendcart_kernel > /dev/null 2>&1
-bash profiles/pmc_config.sh r04_c2tv c2tv back_pass_mx,forward_pipe_kernel > /dev/null 2>&1
+bash profiles/pmc_config.sh r04_c2tv c2tv back_pass_mx,forward_pipe > /dev/null 2>&1
 bash profiles/pmc_config.sh r04_c4 c4 back_pass_mfma,forward_big64 > /dev/null 2>&1
 bash profiles/pmc_config.sh r04_c5 c5 back_pass_q4c,forward_pend_row_kernel,fcov_q4l_kernel,kl_div_lds_kernel > /dev/null 2>&1
 DDP_C4_LIMS=0.05 DDP_C4_SOLVE=0 DDP_BC_STEPS=40 DDP_BC_WARMUP=8 python profiles/bench_configs.py c4 > gpurun_out/r04_c4_lims.json 2>&1
