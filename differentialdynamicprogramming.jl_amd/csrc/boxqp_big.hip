@@ -4,7 +4,7 @@
 // algebra inside an iteration:
 //   grad = g + H·x, g + H·(x∘clamped)     one row per thread, j ascending (the reference's order); H[i + m·j]: coalesced
 //   value = x'g + ((½x')·H)·x              a wave per column (lanes over rows, coalesced), wave sums, then a fixed-order sum
-//   cholesky(H[free,free]).U               row by row (the order of LAPACK's unblocked dpotrf-U and of oracle/ddp_oracle.c:26-43):
+//   cholesky(H[free,free]).U               row by row (the order of LAPACK's unblocked dpotrf-U):
 //                                          R[k,c] = (A[k,c] − Σ_{p<k} R[p,k]·R[p,c]) / R[k,k], one column c per thread, p ascending;
 //                                          the factor is kept ROW-MAJOR in the caller's Hfree while it is worked on (row p of R is
 //                                          then contiguous over the threads' columns) and transposed in place at the end
