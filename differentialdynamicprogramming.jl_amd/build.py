@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libddp_amd.so")
 SOURCES = ["capi.hip", "back_pass.hip", "back_pass_dpp.hip", "back_pass_dppw.hip", "back_pass_big.hip", "back_pass_gps_lane.hip", "back_pass_mfma.hip", "back_pass_mfma_lims.hip", "back_pass_mx.hip", "back_pass_mx2.hip", "back_pass_sh.hip", "back_pass_q4.hip",
            "forward_pass.hip", "forward_pass_dpp.hip", "forward_pass_pipe.hip", "forward_pass_big.hip", "df.hip", "ilqg.hip", "kl.hip", "comm.hip", "boxqp_big.hip"]
 HEADERS = ["ddp_internal.h", "boxqp_dev.h", "boxqp_rows.h", "arena.h", os.path.join("..", "..", "include", "ddp_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Rpass-analysis=kernel-resource-usage", "-Wall", "-Wno-unused-function",
          "-Wno-unused-but-set-variable", "-Wno-unused-variable"]
 
 
@@ -55,6 +55,23 @@ def _code_digest(path):
     return _digests[path]
 
 
+def _save_usage(obj, stderr):
+    """registers, scratch and LDS of every kernel of a translation unit, from the compiler's kernel-resource-usage remarks ->
+    build/<unit>.usage.json (tests/test_capi_cpu.py: the kernels that count their own vector-memory operations — s_waitcnt vmcnt(N)
+    with N from the number of loads they issue — must not spill to scratch: a spill is a vector-memory operation the count does not know)"""
+    import json
+    out, cur = {}, None
+    for line in stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass-analysis", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = m.group(2)
+    json.dump(out, open(obj + ".usage.json", "w"), indent=0)
+
+
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     hdrs = [os.path.join(CSRC, h) for h in HEADERS + EXTRA_DEPS.get(src, [])]
@@ -66,6 +83,7 @@ def _compile(src):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        _save_usage(obj, r.stderr)
         open(stamp, "w").write(want)
         return src, True
     return src, False

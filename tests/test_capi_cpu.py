@@ -48,3 +48,25 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle_ctypes" not in src and "np_restatement" not in src and "ddp_oracle" not in src, f
+
+
+def test_kernels_that_count_their_memory_operations_do_not_spill():
+    """The pipeline kernels wait with `s_waitcnt vmcnt(N)` where N is the number of loads THEY issued (forward_pass_pipe.hip,
+    back_pass_mx*.hip, back_pass_sh.hip, back_pass_q4.hip).  A register spill would add scratch loads / stores the count does not know
+    about: the build records every kernel's resource usage (build.py, -Rpass-analysis=kernel-resource-usage) and none of these kernels
+    may use scratch.  (the bit-identity tests on the GPU were the only guard against a compiler change.)"""
+    import glob
+    import json
+    import __graft_entry__ as g
+    g.build()
+    files = glob.glob(os.path.join(ROOT, "differentialdynamicprogramming.jl_amd", "build", "*.usage.json"))
+    assert files, "no resource-usage records: build.py did not run with -Rpass-analysis=kernel-resource-usage"
+    usage = {}
+    for f in files:
+        usage.update(json.load(open(f)))
+    counted = [k for k in usage if any(s in k for s in ("forward_pipe", "sh_back_kernel", "back_pass_mx2_kernel", "back_pass_mx_kernel",
+                                                        "back_pass_q4c_kernel", "back_pass_q4l_kernel"))]
+    assert len(counted) >= 8, counted
+    for k in counted:
+        u = usage[k]
+        assert int(u["ScratchSize"]) == 0 and int(u["VGPRs Spill"]) == 0 and u["Dynamic Stack"] == "False", (k, u)
