@@ -218,3 +218,33 @@ def test_full_size_c2_groups_of_lambda(ddp):
     assert not out[0].any()
     assert np.array_equal(out[3], np.transpose(out[3], (1, 0, 2, 3)))
     par_map(lambda b: _check_all(out, cx, cu, P["Q"], np.zeros((n, m)), P["R"], P["A"], P["B"], lam, 1, u, who=[b]), range(B))
+
+
+def test_large_batch_grouping_path(ddp):
+    """B = 9 000 > 8 192: the grouping kernel parks the table slots in global memory between its passes (sh_group_kernel<false>) instead
+    of keeping them in registers; 6 λ groups in random order + singletons; a sample of trajectories (incl. the singletons and the ends of
+    the batch) against the oracle, and the whole batch against the per-trajectory kernels (DDP_BACKPASS forces them)"""
+    import os
+    from ddp_amd import _lib
+    rng = np.random.default_rng(2024)
+    N, B = 24, 9000
+    cx, cu, cxx, cxu, cuu, A, Bm, u = _lti(rng, N, B)
+    vals = np.array([0.0, 1.0, 1.0 / 1.6, 1.6, 1e-6, 2.56])
+    lam = vals[rng.integers(0, len(vals), B)]
+    single = [0, 4097, 8191, 8192, 8999]
+    lam[single] = [0.321, 3.3, 0.047, 9e-4, 0.77]
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)
+    assert _lib.default_handle().last_kernel(0) == "sh_back_kernel"
+    who = sorted(set(single + [1, 2, 63, 64, 1023, 1024, 4096, 8190, 8193, 8998] + list(rng.integers(0, B, 40))))
+    _check_all(out, cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, u, who=who)
+    os.environ["DDP_BACKPASS"] = "x"                              # mx: the per-trajectory kernel
+    try:
+        _lib.default_handle().raw
+        ref = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)
+        assert _lib.default_handle().last_kernel(0) != "sh_back_kernel"
+    finally:
+        del os.environ["DDP_BACKPASS"]
+        _lib.default_handle().raw
+    assert (out[0] == ref[0]).all()
+    for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4])):
+        assert relerr(a_, b_) < 1e-10
