@@ -87,3 +87,34 @@ def test_demoqp(ddp):
 def test_m_limit_is_reported(ddp):
     with pytest.raises(ddp.DDPError):
         ddp.boxQP(np.eye(1025), np.zeros(1025), -np.ones(1025), np.ones(1025), np.zeros(1025))
+
+
+@pytest.mark.parametrize("opts", [dict(maxIter=1), dict(maxIter=2), dict(maxIter=3), dict(minRelImprove=0.5), dict(minGrad=1e3),
+                                  dict(Armijo=0.9999, stepDec=0.5, minStep=0.3)])
+def test_boxqp_big_options_and_exit_codes(ddp, opts):
+    """the solver's keyword options (boxQP.jl:30-35): iteration cap (result 1 incl. the reference's `iter == maxIter` quirk), relative
+    improvement (4), gradient tolerance (5), a line search that gives up (2) — whatever the oracle returns, with the same iterate"""
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(17)
+    m = 30
+    H, g, lo, up, x0 = _qp(rng, m, 0.4)
+    x, res, Hf, free = ddp.boxQP(H, g, lo, up, x0, **opts)
+    xr, rr, Hfr, fr, it = oc.boxqp(H, g, lo, up, x0, opts=dict(dict(maxIter=100, minGrad=1e-8, minRelImprove=1e-8, stepDec=0.6, minStep=1e-22, Armijo=0.1), **opts))
+    assert res == rr and (free == fr).all(), (opts, res, rr)
+    assert relerr(x, xr) < RTOL and relerr(Hf, Hfr) < RTOL
+
+
+def test_boxqp_big_degenerate_bounds_and_start_outside(ddp):
+    """coordinates with lower == upper (always at a bound), a start far outside the box, one free coordinate only"""
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(23)
+    m = 20
+    H, g, lo, up, x0 = _qp(rng, m, 0.2)
+    lo[:5] = up[:5] = 0.25
+    x0 = 50.0 * rng.standard_normal(m)
+    for case in ((H, g, lo, up, x0), (H, 1e3 * np.r_[-1.0, np.ones(m - 1)], -np.ones(m), np.r_[1e6, np.ones(m - 1)], x0)):
+        x, res, Hf, free = ddp.boxQP(*case)
+        xr, rr, Hfr, fr, it = oc.boxqp(*case)
+        assert res == rr and (free == fr).all() and relerr(x, xr) < RTOL and Hf.shape == Hfr.shape
+        if Hf.size:
+            assert relerr(Hf, Hfr) < RTOL
