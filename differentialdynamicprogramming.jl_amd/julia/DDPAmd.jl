@@ -462,15 +462,7 @@ function iLQG(problem::RegisteredProblem, x0, u0; lims=[], α=DEFAULT_ALPHA, tol
     return x, u, policy(N, n, m, K, k, zeros(m, m, N, bt...), Quu), Vx, Vxx, costo, trace
 end
 
-# ---- the drop-in entry point ------------------------------------------------------------------------------------------
-const _ref = Ref{Any}(nothing)         # the reference module once `install!` has rebound its back_pass
-
-"""
-    install!(ref::Module = Main.DifferentialDynamicProgramming)
-
-Rebinds the three linear-system `back_pass` methods of the loaded reference package (src/backward_pass.jl:162,179,217) to
-`DDPAmd.back_pass`, so that the reference's own `iLQG(f,costfun,df,x0,u0; ...)` — arbitrary Julia closures, its own line search,
-trace and printing — runs STEP 2 (iLQG.jl:235-251) on the GPU.  Returns policies of the reference's own `GaussianPolicy` type.
+# ---- more problems than resident trajectories, and the closed loop ----------------------------------------------------
 """
     iLQG_queue(problem, x0[n,P], u0[m,N,P]; slots=0, lims=[], α, tol_fun, ...) -> x, u, traj_new, Vx, Vxx, cost, trace
 
@@ -526,6 +518,15 @@ function iLQG_mpc(problem::RegisteredProblem, x0::AbstractMatrix, u0::AbstractAr
     return xcl, ucl, scl, x, u
 end
 
+# ---- the drop-in entry point ------------------------------------------------------------------------------------------
+const _ref = Ref{Any}(nothing)         # the reference module once `install!` has rebound its back_pass
+
+"""
+    install!(ref::Module = Main.DifferentialDynamicProgramming)
+
+Rebinds the three linear-system `back_pass` methods of the loaded reference package (src/backward_pass.jl:162,179,217) to
+`DDPAmd.back_pass`, so that the reference's own `iLQG(f,costfun,df,x0,u0; ...)` — arbitrary Julia closures, its own line search,
+trace and printing — runs STEP 2 (iLQG.jl:235-251) on the GPU.  Returns policies of the reference's own `GaussianPolicy` type.
 """
 function install!(ref::Module=getfield(Main, :DifferentialDynamicProgramming))
     pol(N, n, m, K, k, Σ, Σi) = ref.GaussianPolicy(N, n, m, K, k, Σ, Σi)

@@ -1,0 +1,248 @@
+"""Structural lint of the shipped Julia sources (no Julia in the build image, so nothing can `include` them here).
+
+`tests/test_julia_binding.py` checks every `@ccall` against include/ddp_amd.h with regular expressions; a file whose functions sit INSIDE
+string literals (round 4: a lost triple quote put `iLQG_queue` / `iLQG_mpc` into `install!`'s docstring — a ParseError for
+`include("DDPAmd.jl")`) passes that check.  This one tokenises the files with pygments' JuliaLexer and verifies the structure a parser
+would need:
+
+ (i)   no definition text (`function name(`, `struct Name`, `@ccall lib.f(`) inside a string token;
+ (ii)  every top-level triple-quoted block is a docstring: the next token starts a definition;
+ (iii) block openers and `end` keywords nest and balance (with `end` inside `[...]` read as an index and `for` / `if` inside brackets
+       read as generator clauses), brackets balance, every string is closed;
+ (iv)  the public names the reference's users call are defined at top level of `module DDPAmd` (iLQG keeps the signature of
+       /root/reference/src/iLQG.jl:143-163).
+"""
+import glob
+import os
+import re
+
+import pytest
+from pygments.lexers import JuliaLexer
+from pygments.token import Comment, Error, Keyword, Name, Punctuation, String, Text, Whitespace
+
+from conftest import ROOT
+
+JL_FILES = sorted(glob.glob(os.path.join(ROOT, "differentialdynamicprogramming.jl_amd", "julia", "*.jl"))
+                  + glob.glob(os.path.join(ROOT, "julia", "*.jl")) + glob.glob(os.path.join(ROOT, "bench", "*.jl")))
+
+OPENERS = {"function", "macro", "begin", "let", "do", "quote", "try", "struct", "module", "baremodule", "while", "for", "if"}
+SOFT = {"for", "if", "while"}            # generator / filter clauses when met deeper in brackets than the enclosing block
+DEF_IN_STRING = re.compile(r"^\s*(?:function\s+[\w.!]+\s*\(|(?:mutable\s+)?struct\s+\w+\s*$|module\s+\w+\s*$)|@ccall\s+\w+\.\w+\(", re.M)
+
+
+def tokens(src):
+    """(type, text, line) of every token"""
+    line = 1
+    for t, v in JuliaLexer().get_tokens(src):
+        yield t, v, line
+        line += v.count("\n")
+
+
+def lint(src):
+    """list of 'line N: problem' — empty for a well-formed file"""
+    problems = []
+    toks = [(t, v, ln) for t, v, ln in tokens(src)]
+
+    # strings: pygments emits the delimiter as its own String token; an unterminated literal runs to the end of the file
+    in_str = None            # (delimiter, line)
+    string_body = []
+    code = []                # the tokens outside strings, with triple-quoted blocks collapsed to one ('DOC', text, line) entry
+    depth_interp = 0         # inside $( ... ) of a string the lexer returns to code tokens; we do not lint those
+    for t, v, ln in toks:
+        if t in String and t is not String.Symbol and t is not String.Char and t not in String.Interpol:
+            if in_str is None and v in ('"""', '"', "`", "```"):
+                in_str = (v, ln); string_body = []
+                continue
+            if in_str is not None and v == in_str[0] and depth_interp == 0:
+                body = "".join(string_body)
+                m = DEF_IN_STRING.search(body)
+                if m:
+                    problems.append(f"line {in_str[1] + body[:m.start()].count(chr(10))}: definition text inside a string literal: "
+                                    f"{m.group(0).strip()!r}")
+                code.append(("DOC" if in_str[0] == '"""' else "STR", body, in_str[1]))
+                in_str = None
+                continue
+            if in_str is not None:
+                string_body.append(v)
+                continue
+            code.append((t, v, ln))        # a string-like token outside a literal (prefix such as r"..." is emitted whole)
+            continue
+        if in_str is not None:
+            # code inside $( ... ) interpolation
+            if t in String.Interpol:
+                continue
+            if v == "(":
+                depth_interp += 1
+            elif v == ")":
+                depth_interp -= 1
+            string_body.append(v)
+            continue
+        if t in Error:
+            problems.append(f"line {ln}: lexer error at {v!r}")
+        code.append((t, v, ln))
+    if in_str is not None:
+        problems.append(f"line {in_str[1]}: string opened with {in_str[0]} is never closed")
+
+    # structure
+    stack = []               # ('block', keyword, bracket depth, line) and ('br', char, line)
+    closing = {")": "(", "]": "[", "}": "{"}
+
+    def bdepth():
+        return sum(1 for e in stack if e[0] == "br")
+
+    sig = [(t, v, ln) for t, v, ln in code if not (t in Comment or t in Whitespace or (t in Text and not v.strip()))]
+    prev_kw = None
+    for i, (t, v, ln) in enumerate(sig):
+        if t == "DOC":
+            if not any(e[0] == "block" and e[1] not in ("module", "baremodule") for e in stack) and bdepth() == 0:
+                # top level (possibly inside `module`): must document something
+                nxt = sig[i + 1] if i + 1 < len(sig) else (None, "", ln)
+                ok = (nxt[0] in Keyword and nxt[1] in ("function", "struct", "mutable", "macro", "module", "const", "abstract", "primitive")) \
+                    or nxt[0] in Name or nxt[0] is Name.Decorator or nxt[0] in Keyword.Type
+                prv = sig[i - 1] if i > 0 else (None, "", 0)
+                is_value = prv[1] in ("=", "(", ",", "return") or prv[0] is Name.Decorator     # a triple-quoted VALUE, not a docstring
+                if not ok and not is_value:
+                    problems.append(f"line {ln}: top-level triple-quoted block is not followed by a definition (next: {nxt[1]!r})")
+                if nxt[0] == "DOC":
+                    problems.append(f"line {ln}: two triple-quoted blocks in a row")
+            continue
+        if t == "STR":
+            continue
+        if t in Punctuation or v in "()[]{}":
+            if v in "([{" and len(v) == 1:
+                stack.append(("br", v, ln))
+            elif v in ")]}" and len(v) == 1:
+                if not stack or stack[-1][0] != "br" or stack[-1][1] != closing[v]:
+                    problems.append(f"line {ln}: {v!r} closes {stack[-1][1:] if stack else 'nothing'}")
+                    if stack and stack[-1][0] == "br":
+                        stack.pop()
+                else:
+                    stack.pop()
+            continue
+        if t in Keyword and t not in Keyword.Type:
+            if v == "end":
+                if stack and stack[-1][0] == "br":
+                    if stack[-1][1] != "[":
+                        problems.append(f"line {ln}: `end` inside {stack[-1][1]!r} opened on line {stack[-1][2]}")
+                    continue                                   # a[end]
+                if not stack:
+                    problems.append(f"line {ln}: `end` without an opener")
+                else:
+                    stack.pop()
+            elif v in OPENERS:
+                if v == "struct" and prev_kw == ("mutable", i - 1):
+                    pass
+                enclosing = 0
+                for e in reversed(stack):
+                    if e[0] == "block":
+                        enclosing = e[2]; break
+                d = bdepth()
+                after_semicolon = i > 0 and sig[i - 1][1] == ";"                # (a = 1; for c in cs; ...; end; a): a statement
+                if v in SOFT and d > enclosing and not after_semicolon:
+                    pass                                       # [x for x in xs if p(x)]
+                else:
+                    stack.append(("block", v, d, ln))
+            elif v in ("abstract", "primitive"):
+                # `abstract type X end`
+                stack.append(("block", v, bdepth(), ln))
+            prev_kw = (v, i)
+    for e in stack:
+        problems.append(f"line {e[-1]}: {e[1]!r} is never closed")
+    return problems
+
+
+def top_level_functions(src):
+    """names defined by `function name(` directly inside the outermost module (or at file level)"""
+    names, depth = set(), 0
+    sig = [(t, v) for t, v, _ in tokens(src) if not (t in Comment or t in Whitespace or (t in Text and not v.strip()) or t in String)]
+    br = 0
+    for i, (t, v) in enumerate(sig):
+        if v in ("(", "[", "{"):
+            br += 1
+        elif v in (")", "]", "}"):
+            br -= 1
+        elif t in Keyword and t not in Keyword.Type:
+            if v == "end" and br == 0:
+                depth -= 1
+            elif v in OPENERS and not (v in SOFT and br > 0):
+                if v == "function" and depth <= 1 and i + 1 < len(sig):
+                    j = i + 1
+                    name = sig[j][1]
+                    while j + 2 < len(sig) and sig[j + 1][1] == ".":       # Base.show
+                        name = sig[j + 2][1]; j += 2
+                    names.add(name)
+                depth += 1
+    return names
+
+
+def test_the_linter_sees_the_round4_breakage():
+    """the shape of commit a91704b: a function pasted between a docstring's text and its closing quotes"""
+    broken = '''module M
+"""
+    install!(ref)
+
+text
+"""
+    queue(p) -> x
+
+more text with `backticks`...
+"""
+function queue(p)
+    @ccall lib.f(p::Ptr{Cvoid})::Cint
+end
+
+"""
+function install!(ref)
+    ref
+end
+end
+'''
+    probs = lint(broken)
+    assert probs, "a function inside a string literal went unnoticed"
+    assert any("inside a string literal" in p for p in probs), probs
+    good = '''module M
+"""
+    queue(p) -> x
+"""
+function queue(p)
+    y = [i for i in p if i > p[end]]
+    @ccall lib.f(p::Ptr{Cvoid})::Cint
+end
+mutable struct A; x::Int; end
+const S = """
+value, not a docstring
+"""
+f(x) = x[end] + 1
+end
+'''
+    assert lint(good) == []
+    assert lint("function f(x)\n  if x\n  end\n") != []                      # missing end
+    assert lint('x = "abc\n') != []                                          # unterminated string
+    assert lint('"""\ndoc\n"""\n\n1 + 1\n') != []                            # docstring documenting nothing
+    assert lint("f(x) = (x[1]\n") != []                                      # unbalanced bracket
+
+
+@pytest.mark.parametrize("path", JL_FILES, ids=[os.path.relpath(p, ROOT) for p in JL_FILES])
+def test_julia_file_is_structurally_sound(path):
+    probs = lint(open(path, encoding="utf-8").read())
+    assert probs == [], "\n".join(probs)
+
+
+def test_all_four_julia_files_are_linted():
+    rel = {os.path.relpath(p, ROOT) for p in JL_FILES}
+    assert {"differentialdynamicprogramming.jl_amd/julia/DDPAmd.jl", "differentialdynamicprogramming.jl_amd/julia/test_result_lifetime.jl",
+            "julia/make_reference_fixtures.jl", "bench/reference_julia.jl"} <= rel
+
+
+def test_public_entry_points_are_real_definitions():
+    """`iLQG(f,costfun,df,x0,u0; lims...)` (iLQG.jl:143-163) and the batched / queue / MPC / install! entries must be FUNCTIONS of the module,
+    not text: the round-4 file 'defined' iLQG_queue and iLQG_mpc inside a string."""
+    src = open(os.path.join(ROOT, "differentialdynamicprogramming.jl_amd", "julia", "DDPAmd.jl"), encoding="utf-8").read()
+    names = top_level_functions(src)
+    for want in ("iLQG", "iLQG_queue", "iLQG_mpc", "install!", "back_pass", "forward_pass", "boxQP"):
+        assert want in names, f"{want} is not defined at top level of DDPAmd.jl (found: {sorted(names)})"
+    # the keyword names of the reference's signature that the registered-problem iLQG must keep
+    m = re.search(r"^function iLQG\((.*?)\)\n", src, flags=re.S | re.M)
+    assert m, "function iLQG(...) not found"
+    for kw in ("lims", "α", "tol_fun", "tol_grad", "max_iter", "λ", "dλ", "λfactor", "λmax", "λmin", "regType", "reduce_ratio_min", "diff_fun"):
+        assert re.search(rf"\b{kw}\s*=", m.group(1)), f"iLQG lost its keyword {kw}"
