@@ -19,7 +19,7 @@ u8p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
 
 EXPORTS = [
-    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_reload_env", "ddp_last_kernel", "ddp_stream",
+    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_reload_env", "ddp_last_kernel", "ddp_sh_timeouts", "ddp_stream",
     "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_memset", "ddp_host_alloc", "ddp_host_free", "ddp_host_trim",
     "ddp_event_create", "ddp_event_destroy", "ddp_event_record", "ddp_event_elapsed_ms",
     "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
@@ -202,6 +202,13 @@ class Handle:
     def last_kernel(self, which=0):
         """kernel of the last back_pass (0) / forward_pass (1) dispatch (ddp_last_kernel)"""
         return lib().ddp_last_kernel(self._h, int(which)).decode()
+
+    def sh_timeouts(self):
+        """tiles of the shared-operand backward pass that gave their trajectories to the per-trajectory kernels after a timed-out wait"""
+        r = lib().ddp_sh_timeouts(self._h)
+        if r < 0:
+            check(r)
+        return r
 
     def sync(self):
         check(lib().ddp_sync(self._h))

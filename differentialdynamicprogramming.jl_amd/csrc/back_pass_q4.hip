@@ -897,8 +897,14 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     a.sink = (double *)h->sink;
     const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
+    // DDP_Q4_EXP selects "removal experiment" kernels (no result stores / no operand loads: wrong results by design, for profiles/q4_exp.sh);
+    // they exist only in a profiling build (-DDDP_PROFILE_BUILD, profiles/build_variant.sh) — the production library ignores the switch
+#ifdef DDP_PROFILE_BUILD
     const char *ex = ddp_env(h, ENV_Q4_EXP);
     const int exp = ex ? atoi(ex) : 0;
+#else
+    const int exp = 0;
+#endif
     const char *sg = ddp_env(h, ENV_Q4_SINGLE);                  // 1: force the one-step-at-a-time kernel (tests)
     const bool aligned16 = ((((uintptr_t)fx | (uintptr_t)fu | (uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu |
                               (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)(d->has_lims ? u : cu)) & 15) == 0);
@@ -919,6 +925,7 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
 #undef Q4L
     } else if (chunked) {
         const ddp_kl_cost_terms nokl = {};
+#ifdef DDP_PROFILE_BUILD
         if (c3exp) {
             if (exp == 11) hipLaunchKernelGGL((back_pass_q4c_kernel<true, true, false, 8, 1>), grid, block, 0, h->stream, a, nokl);
             else if (exp == 12) hipLaunchKernelGGL((back_pass_q4c_kernel<true, true, false, 8, 2>), grid, block, 0, h->stream, a, nokl);
@@ -926,15 +933,20 @@ int ddp_launch_back_pass_q4(ddp_handle h, const ddp_bp_desc *d, const double *cx
             DDP_HIP(hipGetLastError());
             return 0;
         }
+#endif
 #define Q4C_(L_, R_) hipLaunchKernelGGL((back_pass_q4c_kernel<L_, R_, false, 8>), grid, block, 0, h->stream, a, nokl)
         if (d->has_lims && reg2) Q4C_(true, true); else if (d->has_lims) Q4C_(true, false); else if (reg2) Q4C_(false, true); else Q4C_(false, false);
 #undef Q4C_
     } else if (paired) {
         if (d->has_lims && reg2) {
+#ifdef DDP_PROFILE_BUILD
             switch (exp) {
             case 1: Q4P(true, true, 1); break; case 2: Q4P(true, true, 2); break; case 3: Q4P(true, true, 3); break;
             case 4: Q4P(true, true, 4); break; case 7: Q4P(true, true, 7); break; default: Q4P(true, true, 0);
             }
+#else
+            Q4P(true, true, 0);
+#endif
         } else if (d->has_lims) Q4P(true, false, 0);
         else if (reg2) Q4P(false, true, 0);
         else Q4P(false, false, 0);
@@ -982,12 +994,15 @@ int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double
             a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
             a.eta = kl->eta; a.Quui = Quui; a.sink = (double *)h->sink;
             const dim3 grid((unsigned)((d->B + 3) / 4)), block(DDP_WAVE);
+#ifdef DDP_PROFILE_BUILD
             const char *ex = ddp_env(h, ENV_Q4_EXP);            // removal experiments (profiles/q4_exp.sh): 1 no result stores, 2 no operand loads after the first two chunks
             const int exp = ex ? atoi(ex) : 0;
             if (d->has_lims && exp == 1) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4, 1>), grid, block, 0, h->stream, a, *kl);
             else if (d->has_lims && exp == 2) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4, 2>), grid, block, 0, h->stream, a, *kl);
             else if (d->has_lims && exp == 3) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4, 3>), grid, block, 0, h->stream, a, *kl);
-            else if (d->has_lims) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4>), grid, block, 0, h->stream, a, *kl);
+            else
+#endif
+            if (d->has_lims) hipLaunchKernelGGL((back_pass_q4c_kernel<true, false, true, 4>), grid, block, 0, h->stream, a, *kl);
             else hipLaunchKernelGGL((back_pass_q4c_kernel<false, false, true, 4>), grid, block, 0, h->stream, a, *kl);
             DDP_HIP(hipGetLastError());
             return 0;

@@ -82,7 +82,7 @@ static_assert(CF_UDONE + NAFF + NWR <= 32 && SH_THREADS <= 1024, "flag words, wo
 
 struct ShCtl {                                      // device-resident control block of a launch
     int ticket, G, W, nfb;
-    int error, pad0, pad1, pad2;
+    int error, errors_total, pad1, pad2;              // error: timed-out tiles of this launch; errors_total: since the block was allocated
     int progress[SH_GMAX * 16];                     // chunks published by group g (| SH_FIN) at [16 g]: one 64-byte line each
     int gdiverge[SH_GMAX];
     int gcount[SH_GMAX], gstart[SH_GMAX];
@@ -90,7 +90,7 @@ struct ShCtl {                                      // device-resident control b
 };
 
 struct ShArgs {
-    int N, B, ncu, regType;
+    int N, B, ncu, regType, wmax, test_abort;                   // wmax: the items[] capacity = the work-groups behind the SH_GMAX producers of the grid
     const double *cx, *cu, *cxx, *cxu, *cuu, *fx, *fu, *lambda;
     const int32_t *active;
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
         }
         // Tile size: one work-group per CU is resident (LDS), the G producers hold a CU each while the chain runs.  R rounds of
         // (ncu - G) tiles of equal size, no tile more than TMAX trajectories: every CU is busy until the end, nobody queues behind a
-        // full machine for a lone last tile.  (The host sized the grid for the smallest tile this can choose.)
+        // full machine for a lone last tile.  (The host sizes items[] and the grid for the most tiles ANY grouping of the batch can
+        // produce — ddp_sh_max_tiles — and the count is clamped to that capacity here.)
         if (tid == 0) {
             int T = 4, W = 0;
             if (G > 0) {
@@ -207,7 +208,9 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
                 const int R = (start + slots * TMAX - 1) / (slots * TMAX);
                 T = (start + R * slots - 1) / (R * slots);
                 T = T < 4 ? 4 : T;
-                for (; T < TMAX; ++T) { int w = 0; for (int g = 0; g < G; ++g) w += (gcn[g] + T - 1) / T; if (w <= R * slots) break; }
+                // never more tiles than the host sized items[] and the grid for (at T = TMAX the count is <= B / TMAX + G <= wmax)
+                const int cap = R * slots < a.wmax ? R * slots : a.wmax;
+                for (; T < TMAX; ++T) { int w = 0; for (int g = 0; g < G; ++g) w += (gcn[g] + T - 1) / T; if (w <= cap) break; }
             }
             for (int g = 0; g < G; ++g) { gtile[g] = W; W += (gcn[g] + T - 1) / T; }
             gtile[G] = W;
@@ -554,7 +557,10 @@ __device__ __forceinline__ void sh_publisher(const ShArgs &a, double *sm, const 
 // chunk kinds of the consumer ring
 enum { KIND_NORMAL = 0, KIND_ZERO = 1 << 20 /* no data: everything is zero */ };
 
-__device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gidx, const int nusers)
+// A wait that times out (a protocol error, or a producer that was starved of its CU for seconds) does not end in silently wrong
+// results: the tile hands ITS trajectories to the per-trajectory kernels that the dispatcher launches behind this one (fb_active, the
+// mask those kernels run under — they rewrite every output of a flagged trajectory), and ctl->error counts the event.
+__device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gidx, const int nusers, const int4 item)
 {
     const int lane = threadIdx.x % DDP_WAVE;
     int *flags = (int *)(sm + C_FLAGS);
@@ -563,13 +569,20 @@ __device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gi
     const int *prog = &a.ctl->progress[16 * gidx];
     int pubd = 0;                                               // progress word as last seen
     const unsigned long long t0 = wall_clock64();
+    auto give_up = [&]() {
+        for (int t = lane; t < item.z; t += DDP_WAVE) a.fb_active[a.perm[item.y + t]] = 1;
+        if (lane == 0) { atomicAdd(&a.ctl->error, 1); atomicAdd(&a.ctl->errors_total, 1); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // direct-to-LDS loads of earlier chunks may still be in flight
+        lds_store_flag(&flags[CF_SREADY], SH_ABORT);
+    };
     for (int q = 0; q < NCHK; ++q) {
+        if (__builtin_expect(a.test_abort && q == 1, 0)) { give_up(); return; }       // DDP_TEST_SH_ABORT: every tile gives up at its second chunk
         // (1) the chunk must have been published (or the group has ended before it)
         while ((pubd & SH_CNT) <= q && !(pubd & SH_FIN)) {
             pubd = __builtin_amdgcn_readfirstlane(load4_sc1(prog));          // drains this wave's loads as well
             lds_store_flag(&flags[CF_SREADY], q);                             // chunks < q have landed
             if ((pubd & SH_CNT) <= q && !(pubd & SH_FIN)) {
-                if (timed_out(t0)) { if (lane == 0) a.ctl->error = 1; lds_store_flag(&flags[CF_SREADY], SH_ABORT); return; }
+                if (timed_out(t0)) { give_up(); return; }
                 __builtin_amdgcn_s_sleep(20);
             }
         }
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(SH_THREADS) void sh_back_kernel(ShArgs a)
     if (it >= W) return;
     const int4 item = a.items[it];
     const int naff = (item.z + 3) / 4;
-    if (wave == 0) sh_dma(a, sm, item.x, NAFF + NWR);
+    if (wave == 0) sh_dma(a, sm, item.x, NAFF + NWR, item);
     else if (wave <= NAFF) {
         if (wave - 1 < naff) sh_affine(a, sm, item.x, wave - 1, item);
         else { int *cf = (int *)(sm + C_FLAGS); if (threadIdx.x % DDP_WAVE == 0) lds_store_flag(&cf[CF_UDONE + wave - 1], 1 << 28); }
@@ -799,6 +812,24 @@ __global__ __launch_bounds__(SH_THREADS) void sh_back_kernel(ShArgs a)
 }
 
 }   // namespace
+
+// The most consumer tiles sh_group_kernel can make of a batch of B trajectories on ncu compute units, over every number of groups
+// G = 1 .. SH_GMAX and every grouped count start <= B: it chooses R = ceil(start / (slots TMAX)) rounds of slots = max(ncu - G, 8)
+// tiles and raises the tile size until the tiles fit R * slots (or the tile size reaches TMAX, where the count is <= start / TMAX + G
+// <= R * slots + G).  R * slots + G is largest at start = B; G is scanned.  (The round-4 bound assumed G = 1, start = B: with 16 groups
+// of 500 on 256 CUs the device made 480 tiles for a 272-entry items[] and a 282-work-group grid.)
+extern "C" int ddp_sh_max_tiles(int B, int ncu)
+{
+    int best = 0;
+    for (int G = 1; G <= SH_GMAX; ++G) {
+        const int slots = ncu - G > 8 ? ncu - G : 8;
+        const int R = (B + slots * TMAX - 1) / (slots * TMAX);
+        const int w = R * slots + G;
+        best = w > best ? w : best;
+    }
+    const int floor_ = (B + TMAX - 1) / TMAX + SH_GMAX;          // what the device's clamp needs to terminate at T = TMAX
+    return best > floor_ ? best : floor_;
+}
 
 // Shared-LTI backward pass.  Returns 1 when the shape is not handled here, 0 when launched (the caller then runs the per-trajectory
 // kernels with *fb_active as their activity mask), < 0 on error.
@@ -813,28 +844,26 @@ int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx
     if ((((uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)cxx | (uintptr_t)cuu) & 15) != 0) return 1;
     const int B = d->B, N = d->N;
     if (!h->ncu) { hipDeviceProp_t pr; DDP_HIP(hipGetDeviceProperties(&pr, h->device)); h->ncu = pr.multiProcessorCount; }
-    // the tile size is chosen on the device (it depends on the number of groups); this is the smallest it can choose: the most tiles
-    int Tlo;
-    {
-        const int slots = h->ncu - 1 > 8 ? h->ncu - 1 : 8;
-        const int R = (B + slots * TMAX - 1) / (slots * TMAX);
-        Tlo = (B + R * slots - 1) / (R * slots);
-        Tlo = Tlo < 4 ? 4 : Tlo;
-    }
-    const int Wmax = (B + Tlo - 1) / Tlo + SH_GMAX;
+    const int Wmax = ddp_sh_max_tiles(B, h->ncu);
     const int NCHK = (N - 1) / CH + 1;
     // scratch of the handle: control block | items | perm | fb_active | record streams
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_items = al(sizeof(ShCtl)), o_perm = o_items + al(sizeof(int4) * (size_t)Wmax), o_fb = o_perm + al(sizeof(int) * (size_t)B),
                  o_rec = o_fb + al(sizeof(int32_t) * (size_t)B), total = o_rec + al(sizeof(double) * (size_t)SH_GMAX * NCHK * GCHUNK);
     if (h->sh_bytes < total) {
-        if (h->sh) { DDP_HIP(hipStreamSynchronize(h->stream)); DDP_HIP(hipFree(h->sh)); h->sh = nullptr; h->sh_bytes = 0; }
+        if (h->sh) {
+            DDP_HIP(hipStreamSynchronize(h->stream));
+            ShCtl c; DDP_HIP(hipMemcpy(&c, h->sh, sizeof c, hipMemcpyDeviceToHost)); h->sh_timeouts += c.errors_total;
+            DDP_HIP(hipFree(h->sh)); h->sh = nullptr; h->sh_bytes = 0;
+        }
         DDP_HIP(hipMalloc(&h->sh, total));
         h->sh_bytes = total;
+        DDP_HIP(hipMemsetAsync(h->sh, 0, sizeof(ShCtl), h->stream));
     }
     char *base = (char *)h->sh;
     ShArgs a;
-    a.N = N; a.B = B; a.ncu = h->ncu; a.regType = d->regType;
+    a.N = N; a.B = B; a.ncu = h->ncu; a.regType = d->regType; a.wmax = Wmax;
+    a.test_abort = ddp_env(h, ENV_TEST_SH_ABORT) ? 1 : 0;
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     a.ctl = (ShCtl *)base; a.items = (int4 *)(base + o_items); a.perm = (int *)(base + o_perm); a.fb_active = (int32_t *)(base + o_fb);
@@ -852,4 +881,14 @@ int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx
     DDP_HIP(hipGetLastError());
     *fb_active = a.fb_active;
     return 0;
+}
+
+extern "C" int ddp_sh_timeouts(ddp_handle h)
+{
+    DDP_DEVICE(h);
+    if (!h->sh) return h->sh_timeouts;
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    ShCtl c;
+    DDP_HIP(hipMemcpy(&c, h->sh, sizeof c, hipMemcpyDeviceToHost));
+    return h->sh_timeouts + c.errors_total;
 }

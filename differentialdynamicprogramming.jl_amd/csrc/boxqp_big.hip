@@ -257,11 +257,8 @@ int ddp_launch_boxqp_big(ddp_handle h, int m, int count, const double *H, const 
     QPBig a;
     a.m = m; a.H = H; a.g = g; a.lo = lower; a.up = upper; a.x0 = x0; a.o = o; a.x = x; a.Hfree = Hfree; a.result = result; a.free_out = free_out;
     const size_t shmem = (size_t)(10 * m + 8) * sizeof(double) + (size_t)(2 * m + 4) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DDP_HIP(hipFuncSetAttribute((const void *)boxqp_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    // per device and cheap: set on every launch (a process-wide "done" flag left the second GPU of a process at the 64 KB default)
+    DDP_HIP(hipFuncSetAttribute((const void *)boxqp_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(boxqp_big_kernel, dim3(count), dim3(QT), shmem, h->stream, a);
     DDP_HIP(hipGetLastError());
     return 0;

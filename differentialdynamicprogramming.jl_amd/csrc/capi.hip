@@ -24,7 +24,7 @@ extern "C" {
 const char *ddp_last_error(void) { return g_err; }
 const char *ddp_version(void) { return "ddp_amd 0.3.0 (gfx950, fp64)"; }
 
-static const char *const ddp_env_names[ENV_COUNT] = {"DDP_BACKPASS", "DDP_SH_MIN_B", "DDP_MX2", "DDP_DPPW", "DDP_DPPW_EXP", "DDP_MX_LDS", "DDP_Q4_EXP", "DDP_Q4_SINGLE", "DDP_Q4_LDS", "DDP_GPS_Q4", "DDP_GPS_Q4L", "DDP_DF_DENSE", "DDP_FORWARD", "DDP_FORWARD64", "DDP_FORWARD_FAST", "DDP_FORWARD_FUSE", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND", "DDP_FORWARD_PIPE", "DDP_ILQG_COMPACT", "DDP_ILQG_LSGROUPS", "DDP_TEST_COMPACT_ALLOC_FAIL", "DDP_GPS_LANE", "DDP_FCOV_Q4", "DDP_FCOV_Q4L", "DDP_KL_LDS"};
+static const char *const ddp_env_names[ENV_COUNT] = {"DDP_BACKPASS", "DDP_SH_MIN_B", "DDP_MX2", "DDP_DPPW", "DDP_DPPW_EXP", "DDP_MX_LDS", "DDP_Q4_EXP", "DDP_Q4_SINGLE", "DDP_Q4_LDS", "DDP_GPS_Q4", "DDP_GPS_Q4L", "DDP_DF_DENSE", "DDP_FORWARD", "DDP_FORWARD64", "DDP_FORWARD_FAST", "DDP_FORWARD_FUSE", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND", "DDP_FORWARD_PIPE", "DDP_ILQG_COMPACT", "DDP_ILQG_LSGROUPS", "DDP_TEST_COMPACT_ALLOC_FAIL", "DDP_GPS_LANE", "DDP_FCOV_Q4", "DDP_FCOV_Q4L", "DDP_KL_LDS", "DDP_TEST_SH_ABORT"};
 
 int ddp_reload_env(ddp_handle h)
 {
@@ -34,6 +34,10 @@ int ddp_reload_env(ddp_handle h)
         h->envset[i] = v != nullptr;
         if (v) { strncpy(h->envv[i], v, sizeof h->envv[i] - 1); h->envv[i][sizeof h->envv[i] - 1] = 0; }
     }
+    // the cost_diag verdicts are keyed by device addresses, which allocators recycle: a reload forgets them (so does ddp_free of a
+    // cached address) — the next call with cost_diag = 1 looks at Q, R again
+    for (auto &e : h->diag_cache) { e.Q = e.R = nullptr; e.n = e.m = e.ok = 0; }
+    h->diag_next = 0;
     return 0;
 }
 
@@ -63,7 +67,7 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
     h->device = device;
     h->scratch = nullptr;
     h->scratch_bytes = 0;
-    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr; h->sh = nullptr; h->sh_bytes = 0; h->sh_attr = false; h->ncu = 0; h->sched_aux = nullptr; h->diag_next = 0; h->diag_skip = 0; for (auto &e : h->diag_cache) { e.Q = e.R = nullptr; e.n = e.m = e.ok = 0; } h->last_kernel[0] = h->last_kernel[1] = nullptr; ddp_reload_env(h);
+    h->pad = nullptr; h->pad_bytes = 0; h->sink = nullptr; h->sh = nullptr; h->sh_bytes = 0; h->sh_timeouts = 0; h->sh_attr = false; h->ncu = 0; h->sched_aux = nullptr; h->diag_next = 0; h->diag_skip = 0; for (auto &e : h->diag_cache) { e.Q = e.R = nullptr; e.n = e.m = e.ok = 0; } h->last_kernel[0] = h->last_kernel[1] = nullptr; ddp_reload_env(h);
     h->h_pinned = nullptr;
     h->timing = nullptr; h->timing_cap = 0; h->tev_ok = false;
     h->owns_stream = !adopt;
@@ -121,7 +125,18 @@ int ddp_free(ddp_handle h, void *dptr)
 {
     DDP_DEVICE(h);
     DDP_CHECK(h, "ddp_free: null handle");
-    if (dptr) { DDP_HIP(hipStreamSynchronize(h->stream)); DDP_HIP(hipFree(dptr)); }
+    if (dptr) {
+        DDP_HIP(hipStreamSynchronize(h->stream));
+        // a cost_diag verdict about a Q or R inside this allocation dies with it (the next allocation may get the address back)
+        hipDeviceptr_t base = nullptr; size_t sz = 0;
+        if (hipMemGetAddressRange(&base, &sz, (hipDeviceptr_t)dptr) != hipSuccess) { (void)hipGetLastError(); base = (hipDeviceptr_t)dptr; sz = 1; }
+        const char *lo = (const char *)base, *hi = lo + sz;
+        for (auto &e : h->diag_cache) {
+            const char *q = (const char *)e.Q, *r = (const char *)e.R;
+            if ((q && q >= lo && q < hi) || (r && r >= lo && r < hi)) { e.Q = e.R = nullptr; e.n = e.m = e.ok = 0; }
+        }
+        DDP_HIP(hipFree(dptr));
+    }
     return 0;
 }
 // ---- page-locked host memory for results (ddp_amd.h).  Process-wide cache of freed blocks, keyed by their (2 MB-rounded) size: a host

@@ -12,7 +12,7 @@
 // The DDP_* switches of the dispatchers (kernel choice for A/B timing and for the tests that force every code path) are read from the
 // environment ONCE per handle (ddp_create) and again on ddp_reload_env(): no launch calls getenv, and a setenv() in another thread
 // cannot race with a launch.  ddp_env() returns the cached value or nullptr.
-enum ddp_env_id { ENV_BACKPASS, ENV_SH_MIN_B, ENV_MX2, ENV_DPPW, ENV_DPPW_EXP, ENV_MX_LDS, ENV_Q4_EXP, ENV_Q4_SINGLE, ENV_Q4_LDS, ENV_GPS_Q4, ENV_GPS_Q4L, ENV_DF_DENSE, ENV_FORWARD, ENV_FORWARD64, ENV_FORWARD_FAST, ENV_FORWARD_FUSE, ENV_FORWARD_LANE, ENV_FORWARD_PEND, ENV_FORWARD_PIPE, ENV_ILQG_COMPACT, ENV_ILQG_LSGROUPS, ENV_TEST_COMPACT_ALLOC_FAIL, ENV_GPS_LANE, ENV_FCOV_Q4, ENV_FCOV_Q4L, ENV_KL_LDS, ENV_COUNT };
+enum ddp_env_id { ENV_BACKPASS, ENV_SH_MIN_B, ENV_MX2, ENV_DPPW, ENV_DPPW_EXP, ENV_MX_LDS, ENV_Q4_EXP, ENV_Q4_SINGLE, ENV_Q4_LDS, ENV_GPS_Q4, ENV_GPS_Q4L, ENV_DF_DENSE, ENV_FORWARD, ENV_FORWARD64, ENV_FORWARD_FAST, ENV_FORWARD_FUSE, ENV_FORWARD_LANE, ENV_FORWARD_PEND, ENV_FORWARD_PIPE, ENV_ILQG_COMPACT, ENV_ILQG_LSGROUPS, ENV_TEST_COMPACT_ALLOC_FAIL, ENV_GPS_LANE, ENV_FCOV_Q4, ENV_FCOV_Q4L, ENV_KL_LDS, ENV_TEST_SH_ABORT, ENV_COUNT };
 
 struct ddp_handle_s {
     int          device;
@@ -26,6 +26,7 @@ struct ddp_handle_s {
     size_t       pad_bytes;
     void        *sh;              // back_pass_sh.hip: control block, work items, record streams of the shared-LTI backward pass
     size_t       sh_bytes;
+    int          sh_timeouts;     // timed-out tiles counted by control blocks that have been freed (ddp_sh_timeouts)
     bool         sh_attr;         // its dynamic-LDS attribute has been set on this device
     int          ncu;             // compute units of the device (0: not asked yet)
     struct { const void *Q, *R; int n, m, ok; } diag_cache[8];      // verdicts of ddp_check_cost_diag (forward_pass.hip)
@@ -114,6 +115,7 @@ int ddp_launch_back_pass_mx2(ddp_handle h, const ddp_bp_desc *d, const double *c
 
 // shared time-invariant operands (n=10, m=2, no limits): the matrix recursion once per distinct λ, an affine chain per trajectory
 // (back_pass_sh.hip); 1 = not applicable; 0 = launched, the trajectories it left out are flagged in *fb_active
+extern "C" int ddp_sh_max_tiles(int B, int ncu);      // capacity of its work-item list: the most consumer tiles any grouping of B trajectories can make
 int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
                             const double *fu, const double *lambda, const int32_t *active, double *K,

@@ -277,8 +277,9 @@ int ddp_check_cost_diag(ddp_handle h, const ddp_problem *p)
     int ok = 1;
     for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) if (i != j && q[i + (size_t)n * j] != 0.0) ok = 0;
     for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) if (i != j && r[i + (size_t)m * j] != 0.0) ok = 0;
-    auto &e = h->diag_cache[h->diag_next++ % 8];
-    e.Q = p->Q; e.R = p->R; e.n = n; e.m = m; e.ok = ok;
+    // only a PASS is remembered (a refused pair is looked at again on the next call: the caller may have repaired Q in place); the
+    // entry dies with ddp_free of the allocation it points into and with ddp_reload_env
+    if (ok) { auto &e = h->diag_cache[h->diag_next++ % 8]; e.Q = p->Q; e.R = p->R; e.n = n; e.m = m; e.ok = 1; }
     DDP_CHECK(ok, "forward_pass: ddp_problem.cost_diag = 1 but Q or R has a non-zero off-diagonal entry (the fused rollout cost would drop it); set cost_diag = 0");
     return 0;
 }

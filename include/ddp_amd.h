@@ -45,6 +45,11 @@ int  ddp_reload_env(ddp_handle h);
 /* name of the kernel the last back_pass (which = 0) / forward_pass (which = 1) dispatch of this handle launched ("" before the first
  * one): a debug query — the tests assert through it that the timed path is the one they checked                                    */
 const char *ddp_last_kernel(ddp_handle h, int which);
+/* The shared-operand backward pass (one fx, fu, cxx, cxu, cuu for the batch) hands work between work-groups of one launch; every such
+ * wait is time-bounded (4 s).  A tile whose wait ran out gives its trajectories to the per-trajectory kernels launched behind it — the
+ * results stay correct — and is counted: this returns the number of such tiles since ddp_create (synchronises the stream; 0 in a
+ * healthy run, < 0 on error).  A debug query like ddp_last_kernel.                                                                  */
+int  ddp_sh_timeouts(ddp_handle h);
 void *ddp_stream(ddp_handle h);                 /* the hipStream_t of the handle */
 /* device memory helpers for hosts without their own allocator (the Julia wrapper, tests) */
 int  ddp_malloc(ddp_handle h, size_t bytes, void **dptr);
@@ -155,8 +160,8 @@ typedef struct {
      * kernels of the n = 10 / m = 2 and pendcart shapes then evaluate the cost themselves from the values they hold instead of a
      * second kernel re-reading xnew, unew (only the diagonals are read).  0: general Q, R.  The declaration IS verified: the host-pointer
      * entry points test the host copies; the _dev entry points look at Q, R once per (Q, R) address pair and handle (one small
-     * device-to-host copy, the verdict is cached — a caller that rewrites Q or R in place must keep the flag honest; ddp_reload_env
-     * does not clear the cache, a new handle does).  A full Q or R with cost_diag = 1 is refused (< 0).  Any value but 0 / 1 is refused,
+     * device-to-host copy; a PASS is cached — a caller that rewrites Q or R in place must keep the flag honest; ddp_free of
+     * the allocation holding Q or R, ddp_reload_env and a new handle forget it; a refusal is never cached).  A full Q or R with cost_diag = 1 is refused (< 0).  Any value but 0 / 1 is refused,
      * so a struct that was not zero-initialised — or a caller built against the 0.1.0 layout, which ended at goal[] — fails loudly.   */
     int cost_diag;
     /* diff_fun (src/forward_pass.jl:19, iLQG.jl:160: `K*diff_fun(x̂, x)`; default `-`).  A closure cannot cross the C ABI; what stands in

@@ -248,3 +248,59 @@ def test_large_batch_grouping_path(ddp):
     assert (out[0] == ref[0]).all()
     for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4])):
         assert relerr(a_, b_) < 1e-10
+
+
+@pytest.mark.parametrize("G,B", [(16, 7681), (16, 8000), (16, 15361), (8, 7937), (8, 8100), (2, 8129), (2, 8160), (2, 16300)])
+def test_tile_count_at_the_edges_of_a_round(ddp, G, B):
+    """B just above k * 32 * (ncu - G) with G equal λ groups: the device then chooses MORE, smaller tiles than one group holding the
+    whole batch would get (round 4 sized the work-item list for that single case and overran it — ADVICE r4).  Whole batch against the
+    per-trajectory kernels, a sample against the oracle; no tile may have timed out."""
+    import os
+    from ddp_amd import _lib
+    rng = np.random.default_rng(100 * G + B)
+    N = 16
+    cx, cu, cxx, cxu, cuu, A, Bm, u = _lti(rng, N, B)
+    vals = 1.6 ** -np.arange(G, dtype=float)
+    lam = vals[np.arange(B) % G]
+    rng.shuffle(lam)
+    h = _lib.default_handle()
+    t0 = h.sh_timeouts()
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)
+    assert h.last_kernel(0) == "sh_back_kernel"
+    assert h.sh_timeouts() == t0
+    os.environ["DDP_BACKPASS"] = "x"
+    try:
+        ref = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)
+        assert h.last_kernel(0) != "sh_back_kernel"
+    finally:
+        del os.environ["DDP_BACKPASS"]
+        h.raw
+    assert (out[0] == ref[0]).all()
+    for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4]), (out[1].Σi, ref[1].Σi)):
+        assert relerr(a_, b_) < 1e-10
+    who = sorted({0, 1, B // 2, B - 2, B - 1} | set(int(v) for v in rng.integers(0, B, 12)))
+    _check_all(out, cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, u, who=who)
+
+
+def test_a_timed_out_tile_hands_its_trajectories_to_the_per_trajectory_kernels(ddp, monkeypatch):
+    """DDP_TEST_SH_ABORT makes every consumer tile give up at its second chunk (what a 4 s time-out does): the results must still be
+    those of the oracle — the tile flags its trajectories for the kernels launched behind the shared pass — and the event is counted
+    (ddp_sh_timeouts) instead of vanishing (the flag was written and never read)."""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(77)
+    N, B = 40, 70
+    cx, cu, cxx, cxu, cuu, A, Bm, u = _lti(rng, N, B)
+    lam = np.where(np.arange(B) % 3 == 0, 0.5, 1.0)
+    monkeypatch.setenv("DDP_SH_MIN_B", "1")
+    h = _lib.default_handle()
+    good = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)
+    t0 = h.sh_timeouts()
+    monkeypatch.setenv("DDP_TEST_SH_ABORT", "1")
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)
+    assert h.sh_timeouts() > t0
+    monkeypatch.delenv("DDP_TEST_SH_ABORT")
+    _check_all(out, cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, u)
+    for a_, b_ in ((out[1].K, good[1].K), (out[2], good[2]), (out[3], good[3]), (out[4], good[4])):
+        assert relerr(a_, b_) < 1e-10
+    again = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)       # and the path is healthy afterwards
+    assert np.array_equal(again[3], good[3]) and h.sh_timeouts() == h.sh_timeouts()
