@@ -206,7 +206,7 @@ class PassBench:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU (BASELINE config 2: 1024)")
     ap.add_argument("--horizon", type=int, default=1000)
@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C4 pass lines (profiles/bench_configs.py in a child process)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories for the CPU baseline (0 = auto ~10-20 s)")
     ap.add_argument("--fill-batch", type=int, default=32768, help="machine-filling batch reported next to the headline (0 = skip)")
+    ap.add_argument("--dry-run", action="store_true", help="no device work: the ranks rendezvous (gloo), build their shard of the workload on "
+                    "the host and share the statistics vector exactly as the timed run does; rank 0 prints the launch-contract line "
+                    "(n_ranks_seen, per-rank seeds and input digests).  What a CPU-only host can check of `--gpus N` (tests/test_sharding_gloo.py)")
     args = ap.parse_args()
 
     import torch
@@ -233,6 +236,8 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run,
         # exactly the command line the driver uses) and pass their output through — rank 0 of the children prints the one JSON line
         return spawn_ranks(args.gpus)
+    if args.dry_run:
+        return dry_run(args, torch, dist, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     backend = os.environ.get("DDP_BENCH_BACKEND", "nccl")   # "gloo": test mode — several ranks may share one GPU (RCCL refuses that), the
     local = local % torch.cuda.device_count() if backend == "gloo" else local     # statistics vector travels through host memory
@@ -366,6 +371,41 @@ def main():
     return out
 
 
+def dry_run(args, torch, dist, world, rank):
+    """The launch contract of `bench.py --gpus N` without a device: same environment handling, same per-rank seeds (1000 + rank, the ones
+    PassBench uses), the same 4-double statistics vector through an all-reduce — on gloo, with host tensors.  Nothing here is a measurement."""
+    import hashlib
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, m, N = N_STATE, N_CTRL, min(args.horizon, 50)
+    B = min(args.batch, 64)
+    seed = 1000 + rank
+    A, Bm, Q, R, x0, u0 = make_workload(seed, n, m, N, B)
+    digest = int(hashlib.sha256(x0.tobytes() + u0.tobytes()).hexdigest()[:12], 16)
+    shared = int(hashlib.sha256(A.tobytes() + Bm.tobytes()).hexdigest()[:12], 16)
+    stats = torch.tensor([float(np.sum(x0 * x0)), float(np.sum(u0)), float(B), 0.0], dtype=torch.float64)
+    mine = stats.clone()
+    rows = [None] * world
+    if use_dist:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_gather_object(rows, {"rank": rank, "seed": seed, "inputs_digest": digest, "shared_operands_digest": shared, "local_stats0": float(mine[0])})
+    else:
+        rows = [{"rank": rank, "seed": seed, "inputs_digest": digest, "shared_operands_digest": shared, "local_stats0": float(mine[0])}]
+    out = None
+    if rank == 0:
+        out = {"dry_run": True, "metric": "iLQG iterations/sec (backward+forward, n=10 m=2 T=1000)", "value": None, "n_gpus": world,
+               "n_ranks_seen": dist.get_world_size() if use_dist else 1, "scaling": "weak", "batch_per_gpu": args.batch,
+               "ranks": rows, "collective": {"stats": [float(v) for v in stats]}}
+        print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
 def spawn_ranks(n):
     import socket
     import subprocess
@@ -429,8 +469,8 @@ def other_configs():
     env.setdefault("DDP_BC_STEPS", "40")
     out = []
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c2tv", "c4", "c5"], env=env, capture_output=True,
-                           text=True, timeout=300)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c2tv", "c4", "c5", "offA", "offB"], env=env, capture_output=True,
+                           text=True, timeout=400)
         for line in r.stdout.splitlines():
             if line.startswith("{"):
                 out.append(json.loads(line))

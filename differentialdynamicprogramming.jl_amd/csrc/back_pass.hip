@@ -727,7 +727,8 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
     //   dpp     16 lanes per trajectory (back_pass_dpp.hip): fewest instructions per trajectory-step, best once the
     //           batch gives every SIMD a few wavefronts; also the kernel for control limits;
     //   general 64 lanes per trajectory, any n <= 32 / m <= 8 / limits (this file).
-    // DDP_BACKPASS=x|q|general|dpp|big forces one (A/B timing, tests of every code path).
+    //   row     the same row kernel compiled for PADDED sizes (back_pass_row.hip): any n <= 14, m <= 4, n + m <= 15 that has no exact instantiation;
+    // DDP_BACKPASS=x|q|general|dpp|row|big forces one (A/B timing, tests of every code path).
     const char *force_env = ddp_env(h, ENV_BACKPASS);          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
     if (force == 'x' || (force == 0 && d->B < 5120)) {
@@ -749,9 +750,13 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         const int rw = ddp_launch_back_pass_dppw(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rw <= 0) { h->last_kernel[0] = "back_pass_dppw_kernel"; return rw; }
     }
-    if (force != 'g' && force != 'b') {
+    if (force != 'g' && force != 'b' && force != 'r') {
         const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_dpp_kernel"; return rc; }
+    }
+    if (force == 0 || force == 'r') {                             // every other shape a 16-lane row holds: the row kernel compiled for padded sizes
+        const int rc = ddp_launch_back_pass_row(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_row_kernel"; return rc; }
     }
     h->last_kernel[0] = "back_pass_kernel";
     BPArgs a = {};

@@ -197,19 +197,19 @@ __global__ __launch_bounds__(DDP_WAVE * (NCW + NWW)) void back_pass_dppw_kernel(
                                 if (held[c]) {
                                     const d2 hh = hv[c][hq];
                                     const char *sbh = sbq + GW * PER[A] * 8;
-                                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(vo), "v"(hh), "s"(sbh) : "memory");
+                                    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(vo), "v"(hh), "s"(sbh) : "memory");
                                     if (A == 3) held[c] = false;
                                 }
                             }
                             if constexpr (decltype(plain_c)::value) {
                                 // nt: the results are not read again by this kernel (9.80 against 10.0 ms per pass at B = 32 768)
-                                asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(vo), "v"(vv), "s"(sbq) : "memory");
+                                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(vo), "v"(vv), "s"(sbq) : "memory");
                             } else {                              // a missing / finished trajectory, or the short first group
                                 constexpr int items = GPW * GW * PC[A];
                                 const int idx = qa * DDP_WAVE + lane, id = idx < items ? idx : items - 1;
                                 const int t = id / (GW * PC[A]), so = (id % (GW * PC[A])) / PC[A];
                                 if (((onm[c] >> t) & 1) && so <= top)
-                                    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo), "v"(vv), "s"(sbq) : "memory");
+                                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo), "v"(vv), "s"(sbq) : "memory");
                             }
                         });
                     });

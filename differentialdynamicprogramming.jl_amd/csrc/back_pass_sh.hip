@@ -56,6 +56,12 @@ constexpr int SH_FIN = 1 << 30, SH_ABORT = 1 << 29, SH_CNT = (1 << 24) - 1;
 #ifndef SH_NWR
 #define SH_NWR 6
 #endif
+#ifndef SH_SYM
+#define SH_SYM 8                                    // the chain forms ½(V + V') itself every SH_SYM-th step (the builder wave does it for the records of the others)
+#endif
+#ifndef SH_STRAIGHT
+#define SH_STRAIGHT 1                               // 1: no branch inside a chunk of the chain (a failing step is noted, the chunk runs to its end)
+#endif
 constexpr int TMAX = SH_TMAX;                       // trajectories per consumer tile
 constexpr int NAFF = TMAX / 4, NWR = SH_NWR;        // affine waves, writer waves
 constexpr int SH_THREADS = DDP_WAVE * (1 + NAFF + NWR);
@@ -69,7 +75,8 @@ constexpr int P_FLAGS = P_PUB + NPB * GCHUNK;
 static_assert(P_PUB % 2 == 0 && P_FLAGS % 2 == 0, "16-byte pieces");
 constexpr int C_SBUF = 0;                                           // NSB chunks of the record stream
 constexpr int EIMG = 4 * 96;                                        // [cx 80 | cu 16] of a chunk for the 4 trajectories of a wave
-constexpr int C_WAVE = NSB * GCHUNK, C_WSZ = 2 * EIMG + 8;          // per affine wave: 2 gradient images (the results overwrite the gradients in place), zero cell, dump cell
+constexpr int NEI = 3;                                              // gradient images per affine wave
+constexpr int C_WAVE = NSB * GCHUNK, C_WSZ = NEI * EIMG + 8;        // per affine wave: NEI gradient images (the results overwrite the gradients in place), zero cell, dump cell
 constexpr int C_FLAGS = C_WAVE + NAFF * C_WSZ;
 constexpr int SH_LDS_DOUBLES = (P_FLAGS > C_FLAGS ? P_FLAGS : C_FLAGS) + 48;
 constexpr size_t SH_LDS_BYTES = (size_t)SH_LDS_DOUBLES * 8;
@@ -87,6 +94,7 @@ struct ShCtl {                                      // device-resident control b
     int gdiverge[SH_GMAX];
     int gcount[SH_GMAX], gstart[SH_GMAX];
     double glam[SH_GMAX];
+    unsigned long long prof[64];                    // -DSH_PROF: phase sums of group 0's chain wave + wall-clock marks (ddp_sh_prof)
 };
 
 struct ShArgs {
@@ -99,6 +107,7 @@ struct ShArgs {
     int4 *items;                                    // (group, first position in perm, trajectories, 0)
     int *perm;
     int32_t *fb_active;
+    double *sink;                                   // 4 KB that lanes without a result may write (the handle's)
     double *rec;                                    // record streams: [SH_GMAX][chunks][CH][GREC]
 };
 
@@ -108,7 +117,7 @@ __device__ __forceinline__ void lds_store_flag(int *p, int v) { asm volatile("" 
 
 __device__ __forceinline__ void store16_sc1(void *p, d2 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store4_sc1(int *p, int v)
 {
@@ -120,9 +129,12 @@ __device__ __forceinline__ int load4_sc1(const int *p)
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// (a store of more than 8 bytes reads its data registers AFTER it has been issued: the next instruction must not overwrite them — a
+// hazard the compiler pads for its own stores and cannot see inside an asm statement.  Round 5 met it: with the address select in front
+// of each store the allocator reused the data registers at once and the LOW DWORDS of some stored k / Vx were those of the next value.)
 __device__ __forceinline__ void store16_nt(void *p, d2 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // =============================================================== grouping ====================================================
@@ -216,6 +228,10 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
             gtile[G] = W;
             Gs = G; Ts = T;
             a.ctl->G = G; a.ctl->W = W; a.ctl->ticket = 0; a.ctl->error = 0;
+#ifdef SH_PROF
+            for (int e = 0; e < 64; ++e) a.ctl->prof[e] = 0;
+            a.ctl->prof[19] = ~0ull;
+#endif
         }
     }
     if (tid < SH_GMAX) { a.ctl->progress[16 * tid] = 0; a.ctl->gdiverge[tid] = 0; }
@@ -303,6 +319,7 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
     for (int s = 0; s < 3; ++s) { const int row = l4 + 4 * s; S[s] = (l15 < n && row < n) ? 2.0 * cxx[row + n * l15] : 0.0; }   // 2 Vxx_N (:234)
     for (int e = lane; e < TLD * 16 + 16; e += DDP_WAVE) lds[e] = 0.0;
     const double cB = l4 >= 2 ? 1.0 : -lam;                   // regType 1: T = -λK in the 16-lane rows 0, 1
+    const double chl = -0.5 * lam;
     const bool odd = (l4 & 1) != 0, hi2 = l4 >= 2;
     const int wr = l4 + TLD * l15, rdT = l15 + TLD * l4, rdS = 4 * TLD;
     // where this lane's values go in a step record (lanes without one aim behind the records)
@@ -316,9 +333,22 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
     int diverge = 0;
     int wb1 = w1, wb2 = w2, wb3 = w3;
     // One time step; SIN: S holds V + V' (else V) of the step before; SOUT: ½(V + V') on the chain (else the builder does it)
+#ifdef SH_PROF
+    // phase profile of the chain wave (s_memtime, shader clock): [SOUT][phase] sums over all steps; phases: 0 the six products up to the
+    // first use of G, 1 the 2x2 gain solve up to the issue of the update product, 2 the update product up to V in S, 3 records + branches
+    unsigned long long pacc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, pcnt[2] = {0, 0}, pt[5];
+    const unsigned long long wc0 = wall_clock64();
+// (the stamp takes the value it follows as an operand so that the compiler cannot move it; the wait makes the SGPR pair valid)
+#define SH_PT(k, val) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt[k]), "+v"(val))
+#else
+#define SH_PT(k, val)
+#endif
     auto step = [&](const int i, const int roff, auto sin_c, auto sout_c) __attribute__((always_inline)) {
         constexpr bool SIN = decltype(sin_c)::value != 0, SOUT = decltype(sout_c)::value != 0;
         const double *Bg = SIN ? Fh : Ff;
+#ifdef SH_PROF
+        SH_PT(0, S[0]);
+#endif
         // GEMM1: W = Vxx·F
         d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], Bg[0], zero4, 0, 0, 0);
         w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[1], Bg[1], w, 0, 0, 0);
@@ -327,7 +357,9 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
         d4 g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], w.x, Hc4, 0, 0, 0);
         g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], w.y, g, 0, 0, 0);
         g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[2], w.z, g, 0, 0, 0);
-        const double Z = g.w + 0.0;                        // G row 10 | 11 (Qux | Quu) with the parity of my 16-lane row
+        double Z = g.w + 0.0;                              // G row 10 | 11 (Qux | Quu) with the parity of my 16-lane row
+        const double hZ = 0.5 * Z;
+        SH_PT(1, Z);
         double Q0, Q1, F00, F01, F11;
         if (REG2) {                                        // u-rows of F'(W + λF) + H: Qux_reg, QuuF  (:245-247)
             const double lamB = SIN ? 2.0 * lam : lam;
@@ -347,20 +379,36 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
         const double K0 = -(n0 * y), K1 = -(n1 * y);       // K = -QuuF⁻¹ Qux_reg  (:42)
         const double Ksel = odd ? K1 : K0;
         double Tsel, Bop;
-        if (!REG2) {
+        // value update (:69-72): V = G + K'T + Qux'K with T = Quu K + Qux: the rank-4 product [K' Qux'][T; K].
+        double Aop;
+        if (!REG2 && SH_STRAIGHT) {
+            // regType 1: T = -λK and Qux'K = -Qux'ΦQux is symmetric (Φ = QuuF⁻¹ is, and Qux_reg = Qux), so Qux'K = K'Qux and
+            // V = G + K'Y, Y = T + Qux: the A operand is K' in all four k slots (slot k holds row k & 1), the B operand ½Y — no per-row
+            // selects on the way to the product; ½(V + V') (:71-72) removes the rounding-level difference between the two forms.
+            // (Not for regType 2: K = -ΦQux_reg with Qux_reg != Qux, Qux'K is not symmetric.)
+            Bop = fma(chl, Ksel, hZ);                      // ½(Qux - λK)
+            Aop = Ksel;
+        } else if (!REG2) {
             Bop = Ksel * cB;                               // T = -λK (rows 0, 1) | K (rows 2, 3)
+            Aop = hi2 ? Z : Ksel;
         } else {
             Tsel = Z;
             fmac_bcast<n, 0xf, true>(Tsel, Z, K0);
             fmac_bcast<n + 1>(Tsel, Z, K1);
             Bop = hi2 ? Ksel : Tsel;
+            Aop = hi2 ? Z : Ksel;
         }
-        // value update (:69-72): V = G + [K' Qux']·[T; K]
-        const double Aop = hi2 ? Z : Ksel;
+        SH_PT(2, Bop);
         const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop, Bop, g, 0, 0, 0);
         const bool badu = (__builtin_amdgcn_ballot_w64(!(F00 > 0.0)) | __builtin_amdgcn_ballot_w64(!(det > 0.0))) != 0;
         crec[wb3 + roff] = Z;
+#if SH_STRAIGHT
+        // diverge = i (:37-38), noted without a branch: the steps the chain still runs in this chunk work on garbage that nobody reads
+        // (the builder zero-fills the failing step and everything below it, the chain stops at the end of the chunk)
+        { const int bd = badu ? i + 1 : 0; diverge = diverge ? diverge : bd; }
+#else
         if (__builtin_expect(badu, 0)) { diverge = i + 1; return; }     // diverge = i (:37-38)
+#endif
         if (SOUT) {
             lds[wr] = v.x; lds[wr + 4] = v.y; lds[wr + 8] = v.z;
             wave_sync();
@@ -370,11 +418,24 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
             crec[wb2 + roff] = hi2 ? Ksel : 0.5 * S[2];
             wave_sync();
         } else {
+#ifdef SH_PROF
+            S[0] = v.x + 0.0; S[1] = v.y; S[2] = v.z;        // (a real VALU read of V: the stamp behind it is taken when V has arrived)
+#else
             S[0] = v.x; S[1] = v.y; S[2] = v.z;
+#endif
+#ifdef SH_PROF
+            SH_PT(3, S[0]);
+#endif
             crec[wb1 + roff] = S[0];
             crec[wb1 + 4 + roff] = S[1];
             crec[wb2 + roff] = hi2 ? Ksel : S[2];
         }
+#ifdef SH_PROF
+        if (SOUT) pt[3] = pt[2];                          // (SOUT steps: phases 2 + 3 together in [1][3])
+        SH_PT(4, S[2]);
+        for (int e = 0; e < 4; ++e) pacc[SOUT][e] += pt[e + 1] - pt[e];
+        ++pcnt[SOUT];
+#endif
     };
     const int cTop = (N - 1) / CH, st = (N - 1) % CH, NCHK = cTop + 1;
     // top chunk: the steps below the terminal one, always symmetrised on the chain
@@ -392,15 +453,33 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
         const int ib = CH * (cTop - q);
         static_for<0, CH>([&](auto sc) __attribute__((always_inline)) {
             constexpr int slot = CH - 1 - decltype(sc)::value;
-            constexpr int SINc = (slot == CH - 1 || (slot + 1) % 4 == 0) ? 1 : 0, SOUTc = slot % 4 == 0 ? 1 : 0;
+            constexpr int SINc = (slot == CH - 1 || (slot + 1) % SH_SYM == 0) ? 1 : 0, SOUTc = slot % SH_SYM == 0 ? 1 : 0;
+#if SH_STRAIGHT
+            step(ib + slot, CREC * slot, IC<SINc>{}, IC<SOUTc>{});
+            __builtin_amdgcn_sched_barrier(0);                // (without it the scheduler parks the records of all 8 steps in registers and spills)
+#else
             if (diverge == 0) step(ib + slot, CREC * slot, IC<SINc>{}, IC<SOUTc>{});
+#endif
             if constexpr (slot == CH / 2) seen = lds_load_flag(&flags[PF_BDONE]);
         });
         if (diverge) { lds_store_flag(&flags[PF_CDIV], diverge); lds_store_flag(&flags[PF_CREADY], (q + 1) | SH_FIN); return; }
         lds_store_flag(&flags[PF_CREADY], q + 1);
     }
     if (NCHK > 1) lds_store_flag(&flags[PF_CREADY], NCHK | SH_FIN);
+#ifdef SH_PROF
+    if (gidx == 0 && lane == 0) {
+        for (int so = 0; so < 2; ++so) { for (int e = 0; e < 4; ++e) a.ctl->prof[4 * so + e] = pacc[so][e]; a.ctl->prof[8 + so] = pcnt[so]; }
+        a.ctl->prof[16] = wc0; a.ctl->prof[17] = wall_clock64();
+    }
+#endif
 }
+#ifdef SH_PROF
+#define SH_MARK_MAX(slot) do { if (threadIdx.x % DDP_WAVE == 0) atomicMax(&a.ctl->prof[slot], wall_clock64()); } while (0)
+#define SH_MARK_MIN(slot) do { if (threadIdx.x % DDP_WAVE == 0) { if (a.ctl->prof[slot] == 0) a.ctl->prof[slot] = ~0ull >> 1; atomicMin(&a.ctl->prof[slot], wall_clock64()); } } while (0)
+#else
+#define SH_MARK_MAX(slot)
+#define SH_MARK_MIN(slot)
+#endif
 
 template <bool REG2>
 __device__ __forceinline__ void sh_builder(const ShArgs &a, double *sm, const double lam)
@@ -466,7 +545,7 @@ __device__ __forceinline__ void sh_builder(const ShArgs &a, double *sm, const do
                 for (int t = 0; t < 3; ++t) out[G_M + MLD * j + tq + 4 * t] = 0.0;
                 continue;
             }
-            const bool needsym = q > 0 && (slot % 4) != 0;
+            const bool needsym = q > 0 && (slot % SH_SYM) != 0;
             if (lane < 62) {
                 d2 v = *(const d2 *)(rec + 2 * lane);
                 if (lane < 50 && needsym) { v.x = 0.5 * (v.x + rec[tp0]); v.y = 0.5 * (v.y + rec[tp1]); }        // :71-72
@@ -493,7 +572,7 @@ __device__ __forceinline__ void sh_builder(const ShArgs &a, double *sm, const do
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the records are read, the publish buffer is written
         lds_store_flag(&flags[PF_BDONE], q + 1);
         lds_store_flag(&flags[PF_BREADY], (q + 1) | (last ? SH_FIN : 0));
-        if (last) return;
+        if (last) { SH_MARK_MAX(20); return; }
     }
     // the chain diverged in a chunk it never finished counting: nothing more to build (PF_CREADY carried FIN with have <= q)
     lds_store_flag(&flags[PF_BREADY], (lds_load_flag(&flags[PF_BREADY]) & SH_CNT) | SH_FIN);
@@ -547,6 +626,7 @@ __device__ __forceinline__ void sh_publisher(const ShArgs &a, double *sm, const 
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the chunk has left (write-through) before the progress word says so
             if (lane == 0) store4_sc1(prog, (q + 1) | SH_FIN);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SH_MARK_MAX(21);
             return;
         }
         pending = true;
@@ -615,6 +695,7 @@ __device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_store_flag(&flags[CF_SREADY], NCHK);
+    SH_MARK_MAX(23);
 }
 
 // waits until chunk q of the ring is ready; false: the launch was aborted
@@ -635,7 +716,7 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
     int *flags = (int *)(sm + C_FLAGS);
     const int N = a.N, cTop = (N - 1) / CH, st = (N - 1) % CH, NCHK = cTop + 1;
     double *wv = sm + C_WAVE + aw * C_WSZ;
-    double *eimg = wv, *zcell = wv + 2 * EIMG, *dcell = wv + 2 * EIMG + 4;
+    double *eimg = wv, *zcell = wv + NEI * EIMG, *dcell = wv + NEI * EIMG + 4;
     if (lane < 4) zcell[lane] = 0.0;
     // my row's trajectory (rows past the tile repeat its last trajectory and store nothing)
     const int cnt = item.z, tloc = 4 * aw + r, tl = tloc < cnt ? tloc : cnt - 1;
@@ -656,10 +737,11 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
         rdst[kk] = L < 40 ? (char *)(a.Vx + ((size_t)bb * N + (size_t)CH * cTop) * n) + 16 * L
                           : (char *)(a.k + ((size_t)bb * N + (size_t)CH * cTop) * m) + 16 * (L - 40);
     }
+    char *const sinkp = (char *)a.sink + 16 * lane;
     const int gstep[3] = {(lane % 48) < 40 ? CH * n * 8 : CH * m * 8, ((64 + lane) % 48) < 40 ? CH * n * 8 : CH * m * 8,
                           ((128 + lane) % 48) < 40 ? CH * n * 8 : CH * m * 8};          // bytes per chunk
-    auto dma_e = [&](int q) {                                   // [cx;cu] of chunk q -> image q % 2 (steps past N - 1 are not touched)
-        double *dst = eimg + (q % 2) * EIMG;
+    auto dma_e = [&](int q, int img) {                          // [cx;cu] of chunk q -> image img (steps past N - 1 are not touched)
+        double *dst = eimg + img * EIMG;
         const int top = q == 0 ? st : CH - 1;
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
@@ -667,26 +749,45 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
     };
     // per-lane offsets inside an image: lane j of row r reads / writes element j of step s at eo + es * s
     const int eo = 96 * r + (j < n ? j : (j < p ? 80 + (j - n) : 0)), es = j < n ? n : (j < p ? m : 0);
-    const double *ebase = j < p ? eimg + eo : zcell;            // (image 0; image 1 is EIMG further)
+    const double *ebase = j < p ? eimg + eo : zcell;            // (image 0; image i is i * EIMG further)
     const int eflip = j < p ? EIMG : 0;
     double *rbase0 = j < p ? eimg + eo : dcell + (lane & 3);          // results overwrite the gradients of their step (same image, same cell)
     const double maskx = j < n ? 1.0 : 0.0;
     const int mrow = G_M + MLD * j;
     double s = 0.0, acc1 = 0.0, acc2 = 0.0;
     int seen = 0, gdiv = 0;
-    dma_e(0);
-    if (NCHK > 1) dma_e(1);
+    dma_e(0, 0);
+    dma_e(NCHK > 1 ? 1 : 0, 1);                                 // (always three loads behind the ones a chunk waits for: see below)
     bool ok = true;
     for (int q = 0; q < NCHK; ++q) {
         const int top = q == 0 ? st : CH - 1;
-        // the gradient image of this chunk has landed once at most the loads of chunk q + 1 are outstanding
-        if (q + 1 < NCHK) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The gradient image of this chunk has landed once at most the three loads issued behind it are outstanding.  vmcnt counts the
+        // wave's stores as well, in no order this code relies on relative to the loads — but loads return in order among themselves, so
+        // "<= 3 outstanding" cannot hold with a load of chunk q pending while the three loads behind it are: safe whatever the stores do.
+        // What the wait COSTS depends on when those loads went out and on what else it forces:
+        //  * round 4 issued the loads of chunk q + 1 at the END of iteration q - 1, behind its stores: every chunk waited a memory latency
+        //    here.  Now they go out at the TOP of iteration q - 1 into a third image and have had a whole iteration.
+        //  * the last chunk had no loads behind it and waited for vmcnt(0) — for the acknowledgement of the result stores of the chunk
+        //    before, ~15 us at the end of a launch that has been writing 3 TB/s (profiles/r05_sh_phase_after.json: the affine waves ended
+        //    16 us after the last chunk had landed).  Now every iteration issues three loads: past the end they re-read the last chunk into
+        //    the image nobody uses any more.
+#ifdef SH_PROF
+        const unsigned long long ta0 = __builtin_readcyclecounter();
+#endif
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#ifdef SH_PROF
+        const unsigned long long ta1 = __builtin_readcyclecounter();
+#endif
+        dma_e(q + 2 < NCHK ? q + 2 : NCHK - 1, (q + 2) % NEI);    // image (q + 2) % 3 held chunk q - 1: its results are in flight from registers
         if (!sh_wait_chunk(flags, q, seen)) { ok = false; break; }
+#ifdef SH_PROF
+        const unsigned long long ta2 = __builtin_readcyclecounter();
+#endif
         const int kind = lds_load_flag(&flags[CF_KIND + q % NSB]);
         const double *sb = sm + C_SBUF + (q % NSB) * GCHUNK;
-        const double *eb = ebase + (q % 2) * eflip;
-        double *rbase = rbase0 + (q % 2) * eflip;
-        const double *res = eimg + (q % 2) * EIMG;
+        const double *eb = ebase + (q % NEI) * eflip;
+        double *rbase = rbase0 + (q % NEI) * eflip;
+        const double *res = eimg + (q % NEI) * EIMG;
         if (kind == KIND_NORMAL) {
             for (int slot = top; slot >= 0; --slot) {
                 const double *mr = sb + GREC * slot + mrow;
@@ -719,20 +820,28 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
         }
         // results of the chunk: 3 x 64 pieces, whole 640 / 128 byte bursts per trajectory
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        d2 rv[3];
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const d2 v = *(const d2 *)(res + 128 * kk + 2 * lane);
-            if (plive[kk] && pstep[kk] <= top) store16_nt(rdst[kk] - (long)gstep[kk] * q, v);
-        }
-        if (q + 2 < NCHK) dma_e(q + 2);                          // image q % 2 is free again; the newest 3 vector-memory operations of the wave
+        for (int kk = 0; kk < 3; ++kk) rv[kk] = *(const d2 *)(res + 128 * kk + 2 * lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) store16_nt((plive[kk] && pstep[kk] <= top) ? rdst[kk] - (long)gstep[kk] * q : sinkp, rv[kk]);
         lds_store_flag(&flags[CF_UDONE + aw], q + 1);
+#ifdef SH_PROF
+        if (item.y == 0 && aw == 0 && lane == 0 && q > 0) {       // first tile of group 0: where an affine wave's chunk period goes
+            const unsigned long long ta3 = __builtin_readcyclecounter();
+            a.ctl->prof[32] += ta1 - ta0; a.ctl->prof[33] += ta2 - ta1; a.ctl->prof[34] += ta3 - ta2; a.ctl->prof[35] += 1;
+            if (ta2 - ta1 < 200) a.ctl->prof[36] += 1;              // chunks that were already there when the wave asked for them
+        }
+#endif
     }
-    if (!ok) { lds_store_flag(&flags[CF_UDONE + aw], 1 << 28); return; }
+    if (!ok) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_store_flag(&flags[CF_UDONE + aw], 1 << 28); return; }
     // dV (:68) and diverge of my row's trajectory
     const double d1 = __shfl(acc1, 16 * r + 12) + __shfl(acc2, 16 * r + 13);
     const double d2v = __shfl(acc1, 16 * r + 14) + __shfl(acc2, 16 * r + 15);
     if (rowlive && j == 0) { a.dV[2 * (size_t)b] = d1; a.dV[2 * (size_t)b + 1] = 0.5 * d2v; a.diverge[b] = gdiv; }
+    SH_MARK_MAX(24);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the loads past the end still aim at this work-group's LDS)
 }
 
 __device__ __forceinline__ void sh_writer(const ShArgs &a, double *sm, const int gidx, const int ww, const int4 item)
@@ -792,6 +901,10 @@ __global__ __launch_bounds__(SH_THREADS) void sh_back_kernel(ShArgs a)
     __syncthreads();
     const int role = *role_s;
     const int G = a.ctl->G, W = a.ctl->W;
+#ifdef SH_PROF
+    if (threadIdx.x == 0) atomicMin(&a.ctl->prof[19], wall_clock64());
+    struct Mark { ShCtl *c; bool on; __device__ ~Mark() { if (on) atomicMax(&c->prof[18], wall_clock64()); } } mark_{a.ctl, threadIdx.x % DDP_WAVE == 0};
+#endif
     if (role < G) {
         if (wave > 2) return;
         const double lam = a.ctl->glam[role];
@@ -840,7 +953,7 @@ int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx
                             const int32_t **fb_active)
 {
     if (d->has_lims || d->m != 2 || d->n != 10 || d->fx_batched || d->cost_batched || d->fx_tv || d->cost_tv) return 1;
-    if (d->N < 2 * CH) return 1;
+    if (d->N < 2 * CH || !h->sink) return 1;
     if ((((uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx | (uintptr_t)cxx | (uintptr_t)cuu) & 15) != 0) return 1;
     const int B = d->B, N = d->N;
     if (!h->ncu) { hipDeviceProp_t pr; DDP_HIP(hipGetDeviceProperties(&pr, h->device)); h->ncu = pr.multiProcessorCount; }
@@ -868,6 +981,7 @@ int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     a.ctl = (ShCtl *)base; a.items = (int4 *)(base + o_items); a.perm = (int *)(base + o_perm); a.fb_active = (int32_t *)(base + o_fb);
     a.rec = (double *)(base + o_rec);
+    a.sink = (double *)h->sink;
     if (a.B <= 8 * 1024) hipLaunchKernelGGL(sh_group_kernel<true>, dim3(1), dim3(1024), 0, h->stream, a);
     else hipLaunchKernelGGL(sh_group_kernel<false>, dim3(1), dim3(1024), 0, h->stream, a);
     if (!h->sh_attr) {
@@ -880,6 +994,18 @@ int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx
     else hipLaunchKernelGGL((sh_back_kernel<false>), grid, block, SH_LDS_BYTES, h->stream, a);
     DDP_HIP(hipGetLastError());
     *fb_active = a.fb_active;
+    return 0;
+}
+
+// -DSH_PROF builds (profiles/sh_phase_profile.py): the phase sums of the last launch; zeros in the production library
+extern "C" int ddp_sh_prof(ddp_handle h, unsigned long long *out32)
+{
+    DDP_DEVICE(h);
+    if (!h->sh) return -1;
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    ShCtl c;
+    DDP_HIP(hipMemcpy(&c, h->sh, sizeof c, hipMemcpyDeviceToHost));
+    for (int e = 0; e < 64; ++e) out32[e] = c.prof[e];
     return 0;
 }
 

@@ -115,6 +115,12 @@ int ddp_launch_back_pass_mx2(ddp_handle h, const ddp_bp_desc *d, const double *c
 
 // shared time-invariant operands (n=10, m=2, no limits): the matrix recursion once per distinct λ, an affine chain per trajectory
 // (back_pass_sh.hip); 1 = not applicable; 0 = launched, the trajectories it left out are flagged in *fb_active
+// back_pass_row.hip: the 16-lane-row kernel compiled for padded sizes — any n <= 14, m <= 4 with n + m <= 15; 1 = not applicable
+int ddp_launch_back_pass_row(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const double *lambda, const double *lims, const double *u,
+                             const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                             double *Vxx, double *dV, int32_t *diverge);
 extern "C" int ddp_sh_max_tiles(int B, int ncu);      // capacity of its work-item list: the most consumer tiles any grouping of B trajectories can make
 int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                             const double *cxx, const double *cxu, const double *cuu, const double *fx,

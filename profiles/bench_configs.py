@@ -3,6 +3,8 @@
    C4  large-state LTV n=64 m=8 N=256, per-trajectory dynamics (a3 layout), B=1024 per GPU
    C2TV the C2 shape (n=10, m=2, N=1000, B=1024) in the LTV / TV-cost layout (per-trajectory fx, fu, cxx, cxu, cuu; SURVEY 8d: 4.47 MB/pass)
    C5  one pass of the KL-constrained iteration (C3 + KL): back_pass_gps + forward_pass + forward_covariance + kl_div_wiki, B=4096
+   offA / offB  shapes BASELINE does not name (the reference's back_pass is size-generic, backward_pass.jl:162-252): n=12 m=3 N=500
+       B=2048 with per-trajectory time-varying dynamics; n=6 m=2 N=1000 B=4096 LTI with control limits — the padded row kernel
 Prints one JSON line per config.  Informational; the graded line is bench.py's."""
 import ctypes as C
 import json
@@ -85,11 +87,21 @@ def run(name, prob, n, m, N, B, dx0, du0, lims, regType, fx_desc, steps=10, warm
     tv = fx_tv
     bp_bytes = ((n + m) + (n * n + n * m if tv else 0) + (n * n + n * m + m * m if ctv else 0) + (m if lims is not None else 0) + (m * n + m + n + n * n + m * m)) * 8 * (N - 1) * B
     fp_bytes = ((m * n + m + n + m) + (n * n + n * m if (tv and not pend) else 0) + (n + m + 1)) * 8 * N * B
+    extra = {}
+    if n == 64 and m == 8:
+        # C4 sits on the ridge: the binding roofline is the fp64 matrix pipe.  Products per trajectory-step as the kernel
+        # issues them: 608 v_mfma_f64_16x16x4 (SQ_INSTS_VALU_MFMA_F64 = 158 760 960 per launch of 1 024 x 255 steps, profiles/r04_c4_pmc.txt;
+        # 620 with limits is not counted here), 2 048 flop each; peak 78.6 TFLOP/s dense fp64 matrix (MI355X_MICROARCH.md)
+        flop = 608.0 * 2048.0 * (N - 1) * B
+        extra["back_pass_roofline_mfma"] = {"bound": "mfma_f64", "achieved_TFs": round(flop / (np.mean(bp) * 1e-3) / 1e12, 2), "peak_TFs": 78.6,
+                                           "frac": round(flop / (np.mean(bp) * 1e-3) / 78.6e12, 4), "flop_per_launch": flop}
     out = {"config": name, "n": n, "m": m, "N": N, "batch": B, "iterations_per_s": round(B * steps / el, 1), "ms_per_pass_batch": round(1e3 * el / steps, 3),
            "back_pass_ms": round(float(np.mean(bp)), 3), "forward_ms": round(float(np.mean(fp)), 3),
            "back_pass_ms_median": round(float(np.median(bp)), 4), "back_pass_ms_min": round(float(np.min(bp)), 4),
            "back_pass_alg_bytes_per_launch": int(bp_bytes), "back_pass_alg_GBs": round(bp_bytes / (np.mean(bp) * 1e-3) / 1e9, 1), "back_pass_frac_of_8TBs": round(bp_bytes / (np.mean(bp) * 1e-3) / 8e12, 4),
-           "forward_alg_GBs": round(fp_bytes / (np.mean(fp) * 1e-3) / 1e9, 1), "diverged": int(ddiv.sum().item())}
+           "forward_alg_GBs": round(fp_bytes / (np.mean(fp) * 1e-3) / 1e9, 1), "diverged": int(ddiv.sum().item()),
+           "back_pass_kernel": h.last_kernel(0), "forward_kernel": h.last_kernel(1)}
+    out.update(extra)
     print(json.dumps(out))
 
 
@@ -140,6 +152,37 @@ def c2tv(B=1024):
     x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
     u0 = 0.1 * rng.standard_normal((m, N, B))
     run("C2 LTV / TV-cost layout", prob, n, m, N, B, f64(x0), f64(u0), None, 1, (dA, dB, 1, 1), cost_desc=(dcxx, dcxu, dcuu, 1, 1))
+
+
+def off_shape(tag, n, m, N, B, ltv, lims):
+    """a shape with no exact instantiation: LQ problem of demo_linear's recipe at (n, m); ltv: fx, fu time-varying per trajectory"""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(4321 + n)
+    torch.manual_seed(3)
+    h_ = 0.01
+    a0 = rng.standard_normal((n, n))
+    A = sla.expm(h_ * (a0 - a0.T))
+    Bm = h_ * rng.standard_normal((n, m))
+    prob = _lib.Problem()
+    prob.kind, prob.n, prob.m, prob.N, prob.B = 0, n, m, N, B
+    Q, R = f64(h_ * np.eye(n)), f64(0.1 * h_ * np.eye(m))
+    if ltv:
+        NB = N * B
+        dA = (f64(A).reshape(1, -1) * (1.0 + 0.01 * torch.rand(NB, 1, dtype=torch.float64, device=dev))).reshape(-1).contiguous()
+        dB = (f64(Bm).reshape(1, -1) * (1.0 + 0.01 * torch.rand(NB, 1, dtype=torch.float64, device=dev))).reshape(-1).contiguous()
+        prob.dyn_tv, prob.dyn_batched = 1, 1
+        fxd = (dA, dB, 1, 1)
+    else:
+        dA, dB = f64(A), f64(Bm)
+        fxd = (dA, dB, 0, 0)
+    prob.A, prob.Bm, prob.Q, prob.R = dA.data_ptr(), dB.data_ptr(), Q.data_ptr(), R.data_ptr()
+    prob._Q, prob._R = Q, R
+    prob._keep = (dA, dB)
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
+    u0 = 0.1 * rng.standard_normal((m, N, B))
+    L_ = None if not lims else 0.05 * np.stack([-np.ones(m), np.ones(m)], 1)
+    run("%s n=%d m=%d %s%s" % (tag, n, m, "LTV per-trajectory dynamics" if ltv else "LTI", " lims" if lims else ""), prob, n, m, N, B, f64(x0), f64(u0),
+        L_, 1, fxd)
 
 
 def c5(B=4096):
@@ -297,3 +340,7 @@ if __name__ == "__main__":
         c4()
     if "c5" in which:
         c5()
+    if "offA" in which:
+        off_shape("offA", 12, 3, 500, 2048, True, False)
+    if "offB" in which:
+        off_shape("offB", 6, 2, 1000, 4096, False, True)

@@ -1,0 +1,153 @@
+"""The 16-lane-row backward kernel compiled for PADDED sizes (csrc/back_pass_row.hip): every shape with n <= 14, m <= 4, n + m <= 15 that
+has no exact instantiation runs on it instead of the 64-lanes-per-trajectory kernel.  The reference's back_pass is size-generic
+(src/backward_pass.jl:162-252 + :28-79): every case is compared with the C oracle on every trajectory, for the three rank dispatches
+(LTI :217, LTV / TI-cost :162, LTV / TV-cost :179), both regularisations, with and without control limits, per-trajectory operands,
+inactive trajectories and a diverging λ; the general kernel (DDP_BACKPASS=general) gives the second opinion."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+# (n, m): odd and even n, every padded size NP = 4 .. 14, every MP = 1, 2, 3/4; (10,2) and (4,1) are forced onto the row kernel too
+SHAPES = [(1, 1), (2, 1), (3, 1), (3, 2), (4, 1), (4, 3), (5, 2), (6, 2), (6, 3), (7, 3), (7, 4), (8, 1), (8, 4), (9, 2), (10, 2), (10, 4),
+          (11, 3), (12, 2), (12, 3), (13, 1), (14, 1)]
+
+
+@pytest.fixture(scope="module")
+def ddp():
+    import ddp_amd
+    ddp_amd.default_handle()
+    return ddp_amd
+
+
+def _problem(rng, n, m, N, B, kind):
+    """kind: 'lti' one (fx, fu, cxx, cxu, cuu); 'ltv' fx, fu [.., N], cost time-invariant; 'tv' everything [.., N]; 'btv' [.., N, B]"""
+    import scipy.linalg as sla
+
+    def spd(d, s):
+        a = rng.standard_normal((d, d)); return s * (a @ a.T / d + 0.5 * np.eye(d))
+    A0 = rng.standard_normal((n, n))
+    A = sla.expm(0.1 * (A0 - A0.T)) * rng.uniform(0.95, 1.02)
+    Bm = 0.3 * rng.standard_normal((n, m))
+    cxx, cuu, cxu = spd(n, 0.2), spd(m, 0.1), 0.02 * rng.standard_normal((n, m))
+    tshape = {"lti": (), "ltv": (N,), "tv": (N,), "btv": (N, B)}[kind]
+    cshape = {"lti": (), "ltv": (), "tv": (N,), "btv": (N, B)}[kind]
+
+    def vary(M, shape, amp):
+        if not shape:
+            return M
+        out = M.reshape(M.shape + (1,) * len(shape)) * (1 + amp * rng.standard_normal((1,) * M.ndim + shape))
+        return np.ascontiguousarray(out)
+    fx, fu = vary(A, tshape, 0.02), vary(Bm, tshape, 0.05)
+    cxxv = vary(cxx, cshape, 0.0) * (1 + 0.1 * rng.uniform(size=(1, 1) + cshape)) if cshape else cxx
+    cuuv = vary(cuu, cshape, 0.0) * (1 + 0.1 * rng.uniform(size=(1, 1) + cshape)) if cshape else cuu
+    cxuv = vary(cxu, cshape, 0.1)
+    cx = 0.3 * rng.standard_normal((n, N, B)); cu = 0.2 * rng.standard_normal((m, N, B))
+    u = 0.3 * rng.standard_normal((m, N, B)); x = np.zeros((n, N, B))
+    return cx, cu, cxxv, cxuv, cuuv, fx, fu, x, u
+
+
+def _slice(M, b, batched):
+    return M[..., b] if batched else M
+
+
+def _check(ddp, out, args, lam, regType, L, batched, who=None):
+    from oracle import oracle_ctypes as oc
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    div, pol, Vx, Vxx, dV = out
+    B = cx.shape[-1]
+    lam = np.broadcast_to(np.asarray(lam, float), (B,))
+    for b in (range(B) if who is None else who):
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], _slice(cxx, b, batched), _slice(cxu, b, batched),
+                                                  _slice(cuu, b, batched), _slice(fx, b, batched), _slice(fu, b, batched), lam[b], regType, L,
+                                                  x[..., b], u[..., b])
+        assert d == div[b], (b, d, div[b])
+        for got, ref, name in ((pol.K[..., b], K, "K"), (pol.k[..., b], k, "k"), (Vx[..., b], vx, "Vx"), (Vxx[..., b], vxx, "Vxx"),
+                               (dV[:, b], dv, "dV")):
+            assert relerr(got, ref) < RTOL, (name, b, relerr(got, ref))
+        if d == 0:
+            assert relerr(pol.Σi[..., b], Quu) < RTOL, ("Quu", b)
+            assert np.array_equal(Vxx[..., b], np.transpose(Vxx[..., b], (1, 0, 2)))
+        else:
+            assert not pol.K[:, :, : d - 1, b].any() and not Vxx[:, :, : d - 1, b].any() and not Vx[:, : d - 1, b].any()
+
+
+def _run(ddp, args, lam, regType, L, force):
+    from ddp_amd import _lib
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    os.environ["DDP_BACKPASS"] = force
+    try:
+        out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, L, x, u)
+        name = _lib.default_handle().last_kernel(0)
+    finally:
+        del os.environ["DDP_BACKPASS"]
+        _lib.default_handle().raw
+    return out, name
+
+
+@pytest.mark.parametrize("n,m", SHAPES)
+@pytest.mark.parametrize("kind", ["lti", "ltv", "tv"])
+def test_row_kernel_every_shape_vs_oracle(ddp, n, m, kind):
+    rng = np.random.default_rng(1000 * n + 10 * m + len(kind))
+    N, B = 23, 11                                     # B not a multiple of 4: a wave with idle rows; N not a multiple of the ring
+    args = _problem(rng, n, m, N, B, kind)
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    for regType, lims in ((1, False), (2, True)):
+        L = np.stack([-0.25 * np.ones(m), 0.3 * np.ones(m)], 1) if lims else None
+        out, name = _run(ddp, args, lam, regType, L, "row")
+        assert name == "back_pass_row_kernel", name
+        _check(ddp, out, args, lam, regType, L, False)
+
+
+@pytest.mark.parametrize("n,m", [(3, 1), (5, 2), (6, 3), (9, 2), (12, 3), (13, 1)])
+def test_row_kernel_is_the_default_dispatch(ddp, n, m):
+    """no switch set: these shapes must land on the row kernel, and agree with the general kernel far below the oracle tolerance"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(7 * n + m)
+    N, B = 40, 9
+    args = _problem(rng, n, m, N, B, "ltv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, L, x, u)
+    assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+    ref, name = _run(ddp, args, 0.3, 1, L, "general")
+    assert name == "back_pass_kernel"
+    assert np.array_equal(out[0], ref[0])
+    for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4]), (out[1].Σi, ref[1].Σi)):
+        assert relerr(a_, b_) < 1e-10
+    _check(ddp, out, args, 0.3, 1, L, False)
+
+
+@pytest.mark.parametrize("n,m", [(5, 2), (7, 3), (12, 3)])
+def test_row_kernel_per_trajectory_operands_inactive_and_divergence(ddp, n, m):
+    """a3 layout with a batch axis on every operand; trajectories switched off keep their buffers; a hugely negative λ makes QuuF
+    indefinite at once (diverge = N - 1, everything below zero-filled) for some trajectories only"""
+    rng = np.random.default_rng(31 * n + m)
+    N, B = 19, 10
+    args = _problem(rng, n, m, N, B, "btv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    lam = np.full(B, 0.2); lam[[1, 6]] = -50.0
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 1, None, x, u)
+    assert out[0][1] == N - 1 and out[0][6] == N - 1 and out[0][0] == 0
+    _check(ddp, out, args, lam, 1, None, True)
+    L = np.stack([-0.2 * np.ones(m), 0.2 * np.ones(m)], 1)
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, np.abs(lam), 2, L, x, u)
+    _check(ddp, out, args, np.abs(lam), 2, L, True)
+
+
+def test_row_kernel_full_size_off_shapes(ddp):
+    """the two off-shape lines of bench.py's other_configs at full size: a sample of trajectories against the oracle"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(5150)
+    for n, m, N, B, kind, lims in ((12, 3, 500, 2048, "ltv", False), (6, 2, 1000, 4096, "lti", True)):
+        args = _problem(rng, n, m, N, B, kind)
+        cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+        L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1) if lims else None
+        out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.1, 1, L, x, u)
+        assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+        who = sorted({0, 1, 2, 3, B - 1, B - 2} | set(int(v) for v in rng.integers(0, B, 18)))
+        _check(ddp, out, args, 0.1, 1, L, False, who=who)

@@ -130,3 +130,32 @@ def test_allreduce_stats_single_rank_needs_no_torch(monkeypatch):
     monkeypatch.setitem(sys.modules, "torch.distributed", None)
     v = np.arange(len(sharding.STAT_NAMES), dtype=float)
     assert np.array_equal(sharding.allreduce_stats(v), v)
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_8_launch_contract_dry_run():
+    """`python bench.py --gpus 8` without a launcher starts its eight ranks itself (torch.distributed.run, 127.0.0.1); --dry-run keeps
+    everything but the device work: rank 0's line must report the world size IT SAW in the communicator (n_ranks_seen, not the command line),
+    every rank its own seed and its own trajectories, all of them the same shared operands (A, B: LTI), and the statistics vector the sum
+    over the ranks.  No hardware with more than one RCCL rank has run this yet (the driver's SCALE leg does); this is what a CPU host can pin."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, DDP_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["value"] is None        # nobody can mistake it for a measurement
+    assert out["n_ranks_seen"] == 8 and out["n_gpus"] == 8 and out["scaling"] == "weak"
+    ranks = sorted(out["ranks"], key=lambda d: d["rank"])
+    assert [d["rank"] for d in ranks] == list(range(8))
+    assert len({d["seed"] for d in ranks}) == 8 and len({d["inputs_digest"] for d in ranks}) == 8
+    assert len({d["shared_operands_digest"] for d in ranks}) == 1
+    assert abs(out["collective"]["stats"][0] - sum(d["local_stats0"] for d in ranks)) < 1e-9 * abs(out["collective"]["stats"][0])
+    assert out["collective"]["stats"][2] == 8 * 64
