@@ -59,6 +59,9 @@ constexpr int SH_FIN = 1 << 30, SH_ABORT = 1 << 29, SH_CNT = (1 << 24) - 1;
 #ifndef SH_SYM
 #define SH_SYM 8                                    // the chain forms ½(V + V') itself every SH_SYM-th step (the builder wave does it for the records of the others)
 #endif
+#ifndef SH_RCP1
+#define SH_RCP1 0                                   // 1: one Newton step on 1 / det of the chain's 2x2 gain solve instead of two (A/B)
+#endif
 #ifndef SH_STRAIGHT
 #define SH_STRAIGHT 1                               // 1: no branch inside a chunk of the chain (a failing step is noted, the chunk runs to its end)
 #endif
@@ -75,7 +78,7 @@ constexpr int P_FLAGS = P_PUB + NPB * GCHUNK;
 static_assert(P_PUB % 2 == 0 && P_FLAGS % 2 == 0, "16-byte pieces");
 constexpr int C_SBUF = 0;                                           // NSB chunks of the record stream
 constexpr int EIMG = 4 * 96;                                        // [cx 80 | cu 16] of a chunk for the 4 trajectories of a wave
-constexpr int NEI = 3;                                              // gradient images per affine wave
+constexpr int NEI = NSB;                                            // gradient images per affine wave: freed with the record ring's slots
 constexpr int C_WAVE = NSB * GCHUNK, C_WSZ = NEI * EIMG + 8;        // per affine wave: NEI gradient images (the results overwrite the gradients in place), zero cell, dump cell
 constexpr int C_FLAGS = C_WAVE + NAFF * C_WSZ;
 constexpr int SH_LDS_DOUBLES = (P_FLAGS > C_FLAGS ? P_FLAGS : C_FLAGS) + 48;
@@ -132,9 +135,14 @@ __device__ __forceinline__ int load4_sc1(const int *p)
 // (a store of more than 8 bytes reads its data registers AFTER it has been issued: the next instruction must not overwrite them — a
 // hazard the compiler pads for its own stores and cannot see inside an asm statement.  Round 5 met it: with the address select in front
 // of each store the allocator reused the data registers at once and the LOW DWORDS of some stored k / Vx were those of the next value.)
-__device__ __forceinline__ void store16_nt(void *p, d2 v)
+// NT: non-temporal (the lines do not linger in the L2) or plain.  Measured (profiles/r05_sh_stores.txt): the same at B = 1 024-2 048, plain
+// 12 % faster at B = 32 768 (6.57 vs 7.45 ms: the write-back of full lines from the L2 is what the HBM likes); write-through (sc1) stores
+// triple the time of the small launches.
+template <bool NT>
+__device__ __forceinline__ void store16_res(void *p, d2 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // =============================================================== grouping ====================================================
@@ -374,10 +382,20 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
             F00 = row_bcast<n>(Q0) + lam; F01 = row_bcast<n + 1>(Q0); F11 = row_bcast<n + 1>(Q1) + lam;
         }
         const double det = fma(F00, F11, -(F01 * F01));
-        const double y = rcp_nr(det);
         const double n0 = fma(F11, Q0, -(F01 * Q1)), n1 = fma(F00, Q1, -(F01 * Q0));
+#if SH_RCP1
+        // 1 / det by ONE Newton step folded into the product: K = -(n y0)(2 - det y0), relative error (2^-24.4)^2 = 2^-48.7 (profiles/
+        // microbench/rcp_f64_accuracy.hip) — the dependent chain behind v_rcp_f64 is mul | fma, mul (2 levels) instead of 4 fma + mul
+        const double y0 = __builtin_amdgcn_rcp(det);
+        const double e2 = fma(-det, y0, 2.0);
+        const double Ksel = -(((odd ? n1 : n0) * y0) * e2);
+        const double y = y0 * e2;
+        const double K0 = -(n0 * y), K1 = -(n1 * y);       // (regType 2 only: the compiler drops them otherwise)
+#else
+        const double y = rcp_nr(det);
         const double K0 = -(n0 * y), K1 = -(n1 * y);       // K = -QuuF⁻¹ Qux_reg  (:42)
         const double Ksel = odd ? K1 : K0;
+#endif
         double Tsel, Bop;
         // value update (:69-72): V = G + K'T + Qux'K with T = Quu K + Qux: the rank-4 product [K' Qux'][T; K].
         double Aop;
@@ -464,6 +482,9 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
         });
         if (diverge) { lds_store_flag(&flags[PF_CDIV], diverge); lds_store_flag(&flags[PF_CREADY], (q + 1) | SH_FIN); return; }
         lds_store_flag(&flags[PF_CREADY], q + 1);
+#ifdef SH_PROF
+        if (gidx == 0 && lane == 0 && q >= NCHK - 4) a.ctl->prof[40 + q - (NCHK - 4)] = wall_clock64();
+#endif
     }
     if (NCHK > 1) lds_store_flag(&flags[PF_CREADY], NCHK | SH_FIN);
 #ifdef SH_PROF
@@ -479,6 +500,12 @@ __device__ __forceinline__ void sh_chain(const ShArgs &a, double *sm, const int 
 #else
 #define SH_MARK_MAX(slot)
 #define SH_MARK_MIN(slot)
+#endif
+// time line of the last four chunks (group 0 / its first tile): prof[base + q - (NCHK - 4)] = wall clock
+#ifdef SH_PROF
+#define SH_TL(base, q, nchk, on) do { if ((on) && threadIdx.x % DDP_WAVE == 0 && (q) >= (nchk) - 4 && (q) < (nchk)) a.ctl->prof[(base) + (q) - ((nchk) - 4)] = wall_clock64(); } while (0)
+#else
+#define SH_TL(base, q, nchk, on)
 #endif
 
 template <bool REG2>
@@ -572,6 +599,7 @@ __device__ __forceinline__ void sh_builder(const ShArgs &a, double *sm, const do
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the records are read, the publish buffer is written
         lds_store_flag(&flags[PF_BDONE], q + 1);
         lds_store_flag(&flags[PF_BREADY], (q + 1) | (last ? SH_FIN : 0));
+        SH_TL(44, q, NCHK, true);
         if (last) { SH_MARK_MAX(20); return; }
     }
     // the chain diverged in a chunk it never finished counting: nothing more to build (PF_CREADY carried FIN with have <= q)
@@ -615,6 +643,7 @@ __device__ __forceinline__ void sh_publisher(const ShArgs &a, double *sm, const 
             store16_sc1(dst + 16 * pcc, *(const d2 *)(pb + 2 * pcc));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SH_TL(48, q, NCHK, gidx == 0);
         lds_store_flag(&flags[PF_PDONE], q + 1);                 // the publish buffer is free (its data is in the store queue)
         if (pending) {                                         // everything older than this chunk's 22 stores has left: chunk q - 1 is visible
             asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
@@ -649,6 +678,38 @@ __device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gi
     const int *prog = &a.ctl->progress[16 * gidx];
     int pubd = 0;                                               // progress word as last seen
     const unsigned long long t0 = wall_clock64();
+    // The gradients [cx; cu] of the tile's trajectories come through THIS wave too (round 5).  The affine waves used to fetch their own
+    // by direct-to-LDS loads and wait for them with s_waitcnt vmcnt — a counter their result stores share: with the acknowledgement of a
+    // store taking ~10 us under the launch's 3 TB/s of writes, "at most 3 outstanding" made every chunk wait for the stores of two chunks
+    // before, the tiles ran three chunks (the depth of the ring) behind the chain and ended ~15 us after it.  This wave issues loads only,
+    // so its count is exact: piece P = 64 k + lane of an affine wave's 4 x 48 pieces (trajectory P / 48; L = P % 48 < 40: cx doubles
+    // 2L, 2L + 1 of the chunk, else cu of step L - 40), image q % NEI of that wave, freed with the ring slot of the records.
+    const int cnt = item.z, naff = (cnt + 3) / 4, cTop = (a.N - 1) / CH, st = (a.N - 1) % CH;
+    const char *gsrc[NAFF][3];
+    int pstep[3], gstep[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const int P = 64 * kk + lane, tr = P / 48, L = P % 48;
+        pstep[kk] = L < 40 ? L / 5 : L - 40;
+        gstep[kk] = L < 40 ? CH * n * 8 : CH * m * 8;               // bytes per chunk
+#pragma unroll
+        for (int aw = 0; aw < NAFF; ++aw) {
+            const int tt = 4 * aw + tr, t2 = tt < cnt ? tt : cnt - 1;
+            const int bb = a.perm[item.y + t2];
+            gsrc[aw][kk] = L < 40 ? (const char *)(a.cx + ((size_t)bb * a.N + (size_t)CH * cTop) * n) + 16 * L
+                                  : (const char *)(a.cu + ((size_t)bb * a.N + (size_t)CH * cTop) * m) + 16 * (L - 40);
+        }
+    }
+    auto wait_older_than = [&](int newest) {                    // s_waitcnt vmcnt(22 + 3 naff): the immediate must be a constant
+        switch (newest) {
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break; case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break; case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+        case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break; case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break; case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    static_assert(NAFF <= 8 && 22 + 3 * NAFF <= 63, "vmcnt is a 6-bit counter");
     auto give_up = [&]() {
         for (int t = lane; t < item.z; t += DDP_WAVE) a.fb_active[a.perm[item.y + t]] = 1;
         if (lane == 0) { atomicAdd(&a.ctl->error, 1); atomicAdd(&a.ctl->errors_total, 1); }
@@ -666,6 +727,7 @@ __device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gi
                 __builtin_amdgcn_s_sleep(20);
             }
         }
+        SH_TL(52, q, NCHK, item.y == 0 && gidx == 0);
         // (2) ring slot q % NSB held chunk q - NSB: every user must be past it
         if (q >= NSB) {
             for (;;) {
@@ -684,8 +746,18 @@ __device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gi
                 const int pc = 64 * it + lane;
                 if (pc < GPIECES) __builtin_amdgcn_global_load_lds((glb_void *)(src + 16 * pc), (lds_void *)(dst + 128 * it), 16, 0, 16 /* sc1 */);
             }
-            // everything older than this chunk's 22 loads has landed
-            asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            const int top = q == 0 ? st : CH - 1;                   // (steps past N - 1 are not touched)
+#pragma unroll
+            for (int aw = 0; aw < NAFF; ++aw) {
+                if (aw < naff) {
+                    double *img = sm + C_WAVE + aw * C_WSZ + (q % NEI) * EIMG;
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk)
+                        if (pstep[kk] <= top) __builtin_amdgcn_global_load_lds((glb_void *)(gsrc[aw][kk] - (long)gstep[kk] * q), (lds_void *)(img + 128 * kk), 16, 0, 0);
+                }
+            }
+            // everything older than this chunk's 22 + 3 naff loads has landed
+            wait_older_than(22 + 3 * naff);
             lds_store_flag(&flags[CF_SREADY], q);
         } else {
             lds_store_flag(&flags[CF_KIND + q % NSB], KIND_ZERO);
@@ -710,6 +782,7 @@ __device__ __forceinline__ bool sh_wait_chunk(int *flags, int q, int &seen)
     return true;
 }
 
+template <bool NTS>
 __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int gidx, const int aw, const int4 item)
 {
     const int lane = threadIdx.x % DDP_WAVE, j = lane & 15, r = lane >> 4;
@@ -722,9 +795,9 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
     const int cnt = item.z, tloc = 4 * aw + r, tl = tloc < cnt ? tloc : cnt - 1;
     const bool rowlive = tloc < cnt;
     const int b = a.perm[item.y + tl];
-    // gradient image / result image: piece P = 64 k + lane of the wave's 4 x 48 pieces; trajectory P / 48, piece L = P % 48:
-    // L < 40: cx doubles 2L, 2L + 1 of the chunk (step L / 5), else cu of step L - 40
-    const char *gsrc[3]; char *rdst[3]; bool plive[3]; int pstep[3];
+    // result image (= the gradient image the DMA wave filled, overwritten in place): piece P = 64 k + lane of the wave's 4 x 48 pieces;
+    // trajectory P / 48, piece L = P % 48: L < 40: Vx doubles 2L, 2L + 1 of the chunk (step L / 5), else k of step L - 40
+    char *rdst[3]; bool plive[3]; int pstep[3];
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) {
         const int P = 64 * kk + lane, tr = P / 48, L = P % 48;
@@ -732,21 +805,12 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
         const int bb = a.perm[item.y + t2];
         plive[kk] = tt < cnt;
         pstep[kk] = L < 40 ? L / 5 : L - 40;
-        gsrc[kk] = L < 40 ? (const char *)(a.cx + ((size_t)bb * N + (size_t)CH * cTop) * n) + 16 * L
-                          : (const char *)(a.cu + ((size_t)bb * N + (size_t)CH * cTop) * m) + 16 * (L - 40);
         rdst[kk] = L < 40 ? (char *)(a.Vx + ((size_t)bb * N + (size_t)CH * cTop) * n) + 16 * L
                           : (char *)(a.k + ((size_t)bb * N + (size_t)CH * cTop) * m) + 16 * (L - 40);
     }
     char *const sinkp = (char *)a.sink + 16 * lane;
     const int gstep[3] = {(lane % 48) < 40 ? CH * n * 8 : CH * m * 8, ((64 + lane) % 48) < 40 ? CH * n * 8 : CH * m * 8,
                           ((128 + lane) % 48) < 40 ? CH * n * 8 : CH * m * 8};          // bytes per chunk
-    auto dma_e = [&](int q, int img) {                          // [cx;cu] of chunk q -> image img (steps past N - 1 are not touched)
-        double *dst = eimg + img * EIMG;
-        const int top = q == 0 ? st : CH - 1;
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-            if (pstep[kk] <= top) __builtin_amdgcn_global_load_lds((glb_void *)(gsrc[kk] - (long)gstep[kk] * q), (lds_void *)(dst + 128 * kk), 16, 0, 0);
-    };
     // per-lane offsets inside an image: lane j of row r reads / writes element j of step s at eo + es * s
     const int eo = 96 * r + (j < n ? j : (j < p ? 80 + (j - n) : 0)), es = j < n ? n : (j < p ? m : 0);
     const double *ebase = j < p ? eimg + eo : zcell;            // (image 0; image i is i * EIMG further)
@@ -756,32 +820,17 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
     const int mrow = G_M + MLD * j;
     double s = 0.0, acc1 = 0.0, acc2 = 0.0;
     int seen = 0, gdiv = 0;
-    dma_e(0, 0);
-    dma_e(NCHK > 1 ? 1 : 0, 1);                                 // (always three loads behind the ones a chunk waits for: see below)
     bool ok = true;
     for (int q = 0; q < NCHK; ++q) {
         const int top = q == 0 ? st : CH - 1;
-        // The gradient image of this chunk has landed once at most the three loads issued behind it are outstanding.  vmcnt counts the
-        // wave's stores as well, in no order this code relies on relative to the loads — but loads return in order among themselves, so
-        // "<= 3 outstanding" cannot hold with a load of chunk q pending while the three loads behind it are: safe whatever the stores do.
-        // What the wait COSTS depends on when those loads went out and on what else it forces:
-        //  * round 4 issued the loads of chunk q + 1 at the END of iteration q - 1, behind its stores: every chunk waited a memory latency
-        //    here.  Now they go out at the TOP of iteration q - 1 into a third image and have had a whole iteration.
-        //  * the last chunk had no loads behind it and waited for vmcnt(0) — for the acknowledgement of the result stores of the chunk
-        //    before, ~15 us at the end of a launch that has been writing 3 TB/s (profiles/r05_sh_phase_after.json: the affine waves ended
-        //    16 us after the last chunk had landed).  Now every iteration issues three loads: past the end they re-read the last chunk into
-        //    the image nobody uses any more.
-#ifdef SH_PROF
-        const unsigned long long ta0 = __builtin_readcyclecounter();
-#endif
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 #ifdef SH_PROF
         const unsigned long long ta1 = __builtin_readcyclecounter();
 #endif
-        dma_e(q + 2 < NCHK ? q + 2 : NCHK - 1, (q + 2) % NEI);    // image (q + 2) % 3 held chunk q - 1: its results are in flight from registers
+        // (the chunk's records AND this wave's gradient image come through the tile's DMA wave: one flag says both have landed)
         if (!sh_wait_chunk(flags, q, seen)) { ok = false; break; }
 #ifdef SH_PROF
         const unsigned long long ta2 = __builtin_readcyclecounter();
+        SH_TL(56, q, NCHK, item.y == 0 && aw == 0 && gidx == 0);
 #endif
         const int kind = lds_load_flag(&flags[CF_KIND + q % NSB]);
         const double *sb = sm + C_SBUF + (q % NSB) * GCHUNK;
@@ -825,25 +874,26 @@ __device__ __forceinline__ void sh_affine(const ShArgs &a, double *sm, const int
         for (int kk = 0; kk < 3; ++kk) rv[kk] = *(const d2 *)(res + 128 * kk + 2 * lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) store16_nt((plive[kk] && pstep[kk] <= top) ? rdst[kk] - (long)gstep[kk] * q : sinkp, rv[kk]);
+        for (int kk = 0; kk < 3; ++kk) store16_res<NTS>((plive[kk] && pstep[kk] <= top) ? rdst[kk] - (long)gstep[kk] * q : sinkp, rv[kk]);
         lds_store_flag(&flags[CF_UDONE + aw], q + 1);
+        SH_TL(60, q, NCHK, item.y == 0 && aw == 0 && gidx == 0);
 #ifdef SH_PROF
         if (item.y == 0 && aw == 0 && lane == 0 && q > 0) {       // first tile of group 0: where an affine wave's chunk period goes
             const unsigned long long ta3 = __builtin_readcyclecounter();
-            a.ctl->prof[32] += ta1 - ta0; a.ctl->prof[33] += ta2 - ta1; a.ctl->prof[34] += ta3 - ta2; a.ctl->prof[35] += 1;
+            a.ctl->prof[33] += ta2 - ta1; a.ctl->prof[34] += ta3 - ta2; a.ctl->prof[35] += 1;
             if (ta2 - ta1 < 200) a.ctl->prof[36] += 1;              // chunks that were already there when the wave asked for them
         }
 #endif
     }
-    if (!ok) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_store_flag(&flags[CF_UDONE + aw], 1 << 28); return; }
+    if (!ok) { lds_store_flag(&flags[CF_UDONE + aw], 1 << 28); return; }
     // dV (:68) and diverge of my row's trajectory
     const double d1 = __shfl(acc1, 16 * r + 12) + __shfl(acc2, 16 * r + 13);
     const double d2v = __shfl(acc1, 16 * r + 14) + __shfl(acc2, 16 * r + 15);
     if (rowlive && j == 0) { a.dV[2 * (size_t)b] = d1; a.dV[2 * (size_t)b + 1] = 0.5 * d2v; a.diverge[b] = gdiv; }
     SH_MARK_MAX(24);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the loads past the end still aim at this work-group's LDS)
 }
 
+template <bool NTS>
 __device__ __forceinline__ void sh_writer(const ShArgs &a, double *sm, const int gidx, const int ww, const int4 item)
 {
     const int lane = threadIdx.x % DDP_WAVE;
@@ -879,15 +929,15 @@ __device__ __forceinline__ void sh_writer(const ShArgs &a, double *sm, const int
             char *pV = (char *)(a.Vxx + ((size_t)b * N + c8) * nn), *pK = (char *)(a.K + ((size_t)b * N + c8) * nm),
                  *pQ = (char *)(a.Quu + ((size_t)b * N + c8) * mm);
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) if (gslot[kk] <= top) store16_nt(pV + goff[kk], v[kk]);
-            if (gslot[6] <= top) store16_nt(pK + goff[6], v[6]);
+            for (int kk = 0; kk < 6; ++kk) if (gslot[kk] <= top) store16_res<NTS>(pV + goff[kk], v[kk]);
+            if (gslot[6] <= top) store16_res<NTS>(pK + goff[6], v[6]);
             char *p7 = part == 0 ? pV : (part == 1 ? pK : pQ);
-            if (part < 3 && gslot[7] <= top) store16_nt(p7 + goff[7], v[7]);
+            if (part < 3 && gslot[7] <= top) store16_res<NTS>(p7 + goff[7], v[7]);
         }
     }
 }
 
-template <bool REG2>
+template <bool REG2, bool NTS>
 __global__ __launch_bounds__(SH_THREADS) void sh_back_kernel(ShArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -917,14 +967,26 @@ __global__ __launch_bounds__(SH_THREADS) void sh_back_kernel(ShArgs a)
     if (it >= W) return;
     const int4 item = a.items[it];
     const int naff = (item.z + 3) / 4;
+#ifdef SH_PROF
+    // per-tile end times (the record stream of group 15 is free in a profile run with one group): [4 it + {0 DMA, 1 affine 0, 2 last writer, 3 xcc}]
+    struct TileMark { int *p; bool on; __device__ ~TileMark() { if (on) *p = (int)(wall_clock64() & 0x7fffffffull); } };
+    int *tm = (int *)(a.rec + (size_t)15 * ((a.N - 1) / CH + 1) * GCHUNK) + 4 * it;
+    const bool lane0 = threadIdx.x % DDP_WAVE == 0;
+    TileMark tmk{tm + (wave == 0 ? 0 : (wave == 1 ? 1 : 2)), lane0 && (wave <= 1 || wave == NAFF + 1)};
+    if (threadIdx.x == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); tm[3] = (int)xcc; }
+#endif
     if (wave == 0) sh_dma(a, sm, item.x, NAFF + NWR, item);
     else if (wave <= NAFF) {
-        if (wave - 1 < naff) sh_affine(a, sm, item.x, wave - 1, item);
+        if (wave - 1 < naff) sh_affine<NTS>(a, sm, item.x, wave - 1, item);
         else { int *cf = (int *)(sm + C_FLAGS); if (threadIdx.x % DDP_WAVE == 0) lds_store_flag(&cf[CF_UDONE + wave - 1], 1 << 28); }
-    } else sh_writer(a, sm, item.x, wave - 1 - NAFF, item);
+    } else sh_writer<NTS>(a, sm, item.x, wave - 1 - NAFF, item);
 }
 
 }   // namespace
+
+#ifdef SH_PROF
+static const int *g_sh_dbg = nullptr; static int g_sh_dbg_w = 0;
+#endif
 
 // The most consumer tiles sh_group_kernel can make of a batch of B trajectories on ncu compute units, over every number of groups
 // G = 1 .. SH_GMAX and every grouped count start <= B: it chooses R = ceil(start / (slots TMAX)) rounds of slots = max(ncu - G, 8)
@@ -985,18 +1047,38 @@ int ddp_launch_back_pass_sh(ddp_handle h, const ddp_bp_desc *d, const double *cx
     if (a.B <= 8 * 1024) hipLaunchKernelGGL(sh_group_kernel<true>, dim3(1), dim3(1024), 0, h->stream, a);
     else hipLaunchKernelGGL(sh_group_kernel<false>, dim3(1), dim3(1024), 0, h->stream, a);
     if (!h->sh_attr) {
-        DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
-        DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
+        DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
+        DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
+        DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
+        DDP_HIP(hipFuncSetAttribute((const void *)sh_back_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_LDS_BYTES));
         h->sh_attr = true;
     }
     const dim3 grid(SH_GMAX + Wmax), block(SH_THREADS);
-    if (d->regType == 2) hipLaunchKernelGGL((sh_back_kernel<true>), grid, block, SH_LDS_BYTES, h->stream, a);
-    else hipLaunchKernelGGL((sh_back_kernel<false>), grid, block, SH_LDS_BYTES, h->stream, a);
+    // result stores: non-temporal while the batch is small, plain from DDP_SH_NT_MAX_B trajectories on (default 3 072; store16_res)
+    const char *nte = ddp_env(h, ENV_SH_NT_MAX_B);
+    const bool nts = B < (nte ? atoi(nte) : 3072);
+    if (d->regType == 2) { if (nts) hipLaunchKernelGGL((sh_back_kernel<true, true>), grid, block, SH_LDS_BYTES, h->stream, a); else hipLaunchKernelGGL((sh_back_kernel<true, false>), grid, block, SH_LDS_BYTES, h->stream, a); }
+    else { if (nts) hipLaunchKernelGGL((sh_back_kernel<false, true>), grid, block, SH_LDS_BYTES, h->stream, a); else hipLaunchKernelGGL((sh_back_kernel<false, false>), grid, block, SH_LDS_BYTES, h->stream, a); }
     DDP_HIP(hipGetLastError());
     *fb_active = a.fb_active;
+#ifdef SH_PROF
+    g_sh_dbg = (const int *)(a.rec + (size_t)15 * NCHK * GCHUNK); g_sh_dbg_w = Wmax;
+#endif
     return 0;
 }
 
+#ifdef SH_PROF
+extern "C" int ddp_sh_prof_tiles(ddp_handle h, int *out, int cap)
+{
+    DDP_DEVICE(h);
+    if (!g_sh_dbg) return -1;
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    ShCtl c; DDP_HIP(hipMemcpy(&c, h->sh, sizeof c, hipMemcpyDeviceToHost));
+    const int W = c.W < cap ? c.W : cap;
+    DDP_HIP(hipMemcpy(out, g_sh_dbg, sizeof(int) * 4 * (size_t)W, hipMemcpyDeviceToHost));
+    return W;
+}
+#endif
 // -DSH_PROF builds (profiles/sh_phase_profile.py): the phase sums of the last launch; zeros in the production library
 extern "C" int ddp_sh_prof(ddp_handle h, unsigned long long *out32)
 {

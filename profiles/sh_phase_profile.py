@@ -75,10 +75,34 @@ if f is not None:
                                               "last_tile_has_last_chunk": 10 * (p[23] - p[17]), "last_affine_wave_done": 10 * (p[24] - p[17]),
                                               "last_wave_out": 10 * (p[18] - p[17])}}
         out["chain_ns_per_step_profiled"] = 10 * (p[17] - p[16]) / (N - 1)
+        t_end = p[17]
+        out["last_four_chunks_us_after_chain_end (group 0, its first tile)"] = {
+            name: [round((p[base + c] - t_end) / 100.0, 2) if p[base + c] else None for c in range(4)]
+            for name, base in (("chain: chunk computed", 40), ("builder: chunk built", 44), ("publisher: chunk's stores issued", 48),
+                               ("tile DMA wave: chunk seen published", 52), ("affine wave: chunk (records + gradients) in the LDS", 56),
+                               ("affine wave: chunk's results stored", 60))}
         if p[35]:
             out["affine_wave_ticks_per_chunk (first tile)"] = {"wait for its gradient loads": p[32] / p[35], "wait for the record chunk": p[33] / p[35],
                                                                 "8 steps + result stores": p[34] / p[35], "chunks": p[35],
                                                                 "chunks already there when asked for": p[36]}
     else:
         out["note"] = "library built without -DSH_PROF: no phase sums"
+try:
+    ft = L.ddp_sh_prof_tiles
+except AttributeError:
+    ft = None
+if ft is not None and f is not None:
+    ft.restype = C.c_int
+    tb = (C.c_int * (4 * 1024))()
+    W = ft(h.raw, tb, 1024)
+    if W > 0:
+        t = np.array(list(tb)[: 4 * W]).reshape(W, 4)
+        ce = int(p[17] & 0x7fffffff)
+        rel = (t[:, :3] - ce) / 100.0                            # us after the chain wave's end
+        out["tiles"] = {"count": W, "xcc_of_tiles": {int(x): int((t[:, 3] == x).sum()) for x in np.unique(t[:, 3])}}
+        for k, name in enumerate(("DMA wave done", "first affine wave done", "first writer wave done")):
+            out["tiles"][name + " (us after chain end): min / median / max"] = [round(float(v), 2) for v in (rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max())]
+            out["tiles"][name + " by xcc (median)"] = {int(x): round(float(np.median(rel[t[:, 3] == x, k])), 2) for x in np.unique(t[:, 3])}
+        worst = np.argsort(-rel[:, 1])[:8]
+        out["tiles"]["slowest tiles (index, xcc, DMA, affine, writer)"] = [[int(i), int(t[i, 3])] + [round(float(v), 2) for v in rel[i]] for i in worst]
 print(json.dumps(out, indent=1))
