@@ -319,6 +319,9 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
         if (rp <= 0) return rp;                             // (the launcher names the kernel)
         const int rc = ddp_launch_forward_dpp(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rc <= 0) { h->last_kernel[1] = "forward_dpp_kernel"; return rc; }
+        // every other LQ shape a 16-lane row holds: the row kernel compiled for padded sizes (DDP_FORWARD=group keeps the old path)
+        const int rr = ddp_launch_forward_row(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
+        if (rr <= 0) { h->last_kernel[1] = "forward_row_kernel"; return rr; }
     }
     h->last_kernel[1] = "forward_pass_kernel";
     FPArgs a;

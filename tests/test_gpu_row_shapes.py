@@ -151,3 +151,97 @@ def test_row_kernel_full_size_off_shapes(ddp):
         assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
         who = sorted({0, 1, 2, 3, B - 1, B - 2} | set(int(v) for v in rng.integers(0, B, 18)))
         _check(ddp, out, args, 0.1, 1, L, False, who=who)
+
+
+# ------------------------------------------------------------------------------------------------------------------ forward_pass
+FSHAPES = [(1, 1), (2, 1), (3, 2), (4, 3), (5, 2), (6, 2), (6, 3), (7, 4), (8, 1), (9, 2), (10, 4), (11, 3), (12, 2), (12, 4), (13, 1), (14, 2)]
+
+
+def _lq(rng, n, m, N, B, ltv, batched):
+    import scipy.linalg as sla
+    A0 = rng.standard_normal((n, n))
+    A = sla.expm(0.1 * (A0 - A0.T)) * 0.99
+    Bm = 0.2 * rng.standard_normal((n, m))
+    q = rng.standard_normal((n, n)); Q = 0.1 * (q @ q.T / n + 0.3 * np.eye(n))          # FULL Q, R: the separate cost kernel
+    r = rng.standard_normal((m, m)); R = 0.05 * (r @ r.T / m + 0.3 * np.eye(m))
+    shape = ((N,) if ltv else ()) + ((B,) if batched else ())
+    if shape:
+        A = np.ascontiguousarray(A.reshape(n, n, *([1] * len(shape))) * (1 + 0.02 * rng.standard_normal((1, 1) + shape)))
+        Bm = np.ascontiguousarray(Bm.reshape(n, m, *([1] * len(shape))) * (1 + 0.05 * rng.standard_normal((1, 1) + shape)))
+    return A, Bm, Q, R
+
+
+@pytest.mark.parametrize("n,m", FSHAPES)
+def test_forward_row_kernel_every_shape_vs_oracle(ddp, n, m):
+    """src/forward_pass.jl:9-33 at sizes no exact kernel exists for: closed-loop rollouts of 7 step sizes with limits, the initial
+    rollout (empty policy), LTI and LTV dynamics, on the padded row kernel; every rollout against the C oracle"""
+    from ddp_amd import _lib
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(77 * n + m)
+    N, B = 29, 6
+    alphas = 10.0 ** np.linspace(0, -3, 7)
+    L = np.stack([-0.4 * np.ones(m), 0.5 * np.ones(m)], 1)
+    for ltv in (False, True):
+        A, Bm, Q, R = _lq(rng, n, m, N, B, ltv, False)
+        prob = ddp.LQProblem(A, Bm, Q, R)
+        po = oc.make_problem("lq", n, m, N, A=A, B=Bm, Q=Q, R=R)
+        x0 = rng.standard_normal((n, B)); u = 0.3 * rng.standard_normal((m, N, B))
+        K = 0.2 * rng.standard_normal((m, n, N, B)); k = 0.1 * rng.standard_normal((m, N, B))
+        x, _, _ = ddp.forward_pass(ddp.GaussianPolicy(), x0, u, None, 1.0, prob, None)
+        if not (n == 10 and m == 2):
+            assert _lib.default_handle().last_kernel(1) == "forward_row_kernel"
+        for b in range(B):
+            xr, ur, cr = oc.forward_pass(po, None, x0[:, b], u[..., b], None, 1.0, None)
+            assert relerr(x[..., b], xr) < 1e-10
+        for lims in (None, L):
+            pol = ddp.GaussianPolicy(N, n, m, K, k)
+            xn, un, cn = ddp.forward_pass(pol, x0, u, x, alphas, prob, lims)
+            for b in range(B):
+                for ai, al in enumerate(alphas):
+                    xr, ur, cr = oc.forward_pass(po, (K[..., b], k[..., b]), x0[:, b], u[..., b], x[..., b], float(al), lims)
+                    assert relerr(xn[..., b, ai], xr) < RTOL and relerr(un[..., b, ai], ur) < RTOL and relerr(cn[:, b, ai], cr) < RTOL, (n, m, ltv, b, ai)
+
+
+@pytest.mark.parametrize("n,m", [(5, 2), (12, 3)])
+def test_forward_row_kernel_agrees_with_the_group_kernel(ddp, n, m):
+    """the run-time-sized kernel (DDP_FORWARD=group) on the same rollouts, per-trajectory time-varying dynamics, inactive trajectories"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(5 * n + m)
+    N, B = 33, 9
+    A, Bm, Q, R = _lq(rng, n, m, N, B, True, True)
+    prob = ddp.LQProblem(A, Bm, Q, R, dyn_batched=True)
+    x0 = rng.standard_normal((n, B)); u = 0.3 * rng.standard_normal((m, N, B))
+    K = 0.2 * rng.standard_normal((m, n, N, B)); k = 0.1 * rng.standard_normal((m, N, B))
+    x, _, _ = ddp.forward_pass(ddp.GaussianPolicy(), x0, u, None, 1.0, prob, None)
+    pol = ddp.GaussianPolicy(N, n, m, K, k)
+    al = np.array([1.0, 0.3, 0.01])
+    got = ddp.forward_pass(pol, x0, u, x, al, prob, None)
+    assert _lib.default_handle().last_kernel(1) == "forward_row_kernel"
+    os.environ["DDP_FORWARD"] = "group"
+    try:
+        ref = ddp.forward_pass(pol, x0, u, x, al, prob, None)
+        assert _lib.default_handle().last_kernel(1) == "forward_pass_kernel"
+    finally:
+        del os.environ["DDP_FORWARD"]
+        _lib.default_handle().raw
+    for a_, b_ in zip(got, ref):
+        assert relerr(a_, b_) < 1e-11
+
+
+@pytest.mark.parametrize("n,m", [(6, 2), (12, 3)])
+def test_ilqg_solves_at_an_off_shape_match_the_oracle(ddp, n, m):
+    """whole iLQG solves (src/iLQG.jl:143-341) of an LQ problem of demo_linear's recipe at (n, m): both passes on the row kernels"""
+    from oracle import np_restatement as npr
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(900 + n)
+    N, B = 60, 5
+    P = npr.make_lq_problem(rng, n=n, m=m, T=N)
+    prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B)); u0 = 0.1 * rng.standard_normal((m, N, B))
+    x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(prob, x0, u0)
+    po = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=P["Q"], R=P["R"])
+    for b in range(B):
+        xr, ur, (Kr, kr, Quur), Vxr, Vxxr, cr, info = oc.ilqg(po, x0[:, b], u0[:, :, b])
+        assert int(tr["stats"][0, b]) == info["status"] and abs(int(tr["stats"][1, b]) - info["iter"]) <= 1
+        for got, ref in ((x[..., b], xr), (u[..., b], ur), (cost[:, b], cr)):
+            assert relerr(got, ref) < 1e-7
