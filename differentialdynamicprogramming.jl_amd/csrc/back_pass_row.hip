@@ -11,7 +11,8 @@
 //   the m x m system is factorised by the run-time-sized routines of boxqp_dev.h (the ones the general kernel uses), so the padded
 //   control dimensions never enter the Cholesky or the boxQP — iteration counts and result codes are those of the actual m;
 //   the operands are addressed with run-time strides (0 for time-invariant ones: the kernel re-reads them every step, from the L2;
-//   one instantiation serves the LTI, LTV / TI-cost and LTV / TV-cost methods :217, :162, :179), results are stored with the actual n, m.
+//   one instantiation serves the LTI, LTV / TI-cost and LTV / TV-cost methods :217, :162, :179 — a variant that loads time-invariant
+//   operands once was measured SLOWER, 1.44 vs 1.28 ms at n = 6, m = 2, N = 1000, B = 4096, and dropped), results are stored with the actual n, m.
 // Arithmetic per step as back_pass_dpp.hip (same statement order for the actual entries; the padded ones contribute exact zeros).
 #include <type_traits>
 #include "ddp_internal.h"
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
     double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b, *Quug = a.Quu + mm * N * b,
            *Vxg = a.Vx + (size_t)n * N * b, *Vxxg = a.Vxx + nn * N * b;
     const double lam = a.lambda[b];
-    const bool reg2 = a.regType == 2;
+    const bool reg2 = a.regType == 2, mfull = m == MP;
     bool nolims = true;
     double limlo[MP], limhi[MP];
     if (LIMS) {
@@ -247,8 +248,9 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
 #pragma unroll
             for (int q = 0; q < MP * MP; ++q) R[q] = 0.0;
             if (!LIMS || nolims) {
-                fail = chol_masked_ri<MP>(m, H, 0u, R, ri);              // cholesky(Hermitian(QuuF))  (:35)
-                chol_solve_ri<MP>(m, R, ri, kk);
+                // (m == MP, the usual case, as a literal: the run-time-sized routines then fold their `i < m` tests away)
+                if (mfull) { fail = chol_masked_ri<MP>(MP, H, 0u, R, ri); chol_solve_ri<MP>(MP, R, ri, kk); }   // cholesky(Hermitian(QuuF))  (:35)
+                else { fail = chol_masked_ri<MP>(m, H, 0u, R, ri); chol_solve_ri<MP>(m, R, ri, kk); }
 #pragma unroll
                 for (int q = 0; q < MP; ++q) kk[q] = -kk[q];             // k_i = -(R\Qu)  (:41)
             } else {
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
                     result = boxqp_dev1(H[0], Qu[0], lo[0], up[0], kprev[0], qpo, kk[0], rH1, clamped, iters);
                     use_rh = true;
                 } else {
-                    result = boxqp_dev_ri<MP>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);        // (:49)
+                    result = mfull ? boxqp_dev_ri<MP>(MP, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters)        // (:49)
+                                   : boxqp_dev_ri<MP>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);
                 }
                 fail = (result < 1);                                     // (:53)
             }
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
             } else {
 #pragma unroll
                 for (int q = 0; q < MP; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : gr[q];
-                chol_solve_ri<MP>(m, R, ri, Kc);
+                if (mfull) chol_solve_ri<MP>(MP, R, ri, Kc); else chol_solve_ri<MP>(m, R, ri, Kc);
 #pragma unroll
                 for (int q = 0; q < MP; ++q) Kc[q] = ((clamped >> q) & 1u) ? 0.0 : -Kc[q];
             }

@@ -180,7 +180,7 @@ def off_shape(tag, n, m, N, B, ltv, lims):
     prob._keep = (dA, dB)
     x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B))
     u0 = 0.1 * rng.standard_normal((m, N, B))
-    L_ = None if not lims else 0.05 * np.stack([-np.ones(m), np.ones(m)], 1)
+    L_ = None if not lims else float(os.environ.get("DDP_OFF_LIMS", "0.05")) * np.stack([-np.ones(m), np.ones(m)], 1)
     run("%s n=%d m=%d %s%s" % (tag, n, m, "LTV per-trajectory dynamics" if ltv else "LTI", " lims" if lims else ""), prob, n, m, N, B, f64(x0), f64(u0),
         L_, 1, fxd)
 
@@ -343,4 +343,4 @@ if __name__ == "__main__":
     if "offA" in which:
         off_shape("offA", 12, 3, 500, 2048, True, False)
     if "offB" in which:
-        off_shape("offB", 6, 2, 1000, 4096, False, True)
+        off_shape("offB", 6, 2, 1000, 4096, False, os.environ.get("DDP_OFF_NOLIMS") != "1")
