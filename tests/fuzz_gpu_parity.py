@@ -19,8 +19,16 @@ def spd(rng, d, s):
     return s * (a @ a.T / d + 0.5 * np.eye(d))
 
 
-def gen_case(rng):
-    n, m = [(10, 2), (4, 1), (6, 3), (64, 8), (7, 2), (12, 4), (40, 4), (37, 3), (51, 2)][rng.integers(0, 9)]
+# every (n, m) the padded row kernels (csrc/back_pass_row.hip, forward_pass_row.hip) hold: n <= 14, m <= 4, n + m <= 15 and their table of
+# padded sizes — the sweep of round 5 draws from these with the row kernel forced, dispatched by default, or the run-time-sized kernel
+ROW_SHAPES = [(n_, m_) for n_ in range(1, 15) for m_ in range(1, 5) if n_ + m_ <= 15 and not (n_ > 12 and m_ > 1) and not (n_ > 10 and m_ > 3)]
+ROW_IMPLS = [None, None, "row", "row", "general"]
+
+
+def gen_case(rng, shapes=None, impls=None):
+    default_shapes = [(10, 2), (4, 1), (6, 3), (64, 8), (7, 2), (12, 4), (40, 4), (37, 3), (51, 2)]
+    shapes = shapes or default_shapes
+    n, m = shapes[rng.integers(0, len(shapes))]
     big = rng.integers(0, 6) == 0                                 # now and then a long horizon / several waves
     N = (int(rng.integers(1, 300 if big else 40))) if n < 40 else int(rng.integers(2, 50 if big else 14))
     if rng.integers(0, 3) == 0:
@@ -51,7 +59,8 @@ def gen_case(rng):
         cuu[:, :, int(rng.integers(0, N - 1)), int(rng.integers(0, B))] = -np.eye(m)
     Q, R = spd(rng, n, h), spd(rng, m, 0.1 * h)
     x0 = rng.standard_normal((n, B)); xnom = rng.standard_normal((n, N, B))
-    impl = [None, None, None, "x", "dpp", "dpp", "general", "big", "q"][rng.integers(0, 9)]     # forced kernel (falls back when it has no such shape)
+    impls = impls or [None, None, None, "x", "dpp", "dpp", "general", "big", "q"]
+    impl = impls[rng.integers(0, len(impls))]                      # forced kernel (falls back when it has no such shape)
     return dict(impl=impl, n=n, m=m, N=N, B=B, fx_tv=fx_tv, fx_b=fx_b, c_tv=c_tv, regType=regType, lims=lims, fx=fx, fu=fu, cxx=cxx, cuu=cuu, cxu=cxu,
                 cx=cx, cu=cu, u=u, lam=lam, Q=Q, R=R, x0=x0, xnom=xnom)
 
@@ -74,8 +83,8 @@ def escape_counts():
                 knife_edge=getattr(ilqg_case, "knife_edge", 0), exploded_kl_draws=getattr(gps_case, "skipped", 0))
 
 
-def one_case(ddp, oc, rng, case):
-    c = gen_case(rng)
+def one_case(ddp, oc, rng, case, shapes=None, impls=None):
+    c = gen_case(rng, shapes, impls)
     n, m, N, B, lims = c["n"], c["m"], c["N"], c["B"], c["lims"]
     tag = (case, {k: c[k] for k in ("n", "m", "N", "B", "fx_tv", "fx_b", "c_tv", "regType", "impl")}, "lims" if lims is not None else "no lims")
     os.environ.pop("DDP_BACKPASS", None)

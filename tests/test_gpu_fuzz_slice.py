@@ -47,6 +47,18 @@ def test_fuzz_pass_cases(fz, chunk):
     assert worst < mod.RTOL
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_fuzz_row_kernel_cases(fz, chunk):
+    """the same sweep over EVERY (n, m) the padded row kernels hold (n <= 14, m <= 4: 45 pairs), with the row kernel forced, dispatched by
+    default, or the run-time-sized kernel: back_pass + 1..11 rollouts per case against the oracle (round 5: the shape range)"""
+    mod, ddp = fz
+    from oracle import oracle_ctypes as oc
+    worst = 0.0
+    for c in range(100 * chunk, 100 * (chunk + 1)):
+        worst = max(worst, mod.one_case(ddp, oc, np.random.default_rng([SEED, 500000 + c]), c, shapes=mod.ROW_SHAPES, impls=mod.ROW_IMPLS))
+    assert worst < mod.RTOL
+
+
 def test_fuzz_ilqg_solves(fz):
     mod, ddp = fz
     from oracle import oracle_ctypes as oc
