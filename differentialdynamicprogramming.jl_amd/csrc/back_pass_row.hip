@@ -95,6 +95,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
 #pragma unroll
     for (int q = 0; q < MP; ++q) mq[q] = q < m ? 1.0 : 0.0;
     const double zF = (inx || inu) ? 1.0 : 0.0, zx = inx ? 1.0 : 0.0;
+    double mF[NP], mX[NP], mC[MP];                                   // ... combined with the lane's role
+#pragma unroll
+    for (int r = 0; r < NP; ++r) { mF[r] = zF * mrow[r]; mX[r] = zx * mrow[r]; }
+#pragma unroll
+    for (int q = 0; q < MP; ++q) mC[q] = zF * mq[q];
     int rcl[NP], qcl[MP];                                            // clamped row indices: the loads of padded rows re-read a valid one
 #pragma unroll
     for (int r = 0; r < NP; ++r) rcl[r] = r < n ? r : n - 1;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
     };
     auto mask_F = [&](double (&F)[NP], const double (&raw)[NP]) {
 #pragma unroll
-        for (int r = 0; r < NP; ++r) F[r] = (zF * mrow[r]) * raw[r];
+        for (int r = 0; r < NP; ++r) F[r] = mF[r] * raw[r];
     };
     auto load_C = [&](int i, double (&cc)[NP], double (&c2)[MP]) {   // x-lanes: cxx[:, j], cxu[j, :]; u-lanes: cuu[:, j-n]
 #pragma unroll
@@ -119,9 +124,9 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
     };
     auto mask_C = [&](double (&cc)[NP], double (&c2)[MP], const double (&rawc)[NP], const double (&raw2)[MP]) {
 #pragma unroll
-        for (int r = 0; r < NP; ++r) cc[r] = (zx * mrow[r]) * rawc[r];
+        for (int r = 0; r < NP; ++r) cc[r] = mX[r] * rawc[r];
 #pragma unroll
-        for (int q = 0; q < MP; ++q) c2[q] = (zF * mq[q]) * raw2[q];
+        for (int q = 0; q < MP; ++q) c2[q] = mC[q] * raw2[q];
     };
     double Fcol[NP], cxxcol[NP], ccol[MP], Vcol[NP], vj;
     {   // terminal step (backward_pass.jl:234-236 / :197-199)
@@ -214,18 +219,18 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
             // ================= P2: g = F'·w  (column j of G = F'VxxF) ===================================
             double g[PP];
 #pragma unroll
-            for (int r = 0; r < PP; ++r) g[r] = 0.0;
+            for (int r = 0; r < NP; ++r) g[r] = cxxcol[r];               // the sums start at the cost terms of Qxx / Qux | Quu (:242-244): no zero fill, no add behind
+#pragma unroll
+            for (int q = 0; q < MP; ++q) g[NP + q] = ccol[q];
             dpp_fence(w);
             static_for<0, NP>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 static_for<0, PP>([&](auto ic) { constexpr int ii = decltype(ic)::value; fmac_bc<ii>(g[ii], Fcol[k], w[k]); });
             });
-#pragma unroll
-            for (int r = 0; r < NP; ++r) g[r] += cxxcol[r];              // Qxx[:, j]           (:244)
             double gu[MP], gr[MP];                                       // x-lanes: Qux[:, j]; u-lanes: Quu[:, j-n]
 #pragma unroll
             for (int q = 0; q < MP; ++q) {
-                gu[q] = g[NP + q] + ccol[q];                             // (:242-243)
+                gu[q] = g[NP + q];                                       // (:242-243)
                 gr[q] = gu[q] + (reg2 ? lam * FuF[q] : ((j == NP + q) ? lam : 0.0));     // Qux_reg / QuuF (:246-247)
             }
             // ================= P3: gains ==================================================================
@@ -296,15 +301,16 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
                 for (int q = 0; q < MP; ++q) { dV0 += kk[q] * Qu[q]; dV1 += 0.5 * kk[q] * Quuk[q]; }
             }
             // ================= P4: value update (:69-72) ===================================================
-            double P1a[NP], P2a[NP];
+            // ½(K'Y + Y'K) accumulates on g with the halves on Y (:70-72 before the symmetrisation of the stored value)
+            double hY[MP];
 #pragma unroll
-            for (int r = 0; r < NP; ++r) { P1a[r] = 0.0; P2a[r] = 0.0; }
+            for (int q = 0; q < MP; ++q) hY[q] = 0.5 * Y[q];
             dpp_fence(Kc);
-            dpp_fence(Y);
+            dpp_fence(hY);
             static_for<0, MP>([&](auto ac) {
                 constexpr int aa = decltype(ac)::value;
-                static_for<0, NP>([&](auto ic) { constexpr int ii = decltype(ic)::value; fmac_bc<ii>(P1a[ii], Kc[aa], Y[aa]); });
-                static_for<0, NP>([&](auto ic) { constexpr int ii = decltype(ic)::value; fmac_bc<ii>(P2a[ii], Y[aa], Kc[aa]); });
+                static_for<0, NP>([&](auto ic) { constexpr int ii = decltype(ic)::value; fmac_bc<ii>(g[ii], Kc[aa], hY[aa]); });
+                static_for<0, NP>([&](auto ic) { constexpr int ii = decltype(ic)::value; fmac_bc<ii>(g[ii], hY[aa], Kc[aa]); });
             });
             double vx = qj;                                              // Vx_i[j] (:69)
 #pragma unroll
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
             double vnew[NP];
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
-                vnew[r] = zx * (g[r] + 0.5 * (P1a[r] + P2a[r]));         // Qxx + ½(S+S'); exact zeros outside the n x n block
+                vnew[r] = zx * g[r];                                     // Qxx + ½(S+S'); exact zeros outside the n x n block
                 if (j < NP) tb0[j * LD + r] = vnew[r];
             }
             // the recursion continues with the SYMMETRISED value like the reference (:71-72), read back as row j of the buffer
