@@ -53,6 +53,8 @@ for rep in range(2):
 st_q = stats_of(o_q[8], P)
 print("queue: %d problems through %d slots: %.3f s, %d global iterations, iterations per solve median %d max %d, status %s"
       % (P, S, tq, git.value, np.median(st_q[1]), st_q[1].max(), dict(zip(*np.unique(st_q[0].astype(int), return_counts=True)))))
+if os.environ.get('DDP_QUEUE_ONLY') == '1':
+    sys.exit(0)
 # lock-step batches of S
 dpb = dev_problem(S)
 o_b = outs(S)
