@@ -139,6 +139,8 @@ device_count() = Int(@ccall libddp.ddp_device_count()::Cint)
 reload_env(h::Handle=default_handle()) = check(@ccall libddp.ddp_reload_env(h.ptr::Ptr{Cvoid})::Cint)
 "kernel of the last back_pass (0) / forward_pass (1) dispatch of the handle (debug query)"
 last_kernel(which::Integer=0; handle::Handle=default_handle()) = unsafe_string(@ccall libddp.ddp_last_kernel(handle.ptr::Ptr{Cvoid}, which::Cint)::Cstring)
+# tiles of the shared-operand backward pass that gave their trajectories to the per-trajectory kernels after a timed-out wait (0 in a healthy run)
+sh_timeouts(; handle::Handle=default_handle()) = Int(@ccall libddp.ddp_sh_timeouts(handle.ptr::Ptr{Cvoid})::Cint)
 
 """
     result_array(dims...) -> Array{Float64}
