@@ -27,6 +27,7 @@ struct BPRArgs {
     const int32_t *active;
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
     int32_t *diverge;
+    double *sink;                                   // >= 64 x 8 B that lanes without an output write to: no exec-mask branch around a store
 };
 
 template <int L>
@@ -191,20 +192,36 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
         int prev_i = 0;
         // ½(V + V') from the transpose buffer, element e = j + 16 s of the n x n result per lane: whole 128-byte runs per row
         constexpr int NE = (NP * NP + G - 1) / G;
-        int oA[NE], oB[NE];
+        // (elements past the end of the n x n result repeat its last one: a duplicate store of the same value instead of a masked store)
+        constexpr int SURE = NP > 4 ? ((NP - 1) * (NP - 1)) / G : 0;     // s < SURE: every lane's element exists whatever n in (NP - 2, NP] is
+        int oA[NE], oB[NE], oE[NE];
 #pragma unroll
         for (int s4 = 0; s4 < NE; ++s4) {
-            const int e = j + G * s4, ee = e < (int)nn ? e : 0, c = ee / n, r = ee % n;
-            oA[s4] = c * LD + r; oB[s4] = r * LD + c;
+            const int e = j + G * s4, ee = e < (int)nn ? e : (int)nn - 1, c = ee / n, r = ee % n;
+            oA[s4] = c * LD + r; oB[s4] = r * LD + c; oE[s4] = 8 * (ee - j);
         }
-        auto store_sym = [&](const double *tbuf, int istep) __attribute__((always_inline)) {
+        // Stores without exec-mask branches (a save-exec / branch / restore costs a lone wave ~25 cycles, and there were ~20 per step): every
+        // lane has ONE role — x-lane: K_i[:, j] and Vx_i[j]; u-lane: Quu_i[:, j - n]; the spare lane: k_i — and a running byte pointer for it
+        // that steps back one time step per step; lanes without a role (and rows of switched-off trajectories) point at the sink with stride 0.
+        char *const sinkp = (char *)a.sink + 8 * lane;
+        const bool role = act && (inx || inu || ink);
+        unsigned long long pS = (unsigned long long)(role ? (inx ? (char *)(Kg + nm * (size_t)(N - 2) + (size_t)m * j) : inu ? (char *)(Quug + mm * (size_t)(N - 2) + (size_t)m * ja) : (char *)(kg + (size_t)m * (N - 2))) : sinkp);
+        const unsigned long long sS = role ? 8ull * (inx ? nm : inu ? mm : (size_t)m) : 0ull;
+        unsigned long long pX = (unsigned long long)((act && inx) ? (char *)(Vxg + (size_t)n * (N - 2) + j) : sinkp);
+        const unsigned long long sX = (act && inx) ? 8ull * n : 0ull;
+        // ½(V + V'): element e = j + 16 s of the step at pV + 128 s bytes (pV points at element j)
+        unsigned long long pV = (unsigned long long)(act ? (char *)(Vxxg + nn * (size_t)(N - 2) + j) : sinkp);
+        const unsigned long long sV = act ? 8ull * nn : 0ull;
+        typedef __attribute__((address_space(1))) double gdbl;
+        auto store_sym = [&](const double *tbuf) __attribute__((always_inline)) {      // the step pV points at
 #pragma unroll
             for (int s4 = 0; s4 < NE; ++s4) {
-                const int e = j + G * s4;
-                if (e < (int)nn) Vxxg[nn * istep + e] = 0.5 * (tbuf[oA[s4]] + tbuf[oB[s4]]);
+                const double v = 0.5 * (tbuf[oA[s4]] + tbuf[oB[s4]]);
+                if (s4 < SURE) *(gdbl *)(pV + 128 * s4) = v;
+                else *(gdbl *)(pV + (unsigned long long)(long)oE[s4]) = v;
             }
+            pV -= sV;
         };
-
         auto step = [&](int i, int d) __attribute__((always_inline)) {
             // ================= P1: w = Vxx·F[:,j],  q = c + F[:,j]'Vx ==================================
             double w[NP], qj = 0.0;
@@ -315,27 +332,17 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
             double vx = qj;                                              // Vx_i[j] (:69)
 #pragma unroll
             for (int q = 0; q < MP; ++q) vx += Kc[q] * (Quuk[q] + Qu[q]) + gu[q] * kk[q];
-            if (act) {
-                if (inx) {
 #pragma unroll
-                    for (int q = 0; q < MP; ++q) if (q < m) Kg[nm * i + (size_t)m * j + q] = Kc[q];          // (:76)
-                    Vxg[(size_t)n * i + j] = vx;
-                }
-                if (inu) {
-#pragma unroll
-                    for (int q = 0; q < MP; ++q) if (q < m) Quug[mm * i + (size_t)m * ja + q] = gu[q];
-                }
-                if (ink) {
-#pragma unroll
-                    for (int q = 0; q < MP; ++q) if (q < m) kg[(size_t)m * i + q] = kk[q];                    // (:75)
-                }
-            }
+            for (int q = 0; q < MP; ++q)
+                if (q < m) *(gdbl *)(pS + 8 * q) = inx ? Kc[q] : (inu ? gu[q] : kk[q]);                    // (:75-76), Quu_i
+            *(gdbl *)pX = vx;
+            pS -= sS; pX -= sX;
             double *tb0 = &tr[grp][i & 1][0], *tb1 = &tr[grp][(i + 1) & 1][0];
-            if (have_prev && act) store_sym(tb1, prev_i);
+            if (have_prev) store_sym(tb1);
             double vnew[NP];
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
-                vnew[r] = zx * g[r];                                     // Qxx + ½(S+S'); exact zeros outside the n x n block
+                vnew[r] = g[r];                                          // Qxx + ½(S+S'): a padded x-lane holds exact zeros by itself (its F, cxx, K, Y are zero)
                 if (j < NP) tb0[j * LD + r] = vnew[r];
             }
             // the recursion continues with the SYMMETRISED value like the reference (:71-72), read back as row j of the buffer
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
         for (int d = 0; d < D; ++d) {
             if (i0 - d >= 0) step(i0 - d, d);
         }
-        if (have_prev && act) store_sym(&tr[grp][prev_i & 1][0], prev_i);
+        if (have_prev) store_sym(&tr[grp][prev_i & 1][0]);
         if (diverge && act) {                                            // outputs earlier in time than a failing step are zero (:37-38 with :226-229)
             const size_t ie = (size_t)diverge;
             for (size_t e = j; e < nm * ie; e += G) Kg[e] = 0.0;
@@ -422,6 +429,8 @@ int ddp_launch_back_pass_row(ddp_handle h, const ddp_bp_desc *d, const double *c
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.lims = lims;
     a.u = u; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    a.sink = (double *)h->sink;
+    if (!a.sink) return 1;
     const int np = n <= 4 ? 4 : (n + 1) & ~1;
     if (np > 8) return ddp_launch_back_pass_row_hi(h, d, &a);
     const int mp = m <= 2 ? m : 4;
