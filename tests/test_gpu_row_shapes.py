@@ -245,3 +245,33 @@ def test_ilqg_solves_at_an_off_shape_match_the_oracle(ddp, n, m):
         assert int(tr["stats"][0, b]) == info["status"] and abs(int(tr["stats"][1, b]) - info["iter"]) <= 1
         for got, ref in ((x[..., b], xr), (u[..., b], ur), (cost[:, b], cr)):
             assert relerr(got, ref) < 1e-7
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 9])
+@pytest.mark.parametrize("n,m", [(3, 2), (7, 3), (12, 2)])
+def test_row_kernels_short_horizons(ddp, n, m, N):
+    """N = 1 (only the terminal step, backward_pass.jl:21-23), N = 2 .. 9: shorter than the prefetch rings and the unrolled groups of both
+    row kernels; B = 1 and B = 5 (one wave with idle rows / two waves)"""
+    from ddp_amd import _lib
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(1000 * n + 10 * m + N)
+    for B in (1, 5):
+        args = _problem(rng, n, m, N, B, "ltv")
+        cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+        L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
+        for lims in (None, L):
+            out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.2, 1, lims, x, u)
+            assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+            _check(ddp, out, args, 0.2, 1, lims, False)
+        A, Bm, Q, R = _lq(rng, n, m, N, B, True, False)
+        prob = ddp.LQProblem(A, Bm, Q, R)
+        po = oc.make_problem("lq", n, m, N, A=A, B=Bm, Q=Q, R=R)
+        x0 = rng.standard_normal((n, B)); uu = 0.3 * rng.standard_normal((m, N, B))
+        K = 0.2 * rng.standard_normal((m, n, N, B)); k = 0.1 * rng.standard_normal((m, N, B))
+        xr0, _, _ = ddp.forward_pass(ddp.GaussianPolicy(), x0, uu, None, 1.0, prob, None)
+        xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(N, n, m, K, k), x0, uu, xr0, np.array([1.0, 0.1]), prob, L)
+        assert _lib.default_handle().last_kernel(1) == "forward_row_kernel"
+        for b in range(B):
+            for ai, al in enumerate((1.0, 0.1)):
+                xr, ur, cr = oc.forward_pass(po, (K[..., b], k[..., b]), x0[:, b], uu[..., b], xr0[..., b], al, L)
+                assert relerr(xn[..., b, ai], xr) < RTOL and relerr(un[..., b, ai], ur) < RTOL and relerr(cn[:, b, ai], cr) < RTOL
