@@ -758,6 +758,10 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         const int rc = ddp_launch_back_pass_row(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_row_kernel"; return rc; }
     }
+    if (force == 0 || force == 'm') {                             // 14 < n <= 32 (or m > 4): one wave per trajectory on the matrix cores, LDS operands
+        const int rc = ddp_launch_back_pass_mid(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mid_kernel"; return rc; }
+    }
     h->last_kernel[0] = "back_pass_kernel";
     BPArgs a = {};
     a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;

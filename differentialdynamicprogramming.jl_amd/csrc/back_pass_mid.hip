@@ -1,0 +1,355 @@
+// back_pass_mid.hip — backward pass for the shapes between the 16-lane rows (n <= 14) and the n = 64 matrix-core kernel:
+// any n <= 32, m <= 8 (src/backward_pass.jl:162-252 + :28-79), ONE wave per trajectory, the three products of a step on
+// v_mfma_f64_16x16x4 with their operands in the LDS.  Before this file these shapes ran on the 64-lane vector kernel of back_pass.hip
+// (n = 24, m = 4, N = 300, B = 1 024 with per-trajectory dynamics: 11.5 ms, 0.04 of HBM; n = 32, m = 8: 58 ms).
+//
+// Padded sizes: NR = 16 NTR >= n rows / contraction length (NTR = 1, 2), PC = 16 PT >= n + m + 1 columns (PT = 2, 3); the LDS images are
+// zero outside the actual n, m, so every product over the padded range adds exact zeros.  Per step:
+//   W  = Vxx F            NTR x PT tiles, NR / 4 k-steps (A: Vs, B: Fs)                       (:165 / :203 / :240, the products with Vxx)
+//   Ws[:, p] := Vx        the column behind the last one of F, so that
+//   G  = F' [W | Vx] + [H | c]   PT x PT tiles: Qxx, Qux, Quu and, in column p, Qx and Qu     (:165-169 / :203-210 / :240-244)
+//   gains                 every lane factorises QuuF (run-time-sized routines of boxqp_dev.h, as the vector kernel), lane c solves column c of K
+//   Vxx_i = Qxx + ½(K'Y + Y'K), Y = Quu K + 2 Qux     rank-2m update on the xx tiles: 4 NTR² more products (:69-72), then ½(V + V') exactly
+// Operands with run-time strides (one instantiation for the LTI / LTV / TV-cost methods).  Accumulator layout of the instruction:
+// register r of lane (l4, l15) holds row 4r + l4, column l15 of a tile; A operand lane = A[i = l15][k = l4], B = B[k = l4][j = l15].
+#include "ddp_internal.h"
+#include "boxqp_dev.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct BPMidArgs {
+    int n, m, N, B, regType;
+    long fx_t, fx_b, fu_t, fu_b, cxx_t, cxx_b, cxu_t, cxu_b, cuu_t, cuu_b;      // element strides per time step / per trajectory (0: shared)
+    const double *cx, *cu, *cxx, *cxu, *cuu, *fx, *fu, *lambda, *lims, *u;
+    const int32_t *active;
+    double *K, *k, *Quu, *Vx, *Vxx, *dV;
+    int32_t *diverge;
+};
+
+__device__ __forceinline__ d4 mf(double x, double y, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); }
+
+template <int NTR, int PT, int MMX>
+struct MidLds {
+    static constexpr int NR = 16 * NTR, PC = 16 * PT, LDV = NR + 1, LDF = NR + 1, LDW = PC + 1, MM = MMX, MK = 8;      // MK: k length of the rank update (two k-steps)
+    // the W image is dead behind the second product: K, ½Y and the unsymmetrised Vxx_i live there
+    static constexpr int WSZ = NR * LDW > 2 * MK * NR + NR * LDV ? NR * LDW : 2 * MK * NR + NR * LDV;
+    static constexpr int oV = 0, oF = oV + NR * LDV, oW = oF + LDF * PC, oGu = oW + WSZ, oQx = oGu + MK * PC, oVx = oQx + NR,
+                         oQuu = oVx + NR, oTot = oQuu + MK * MK + 2;
+    static constexpr int oK = oW, oY = oW + MK * NR, oVr = oW + 2 * MK * NR;
+};
+
+// MMX: the size the m x m system is compiled for (4 for m <= 4: a quarter of the registers of the 8 x 8 arrays)
+template <int NTR, int PT, int MMX, bool LIMS>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
+{
+    using L = MidLds<NTR, PT, MMX>;
+    constexpr int NR = L::NR, PC = L::PC, LDV = L::LDV, LDF = L::LDF, LDW = L::LDW, MM = L::MM, MK = L::MK, KT = NR / 4;
+    const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+    if (a.active && a.active[b] == 0) return;
+    const int n = a.n, m = a.m, N = a.N, p = n + m;
+    extern __shared__ double lds[];
+    double *Vs = lds + L::oV, *Fs = lds + L::oF, *Ws = lds + L::oW, *Gu = lds + L::oGu, *qxs = lds + L::oQx, *vxs = lds + L::oVx,
+           *Quus = lds + L::oQuu, *Ks = lds + L::oK, *Ys = lds + L::oY, *Vr = lds + L::oVr;
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    const double *cx = a.cx + (size_t)n * N * b, *cu = a.cu + (size_t)m * N * b;
+    const double *ug = LIMS ? a.u + (size_t)m * N * b : nullptr;
+    const double *fx = a.fx + a.fx_b * b, *fu = a.fu + a.fu_b * b;
+    const double *cxx = a.cxx + a.cxx_b * b, *cxu = a.cxu + a.cxu_b * b, *cuu = a.cuu + a.cuu_b * b;
+    double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b, *Quug = a.Quu + mm * N * b,
+           *Vxg = a.Vx + (size_t)n * N * b, *Vxxg = a.Vxx + nn * N * b;
+    const double lam = a.lambda[b];
+    const int regType = a.regType;
+    bool nolims = true;
+    double limlo[MM], limhi[MM];
+#pragma unroll
+    for (int q = 0; q < MM; ++q) { limlo[q] = -1.0; limhi[q] = 1.0; }
+    if (LIMS) {
+        nolims = a.lims[0] > a.lims[m];                             // backward_pass.jl:31
+#pragma unroll
+        for (int q = 0; q < MM; ++q) if (q < m) { limlo[q] = a.lims[q]; limhi[q] = a.lims[q + m]; }
+    }
+    const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};       // boxQP.jl:30-35
+
+    for (int e = lane; e < L::oTot; e += DDP_WAVE) lds[e] = 0.0;    // the padding stays zero for the whole launch
+    wave_sync();
+    {   // terminal step (backward_pass.jl:21-23 / :197-199 / :234-236)
+        const size_t tl = (size_t)(N - 1);
+        for (int e = lane; e < (int)nn; e += DDP_WAVE) { const double v = cxx[a.cxx_t * tl + e]; Vs[(e % n) + LDV * (e / n)] = v; Vxxg[nn * tl + e] = v; }
+        if (lane < n) { const double v = cx[(size_t)n * tl + lane]; vxs[lane] = v; Vxg[(size_t)n * tl + lane] = v; }
+        if (lane < (int)mm) Quug[mm * tl + lane] = cuu[a.cuu_t * tl + lane];
+        for (int e = lane; e < (int)nm; e += DDP_WAVE) Kg[nm * tl + e] = 0.0;
+        if (lane < m) kg[(size_t)m * tl + lane] = 0.0;
+    }
+    double dV0 = 0.0, dV1 = 0.0, kprev[MM];
+#pragma unroll
+    for (int q = 0; q < MM; ++q) kprev[q] = 0.0;
+    int diverge = 0;
+    wave_sync();
+    for (int i = N - 2; i >= 0; --i) {
+        // ---- F_i = [fx fu] into the LDS (k fastest; the memory order of both arrays)
+        for (int e = lane; e < n * p; e += DDP_WAVE) {
+            const int k = e % n, j = e / n;
+            Fs[k + LDF * j] = e < (int)nn ? fx[a.fx_t * i + e] : fu[a.fu_t * i + (e - (int)nn)];
+        }
+        wave_sync();
+        // ================= W = Vxx F ==============================================================================
+        {
+            d4 acc[NTR][PT];
+#pragma unroll
+            for (int ri = 0; ri < NTR; ++ri)
+#pragma unroll
+                for (int cj = 0; cj < PT; ++cj) acc[ri][cj] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+                double av[NTR], bv[PT];
+#pragma unroll
+                for (int ri = 0; ri < NTR; ++ri) av[ri] = Vs[(16 * ri + l15) + LDV * (4 * ks + l4)];
+#pragma unroll
+                for (int cj = 0; cj < PT; ++cj) bv[cj] = Fs[(4 * ks + l4) + LDF * (16 * cj + l15)];
+#pragma unroll
+                for (int ri = 0; ri < NTR; ++ri)
+#pragma unroll
+                    for (int cj = 0; cj < PT; ++cj) acc[ri][cj] = mf(av[ri], bv[cj], acc[ri][cj]);
+            }
+#pragma unroll
+            for (int ri = 0; ri < NTR; ++ri)
+#pragma unroll
+                for (int cj = 0; cj < PT; ++cj) {
+                    double *wp = Ws + (16 * ri + l4) * LDW + 16 * cj + l15;
+                    wp[0] = acc[ri][cj].x; wp[4 * LDW] = acc[ri][cj].y; wp[8 * LDW] = acc[ri][cj].z; wp[12 * LDW] = acc[ri][cj].w;
+                }
+        }
+        wave_sync();
+        if (lane < n) Ws[lane * LDW + p] = vxs[lane];              // column p of [W | Vx]
+        wave_sync();
+        // ================= G = F'[W | Vx] + cost terms ================================================================
+        d4 g[PT][PT];
+#pragma unroll
+        for (int ti = 0; ti < PT; ++ti)
+#pragma unroll
+            for (int cj = 0; cj < PT; ++cj) g[ti][cj] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            double fa[PT], wb[PT];
+#pragma unroll
+            for (int ti = 0; ti < PT; ++ti) fa[ti] = Fs[(4 * ks + l4) + LDF * (16 * ti + l15)];      // A[i][k] = F[k, 16 ti + i]
+#pragma unroll
+            for (int cj = 0; cj < PT; ++cj) wb[cj] = Ws[(4 * ks + l4) * LDW + 16 * cj + l15];        // B[k][j] = W[k, 16 cj + j]
+#pragma unroll
+            for (int ti = 0; ti < PT; ++ti)
+#pragma unroll
+                for (int cj = 0; cj < PT; ++cj) g[ti][cj] = mf(fa[ti], wb[cj], g[ti][cj]);
+        }
+        {   // cost Hessians and gradients; the u rows and column p leave for the gains
+            const double *cxxi = cxx + a.cxx_t * i, *cxui = cxu + a.cxu_t * i, *cuui = cuu + a.cuu_t * i;
+            const double *cxi = cx + (size_t)n * i, *cui = cu + (size_t)m * i;
+#pragma unroll
+            for (int ti = 0; ti < PT; ++ti)
+#pragma unroll
+                for (int cj = 0; cj < PT; ++cj) {
+                    const int col = 16 * cj + l15;
+                    double v[4] = {g[ti][cj].x, g[ti][cj].y, g[ti][cj].z, g[ti][cj].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ti + 4 * r + l4;
+                        double c = 0.0;
+                        if (row < n) {
+                            if (col < n) c = cxxi[row + n * col];                                  // (:244)
+                            else if (col < p) c = cxui[row + n * (col - n)];                        // Qxu = Qux'
+                            else if (col == p) c = cxi[row];                                       // Qx (:241)
+                        } else if (row < p) {
+                            if (col < n) c = cxui[col + n * (row - n)];                            // Qux (:242)
+                            else if (col < p) c = cuui[(row - n) + m * (col - n)];                  // Quu (:243)
+                            else if (col == p) c = cui[row - n];                                   // Qu (:240)
+                        }
+                        v[r] += c;
+                        if (row >= n && row < p) Gu[(row - n) * PC + col] = v[r];
+                        if (row < n && col == p) qxs[row] = v[r];
+                    }
+                    g[ti][cj] = d4{v[0], v[1], v[2], v[3]};
+                }
+        }
+        wave_sync();
+        // ================= gains (backward_pass.jl:30-62), every lane the m x m system ==================================
+        double Quu[MM * MM], H[MM * MM], R[MM * MM], Qu[MM], kk[MM], ri[MM];
+        unsigned clamped = 0u;
+#pragma unroll
+        for (int c2 = 0; c2 < MM; ++c2) {
+            Qu[c2] = c2 < m ? Gu[c2 * PC + p] : 0.0;
+#pragma unroll
+            for (int r2 = 0; r2 < MM; ++r2) { const double v = (r2 < m && c2 < m) ? Gu[r2 * PC + n + c2] : 0.0; Quu[r2 + MM * c2] = v; H[r2 + MM * c2] = v; }
+        }
+        double xr[MM];                                            // Qux_reg[:, lane]
+#pragma unroll
+        for (int q = 0; q < MM; ++q) xr[q] = (q < m && lane < n) ? Gu[q * PC + lane] : 0.0;
+        if (regType == 2) {                                       // Vxx_reg = Vxx + λI: λ fu'fu on QuuF, λ fu'fx on Qux_reg (:245-247)
+#pragma unroll
+            for (int q = 0; q < MM; ++q) {
+                if (q < m) {
+                    double sx = 0.0;
+                    for (int k2 = 0; k2 < n; ++k2) sx += Fs[k2 + LDF * (n + q)] * Fs[k2 + LDF * (lane < n ? lane : 0)];
+                    if (lane < n) xr[q] += lam * sx;
+#pragma unroll
+                    for (int q2 = 0; q2 < MM; ++q2) {
+                        if (q2 < m) {
+                            double s = 0.0;
+                            for (int k2 = 0; k2 < n; ++k2) s += Fs[k2 + LDF * (n + q)] * Fs[k2 + LDF * (n + q2)];
+                            H[q + MM * q2] += lam * s;
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MM; ++q) H[q + MM * q] += (q < m) ? lam : 0.0;
+        }
+        int fail;
+        if (!LIMS || nolims) {
+            fail = chol_masked_ri<MM>(m, H, 0u, R, ri);                // cholesky(Hermitian(QuuF))  (:35)
+#pragma unroll
+            for (int q = 0; q < MM; ++q) kk[q] = Qu[q];
+            chol_solve_ri<MM>(m, R, ri, kk);
+#pragma unroll
+            for (int q = 0; q < MM; ++q) kk[q] = -kk[q];             // k_i = -(R\Qu)  (:41)
+        } else {
+            double lo[MM], up[MM];
+#pragma unroll
+            for (int q = 0; q < MM; ++q) { const double uq = q < m ? ug[(size_t)m * i + q] : 0.0; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; }   // (:45-46)
+            int iters;
+            const int result = boxqp_dev_ri<MM>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);      // (:49), warm start k[:, min(i+1, N-1)]
+            fail = (result < 1);                                     // (:53)
+        }
+        if (lane < (int)mm) Quug[mm * i + lane] = Quu[(lane % m) + MM * (lane / m)];      // assigned before a failure upstream too
+        if (fail) { diverge = i + 1; break; }                        // (:37-38, :54-55): wave-uniform
+        double Quuk[MM];
+#pragma unroll
+        for (int q = 0; q < MM; ++q) {
+            double t = 0.0;
+#pragma unroll
+            for (int q2 = 0; q2 < MM; ++q2) t += Quu[q + MM * q2] * kk[q2];
+            Quuk[q] = t;                                             // (:64)
+            kprev[q] = kk[q];
+        }
+        {
+            double kQu = 0.0, kQuuk = 0.0;
+#pragma unroll
+            for (int q = 0; q < MM; ++q) { kQu += kk[q] * Qu[q]; kQuuk += kk[q] * Quuk[q]; }
+            dV0 += kQu; dV1 += 0.5 * kQuuk;                          // (:68)
+        }
+        {   // K_i column `lane`, Y = Quu K + 2 Qux, Vx_i  (:42 / :57-61, :69)
+            double col[MM], x2[MM];
+#pragma unroll
+            for (int q = 0; q < MM; ++q) { x2[q] = (q < m && lane < n) ? Gu[q * PC + lane] : 0.0; col[q] = ((clamped >> q) & 1u) ? 0.0 : xr[q]; }
+            chol_solve_ri<MM>(m, R, ri, col);
+#pragma unroll
+            for (int q = 0; q < MM; ++q) col[q] = (((clamped >> q) & 1u) || q >= m || lane >= n) ? 0.0 : -col[q];
+            double vx = lane < n ? qxs[lane] : 0.0;
+#pragma unroll
+            for (int q = 0; q < MM; ++q) {
+                double t = 2.0 * x2[q];
+#pragma unroll
+                for (int q2 = 0; q2 < MM; ++q2) t += Quu[q + MM * q2] * col[q2];
+                vx += col[q] * (Quuk[q] + Qu[q]) + x2[q] * kk[q];
+                if (lane < NR) { Ks[q * NR + lane] = col[q]; Ys[q * NR + lane] = (q < m && lane < n) ? 0.5 * t : 0.0; }
+                if (q < m && lane < n) Kg[nm * i + q + (size_t)m * lane] = col[q];       // (:76)
+            }
+            if (lane < n) { Vxg[(size_t)n * i + lane] = vx; vxs[lane] = vx; }
+            if (lane < m) {
+                double kv = kk[0];
+#pragma unroll
+                for (int q = 1; q < MM; ++q) kv = (lane == q) ? kk[q] : kv;
+                kg[(size_t)m * i + lane] = kv;                                           // (:75)
+            }
+        }
+        wave_sync();
+        // ================= Vxx_i = Qxx + ½(K'Y + Y'K)  (:70-72): rank-2m update of the xx tiles, then ½(V + V') ==========
+#pragma unroll
+        for (int ks = 0; ks < MM / 4; ++ks) {                           // (rows q >= MM of K, Y do not exist: MM / 4 k-steps)
+            double ka[NTR], ya[NTR];
+#pragma unroll
+            for (int t = 0; t < NTR; ++t) { ka[t] = Ks[(4 * ks + l4) * NR + 16 * t + l15]; ya[t] = Ys[(4 * ks + l4) * NR + 16 * t + l15]; }
+#pragma unroll
+            for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NTR; ++tj) {
+                    g[ti][tj] = mf(ka[ti], ya[tj], g[ti][tj]);           // K'(½Y)
+                    g[ti][tj] = mf(ya[ti], ka[tj], g[ti][tj]);           // (½Y)'K
+                }
+        }
+        wave_sync();                                                   // K, Y have been read: the region takes the unsymmetrised Vxx_i
+#pragma unroll
+        for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NTR; ++tj) {
+                double *vp = Vr + (16 * ti + l4) + LDV * (16 * tj + l15);
+                vp[0] = g[ti][tj].x; vp[4] = g[ti][tj].y; vp[8] = g[ti][tj].z; vp[12] = g[ti][tj].w;
+            }
+        wave_sync();
+        for (int e = lane; e < (int)nn; e += DDP_WAVE) {
+            const int r_ = e % n, c_ = e / n;
+            const double v = 0.5 * (Vr[r_ + LDV * c_] + Vr[c_ + LDV * r_]);
+            Vs[r_ + LDV * c_] = v;
+            Vxxg[nn * i + e] = v;
+        }
+        wave_sync();
+    }
+    if (diverge) {                                                      // outputs earlier in time than a failing step are zero (:37-38 with :226-229)
+        const size_t ie = (size_t)diverge;
+        for (size_t e = lane; e < nm * ie; e += DDP_WAVE) Kg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)m * ie; e += DDP_WAVE) kg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)n * ie; e += DDP_WAVE) Vxg[e] = 0.0;
+        for (size_t e = lane; e < nn * ie; e += DDP_WAVE) Vxxg[e] = 0.0;
+        for (size_t e = lane; e < mm * (ie - 1); e += DDP_WAVE) Quug[e] = 0.0;
+    }
+    if (lane == 0) { a.dV[2 * b] = dV0; a.dV[2 * b + 1] = dV1; a.diverge[b] = diverge; }
+}
+
+template <int NTR, int PT, int MMX>
+int launch_mid(ddp_handle h, const ddp_bp_desc *d, const BPMidArgs &a)
+{
+    const size_t bytes = (size_t)MidLds<NTR, PT, MMX>::oTot * sizeof(double);
+    const dim3 grid((unsigned)d->B), block(DDP_WAVE);
+    if (d->has_lims) {
+        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mid_kernel<NTR, PT, MMX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL((back_pass_mid_kernel<NTR, PT, MMX, true>), grid, block, bytes, h->stream, a);
+    } else {
+        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mid_kernel<NTR, PT, MMX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL((back_pass_mid_kernel<NTR, PT, MMX, false>), grid, block, bytes, h->stream, a);
+    }
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+}   // namespace
+
+// returns 1 if the shape is not handled here (n > 32, m > 8, n + m + 1 > 48), 0 launched, < 0 error
+int ddp_launch_back_pass_mid(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const double *lambda, const double *lims, const double *u,
+                             const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                             double *Vxx, double *dV, int32_t *diverge)
+{
+    const int n = d->n, m = d->m;
+    if (n < 1 || m < 1 || n > 32 || m > 8) return 1;
+    const long N = d->N;
+    BPMidArgs a;
+    a.n = n; a.m = m; a.N = d->N; a.B = d->B; a.regType = d->regType;
+    const long nn = (long)n * n, nm = (long)n * m, mm = (long)m * m;
+    a.fx_t = d->fx_tv ? nn : 0; a.fx_b = d->fx_batched ? nn * (d->fx_tv ? N : 1) : 0;
+    a.fu_t = d->fx_tv ? nm : 0; a.fu_b = d->fx_batched ? nm * (d->fx_tv ? N : 1) : 0;
+    a.cxx_t = d->cost_tv ? nn : 0; a.cxx_b = d->cost_batched ? nn * (d->cost_tv ? N : 1) : 0;
+    a.cxu_t = d->cost_tv ? nm : 0; a.cxu_b = d->cost_batched ? nm * (d->cost_tv ? N : 1) : 0;
+    a.cuu_t = d->cost_tv ? mm : 0; a.cuu_b = d->cost_batched ? mm * (d->cost_tv ? N : 1) : 0;
+    a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.lims = lims;
+    a.u = u; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    const int ntr = n <= 16 ? 1 : 2, pt = (n + m + 1 + 15) / 16;           // pt = 1 only for n + m <= 15: the row kernels' range, padded to 2 here
+    if (m <= 4) {
+        if (ntr == 1) return launch_mid<1, 2, 4>(h, d, a);
+        return pt <= 2 ? launch_mid<2, 2, 4>(h, d, a) : launch_mid<2, 3, 4>(h, d, a);
+    }
+    if (ntr == 1) return launch_mid<1, 2, 8>(h, d, a);
+    return pt <= 2 ? launch_mid<2, 2, 8>(h, d, a) : launch_mid<2, 3, 8>(h, d, a);
+}

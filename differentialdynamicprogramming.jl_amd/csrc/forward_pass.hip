@@ -322,6 +322,12 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
         // every other LQ shape a 16-lane row holds: the row kernel compiled for padded sizes (DDP_FORWARD=group keeps the old path)
         const int rr = ddp_launch_forward_row(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rr <= 0) { h->last_kernel[1] = "forward_row_kernel"; return rr; }
+        // what no row holds (n > 14, m > 4): the one-wave-per-rollout kernel of the large states is 1.4-2.3x the group-of-lanes kernel
+        // there too (n = 24, m = 4, N = 300, B = 1 024 LTV: 3.1 vs 6.0 ms; n = 32, m = 8: 4.4 vs 10.3 ms)
+        if (p->kind == DDP_PROBLEM_LQ && p->n > 14) {
+            const int rb = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
+            if (rb <= 0) { h->last_kernel[1] = "forward_big_kernel"; return rb; }
+        }
     }
     h->last_kernel[1] = "forward_pass_kernel";
     FPArgs a;

@@ -275,3 +275,52 @@ def test_row_kernels_short_horizons(ddp, n, m, N):
             for ai, al in enumerate((1.0, 0.1)):
                 xr, ur, cr = oc.forward_pass(po, (K[..., b], k[..., b]), x0[:, b], uu[..., b], xr0[..., b], al, L)
                 assert relerr(xn[..., b, ai], xr) < RTOL and relerr(un[..., b, ai], ur) < RTOL and relerr(cn[:, b, ai], cr) < RTOL
+
+
+# ------------------------------------------------------------------------------------------------- 14 < n <= 32 (or m > 4): back_pass_mid.hip
+MID_SHAPES = [(15, 1), (16, 2), (17, 3), (20, 6), (24, 4), (25, 8), (31, 5), (32, 8), (13, 4), (8, 5), (3, 7), (32, 1), (16, 8), (12, 4)]
+
+
+@pytest.mark.parametrize("n,m", MID_SHAPES)
+@pytest.mark.parametrize("kind", ["lti", "ltv", "tv"])
+def test_mid_kernel_every_shape_vs_oracle(ddp, n, m, kind):
+    """one wave per trajectory, products on the fp64 matrix cores with LDS operands (csrc/back_pass_mid.hip): every shape up to n = 32,
+    m = 8 — incl. odd n, m > 4 below n = 14, both tile counts and both sizes of the m x m system — against the C oracle"""
+    rng = np.random.default_rng(2000 * n + 10 * m + len(kind))
+    N, B = 21, 5
+    args = _problem(rng, n, m, N, B, kind)
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    for regType, lims in ((1, False), (2, True), (1, True)):
+        L = np.stack([-0.25 * np.ones(m), 0.3 * np.ones(m)], 1) if lims else None
+        out, name = _run(ddp, args, lam, regType, L, "mid")
+        assert name == "back_pass_mid_kernel", name
+        _check(ddp, out, args, lam, regType, L, False)
+
+
+@pytest.mark.parametrize("n,m", [(16, 2), (24, 4), (32, 8), (9, 6)])
+def test_mid_kernel_default_dispatch_batched_operands_inactive_divergence(ddp, n, m):
+    from ddp_amd import _lib
+    rng = np.random.default_rng(41 * n + m)
+    N, B = 17, 7
+    args = _problem(rng, n, m, N, B, "btv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    lam = np.full(B, 0.2); lam[[2, 5]] = -50.0
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 1, None, x, u)
+    assert _lib.default_handle().last_kernel(0) == "back_pass_mid_kernel"
+    assert out[0][2] == N - 1 and out[0][5] == N - 1 and out[0][0] == 0
+    _check(ddp, out, args, lam, 1, None, True)
+    ref, name = _run(ddp, args, np.abs(lam), 2, None, "general")
+    assert name == "back_pass_kernel"
+    got = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, np.abs(lam), 2, None, x, u)
+    for a_, b_ in ((got[1].K, ref[1].K), (got[1].k, ref[1].k), (got[2], ref[2]), (got[3], ref[3]), (got[4], ref[4]), (got[1].Σi, ref[1].Σi)):
+        assert relerr(a_, b_) < 1e-9
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_mid_kernel_short_horizons(ddp, N):
+    rng = np.random.default_rng(17 + N)
+    for n, m in ((18, 3), (30, 7)):
+        args = _problem(rng, n, m, N, 3, "ltv")
+        out, name = _run(ddp, args, 0.3, 1, None, "mid")
+        assert name == "back_pass_mid_kernel"
+        _check(ddp, out, args, 0.3, 1, None, False)
