@@ -36,7 +36,7 @@ struct MidLds {
     // the W image is dead behind the second product: K, ½Y and the unsymmetrised Vxx_i live there
     static constexpr int WSZ = NR * LDW > 2 * MK * NR + NR * LDV ? NR * LDW : 2 * MK * NR + NR * LDV;
     static constexpr int oV = 0, oF = oV + NR * LDV, oW = oF + LDF * PC, oGu = oW + WSZ, oQx = oGu + MK * PC, oVx = oQx + NR,
-                         oQuu = oVx + NR, oTot = oQuu + MK * MK + 2;
+                         oQuu = oVx + NR, oRs = oQuu + MK * MK, oRi = oRs + MK * MK, oTot = oRi + MK + 2;
     static constexpr int oK = oW, oY = oW + MK * NR, oVr = oW + 2 * MK * NR;
 };
 
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
     const int n = a.n, m = a.m, N = a.N, p = n + m;
     extern __shared__ double lds[];
     double *Vs = lds + L::oV, *Fs = lds + L::oF, *Ws = lds + L::oW, *Gu = lds + L::oGu, *qxs = lds + L::oQx, *vxs = lds + L::oVx,
-           *Quus = lds + L::oQuu, *Ks = lds + L::oK, *Ys = lds + L::oY, *Vr = lds + L::oVr;
+           *Hs = lds + L::oQuu, *Rs = lds + L::oRs, *ris = lds + L::oRi, *Ks = lds + L::oK, *Ys = lds + L::oY, *Vr = lds + L::oVr;
     const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
     const double *cx = a.cx + (size_t)n * N * b, *cu = a.cu + (size_t)m * N * b;
     const double *ug = LIMS ? a.u + (size_t)m * N * b : nullptr;
@@ -86,13 +86,67 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
     for (int q = 0; q < MM; ++q) kprev[q] = 0.0;
     int diverge = 0;
+    // ---- per-lane index tables (no division inside the time loop)
+    constexpr int RF = (NR * (NR + 8) + DDP_WAVE - 1) / DDP_WAVE, RS = (NR * NR + DDP_WAVE - 1) / DDP_WAVE;
+    int f_lds[RF];                                                // element e = lane + 64 r of [fx fu] (contiguous in fx, then in fu): its LDS offset
+#pragma unroll
+    for (int r = 0; r < RF; ++r) {
+        const int e = lane + DDP_WAVE * r, ee = e < n * p ? e : 0;
+        f_lds[r] = e < n * p ? (ee % n) + LDF * (ee / n) : -1;
+    }
+    int s_a[RS], s_b[RS];                                         // element e of Vxx_i: its LDS offset and the transposed one
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const int e = lane + DDP_WAVE * r, ee = e < (int)nn ? e : 0;
+        s_a[r] = (ee % n) + LDV * (ee / n); s_b[r] = (ee / n) + LDV * (ee % n);
+    }
+    double pfF[RF];                                               // F of the next step, requested a step ahead
+    auto load_F = [&](int i) {
+        const double *fxi = fx + a.fx_t * i, *fui = fu + a.fu_t * i;
+#pragma unroll
+        for (int r = 0; r < RF; ++r) {
+            const int e = lane + DDP_WAVE * r, ee = e < n * p ? e : 0;
+            pfF[r] = ee < (int)nn ? fxi[ee] : fui[ee - (int)nn];
+        }
+    };
+    // cost Hessians of this lane's tile elements: registers while they do not vary with time
+    const bool ctv = a.cxx_t != 0 || a.cxu_t != 0 || a.cuu_t != 0;
+    double hc[PT][PT][4];
+    auto load_H = [&](int i) {
+        const double *cxxi = cxx + a.cxx_t * i, *cxui = cxu + a.cxu_t * i, *cuui = cuu + a.cuu_t * i;
+#pragma unroll
+        for (int ti = 0; ti < PT; ++ti)
+#pragma unroll
+            for (int cj = 0; cj < PT; ++cj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * r + l4, col = 16 * cj + l15;
+                    double c = 0.0;
+                    if (row < n) { if (col < n) c = cxxi[row + n * col]; else if (col < p) c = cxui[row + n * (col - n)]; }       // (:244), Qxu = Qux'
+                    else if (row < p) { if (col < n) c = cxui[col + n * (row - n)]; else if (col < p) c = cuui[(row - n) + m * (col - n)]; }   // (:242-243)
+                    hc[ti][cj][r] = c;
+                }
+    };
+    // the gradient column (Qx, Qu: column p of G): the lanes l15 == p % 16 of tile column p / 16 hold it; requested a step ahead like F
+    const bool gcol = l15 == p % 16;
+    double gq[PT][4];
+    auto load_g = [&](int i) {
+        const double *cxi = cx + (size_t)n * i, *cui = cu + (size_t)m * i;
+#pragma unroll
+        for (int ti = 0; ti < PT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * r + l4;
+                gq[ti][r] = !gcol ? 0.0 : (row < n ? cxi[row] : (row < p ? cui[row - n] : 0.0));     // Qx (:241), Qu (:240)
+            }
+    };
+    if (N >= 2) { load_F(N - 2); load_g(N - 2); if (!ctv) load_H(0); }
     wave_sync();
     for (int i = N - 2; i >= 0; --i) {
-        // ---- F_i = [fx fu] into the LDS (k fastest; the memory order of both arrays)
-        for (int e = lane; e < n * p; e += DDP_WAVE) {
-            const int k = e % n, j = e / n;
-            Fs[k + LDF * j] = e < (int)nn ? fx[a.fx_t * i + e] : fu[a.fu_t * i + (e - (int)nn)];
-        }
+        // ---- F_i = [fx fu] into the LDS (k fastest; the memory order of both arrays); the next one is requested behind the products
+#pragma unroll
+        for (int r = 0; r < RF; ++r) if (f_lds[r] >= 0) Fs[f_lds[r]] = pfF[r];
+        if (ctv) load_H(i);
         wave_sync();
         // ================= W = Vxx F ==============================================================================
         {
@@ -142,9 +196,9 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
                 for (int cj = 0; cj < PT; ++cj) g[ti][cj] = mf(fa[ti], wb[cj], g[ti][cj]);
         }
+        if (i > 0) load_F(i - 1);                                     // (Fs has been read for the last time unless regType 2 needs it: it stays untouched)
         {   // cost Hessians and gradients; the u rows and column p leave for the gains
-            const double *cxxi = cxx + a.cxx_t * i, *cxui = cxu + a.cxu_t * i, *cuui = cuu + a.cuu_t * i;
-            const double *cxi = cx + (size_t)n * i, *cui = cu + (size_t)m * i;
+            const int cjp = p / 16;
 #pragma unroll
             for (int ti = 0; ti < PT; ++ti)
 #pragma unroll
@@ -154,81 +208,157 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * ti + 4 * r + l4;
-                        double c = 0.0;
-                        if (row < n) {
-                            if (col < n) c = cxxi[row + n * col];                                  // (:244)
-                            else if (col < p) c = cxui[row + n * (col - n)];                        // Qxu = Qux'
-                            else if (col == p) c = cxi[row];                                       // Qx (:241)
-                        } else if (row < p) {
-                            if (col < n) c = cxui[col + n * (row - n)];                            // Qux (:242)
-                            else if (col < p) c = cuui[(row - n) + m * (col - n)];                  // Quu (:243)
-                            else if (col == p) c = cui[row - n];                                   // Qu (:240)
-                        }
-                        v[r] += c;
+                        v[r] += (cj == cjp && gcol) ? gq[ti][r] : hc[ti][cj][r];
                         if (row >= n && row < p) Gu[(row - n) * PC + col] = v[r];
                         if (row < n && col == p) qxs[row] = v[r];
                     }
                     g[ti][cj] = d4{v[0], v[1], v[2], v[3]};
                 }
+            if (i > 0) load_g(i - 1);
         }
         wave_sync();
         // ================= gains (backward_pass.jl:30-62), every lane the m x m system ==================================
-        double Quu[MM * MM], H[MM * MM], R[MM * MM], Qu[MM], kk[MM], ri[MM];
+        // RL: the m x m system of the 8 x 8 instantiation WITHOUT limits lives in the LDS (Hs, Rs, ris: every lane runs the same scalar
+        // factorisation on them — identical values to identical addresses — and solves its own right-hand side with broadcast reads):
+        // three 64-element register arrays per lane spilled to scratch (n = 32, m = 8: 35 us per step).  The 4 x 4 instantiation and the
+        // box-QP keep the register routines of boxqp_dev.h.
+        constexpr bool RL = MM == 8 && !LIMS;
+        double H[RL ? 1 : MM * MM], R[RL ? 1 : MM * MM], Qu[MM], kk[MM], ri[RL ? 1 : MM];      // (Quu itself stays in the LDS: Gu[q][n + q2])
         unsigned clamped = 0u;
 #pragma unroll
-        for (int c2 = 0; c2 < MM; ++c2) {
-            Qu[c2] = c2 < m ? Gu[c2 * PC + p] : 0.0;
-#pragma unroll
-            for (int r2 = 0; r2 < MM; ++r2) { const double v = (r2 < m && c2 < m) ? Gu[r2 * PC + n + c2] : 0.0; Quu[r2 + MM * c2] = v; H[r2 + MM * c2] = v; }
-        }
+        for (int c2 = 0; c2 < MM; ++c2) Qu[c2] = c2 < m ? Gu[c2 * PC + p] : 0.0;
         double xr[MM];                                            // Qux_reg[:, lane]
 #pragma unroll
         for (int q = 0; q < MM; ++q) xr[q] = (q < m && lane < n) ? Gu[q * PC + lane] : 0.0;
-        if (regType == 2) {                                       // Vxx_reg = Vxx + λI: λ fu'fu on QuuF, λ fu'fx on Qux_reg (:245-247)
+        if (regType == 2) {                                       // Vxx_reg = Vxx + λI: λ fu'fx on Qux_reg (:246)
 #pragma unroll
             for (int q = 0; q < MM; ++q) {
                 if (q < m) {
                     double sx = 0.0;
                     for (int k2 = 0; k2 < n; ++k2) sx += Fs[k2 + LDF * (n + q)] * Fs[k2 + LDF * (lane < n ? lane : 0)];
                     if (lane < n) xr[q] += lam * sx;
+                }
+            }
+        }
+        int fail;
+        // forward / back substitution with the factor in registers or in the LDS; b <- (R'R)\b
+        auto solve = [&](double (&bv)[MM]) __attribute__((always_inline)) {
+            if constexpr (RL) {
 #pragma unroll
-                    for (int q2 = 0; q2 < MM; ++q2) {
-                        if (q2 < m) {
-                            double s = 0.0;
-                            for (int k2 = 0; k2 < n; ++k2) s += Fs[k2 + LDF * (n + q)] * Fs[k2 + LDF * (n + q2)];
-                            H[q + MM * q2] += lam * s;
+                for (int i2 = 0; i2 < MM; ++i2) {
+                    if (i2 < m) {
+                        double sv = bv[i2];
+#pragma unroll
+                        for (int k2 = 0; k2 < i2; ++k2) sv -= Rs[k2 + MM * i2] * bv[k2];
+                        bv[i2] = sv * ris[i2];
+                    }
+                }
+#pragma unroll
+                for (int i2 = MM - 1; i2 >= 0; --i2) {
+                    if (i2 < m) {
+                        double sv = bv[i2];
+#pragma unroll
+                        for (int k2 = i2 + 1; k2 < MM; ++k2)
+                            if (k2 < m) sv -= Rs[i2 + MM * k2] * bv[k2];
+                        bv[i2] = sv * ris[i2];
+                    }
+                }
+            } else {
+                chol_solve_ri<MM>(m, R, ri, bv);
+            }
+        };
+        if constexpr (RL) {
+            {   // QuuF (:247): one element per lane
+                const int r2 = lane & 7, c2 = lane >> 3;
+                double v = 0.0;
+                if (r2 < m && c2 < m) {
+                    v = Gu[r2 * PC + n + c2];
+                    if (regType == 2) {
+                        double sv = 0.0;
+                        for (int k2 = 0; k2 < n; ++k2) sv += Fs[k2 + LDF * (n + r2)] * Fs[k2 + LDF * (n + c2)];
+                        v += lam * sv;
+                    } else if (r2 == c2) v += lam;
+                }
+                Hs[lane] = v;
+            }
+            wave_sync();
+            fail = 0;                                              // chol_masked_ri's statements (boxqp_dev.h) on the LDS image, nothing clamped;
+            // unrolled with guards like the original: the reads of a column are independent and go out together (run-time loops made
+            // every one of the ~100 inner iterations an LDS round trip)
+#pragma unroll
+            for (int j2 = 0; j2 < MM; ++j2) {
+                if (j2 < m) {
+                    double cj_[MM];                               // column j2 of R above the diagonal
+#pragma unroll
+                    for (int k2 = 0; k2 < j2; ++k2) cj_[k2] = Rs[k2 + MM * j2];
+                    double ajj = Hs[j2 + MM * j2];
+#pragma unroll
+                    for (int k2 = 0; k2 < j2; ++k2) ajj -= cj_[k2] * cj_[k2];
+                    if (!(ajj > 0.0) && fail == 0) fail = j2 + 1;
+                    const double rr = ddp_rsqrt(ajj);
+                    ris[j2] = rr;
+                    Rs[j2 + MM * j2] = ajj * rr;
+#pragma unroll
+                    for (int i2 = j2 + 1; i2 < MM; ++i2) {
+                        if (i2 < m) {
+                            double sv = Hs[j2 + MM * i2];
+#pragma unroll
+                            for (int k2 = 0; k2 < j2; ++k2) sv -= cj_[k2] * Rs[k2 + MM * i2];
+                            Rs[j2 + MM * i2] = sv * rr;
                         }
                     }
                 }
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < MM; ++q) H[q + MM * q] += (q < m) ? lam : 0.0;
-        }
-        int fail;
-        if (!LIMS || nolims) {
-            fail = chol_masked_ri<MM>(m, H, 0u, R, ri);                // cholesky(Hermitian(QuuF))  (:35)
+            wave_sync();
 #pragma unroll
             for (int q = 0; q < MM; ++q) kk[q] = Qu[q];
-            chol_solve_ri<MM>(m, R, ri, kk);
+            solve(kk);
 #pragma unroll
             for (int q = 0; q < MM; ++q) kk[q] = -kk[q];             // k_i = -(R\Qu)  (:41)
         } else {
-            double lo[MM], up[MM];
 #pragma unroll
-            for (int q = 0; q < MM; ++q) { const double uq = q < m ? ug[(size_t)m * i + q] : 0.0; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; }   // (:45-46)
-            int iters;
-            const int result = boxqp_dev_ri<MM>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);      // (:49), warm start k[:, min(i+1, N-1)]
-            fail = (result < 1);                                     // (:53)
+            for (int c2 = 0; c2 < MM; ++c2)
+#pragma unroll
+                for (int r2 = 0; r2 < MM; ++r2) H[r2 + MM * c2] = (r2 < m && c2 < m) ? Gu[r2 * PC + n + c2] : 0.0;
+            if (regType == 2) {                                   // λ fu'fu on QuuF (:247)
+#pragma unroll
+                for (int q = 0; q < MM; ++q)
+#pragma unroll
+                    for (int q2 = 0; q2 < MM; ++q2) {
+                        if (q < m && q2 < m) {
+                            double sv = 0.0;
+                            for (int k2 = 0; k2 < n; ++k2) sv += Fs[k2 + LDF * (n + q)] * Fs[k2 + LDF * (n + q2)];
+                            H[q + MM * q2] += lam * sv;
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < MM; ++q) H[q + MM * q] += (q < m) ? lam : 0.0;
+            }
+            if (!LIMS || nolims) {
+                fail = chol_masked_ri<MM>(m, H, 0u, R, ri);            // cholesky(Hermitian(QuuF))  (:35)
+#pragma unroll
+                for (int q = 0; q < MM; ++q) kk[q] = Qu[q];
+                solve(kk);
+#pragma unroll
+                for (int q = 0; q < MM; ++q) kk[q] = -kk[q];         // k_i = -(R\Qu)  (:41)
+            } else {
+                double lo[MM], up[MM];
+#pragma unroll
+                for (int q = 0; q < MM; ++q) { const double uq = q < m ? ug[(size_t)m * i + q] : 0.0; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; }   // (:45-46)
+                int iters;
+                const int result = boxqp_dev_ri<MM>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);      // (:49), warm start k[:, min(i+1, N-1)]
+                fail = (result < 1);                                 // (:53)
+            }
         }
-        if (lane < (int)mm) Quug[mm * i + lane] = Quu[(lane % m) + MM * (lane / m)];      // assigned before a failure upstream too
+        if (lane < (int)mm) Quug[mm * i + lane] = Gu[(lane % m) * PC + n + lane / m];     // assigned before a failure upstream too
         if (fail) { diverge = i + 1; break; }                        // (:37-38, :54-55): wave-uniform
         double Quuk[MM];
 #pragma unroll
         for (int q = 0; q < MM; ++q) {
             double t = 0.0;
 #pragma unroll
-            for (int q2 = 0; q2 < MM; ++q2) t += Quu[q + MM * q2] * kk[q2];
+            for (int q2 = 0; q2 < MM; ++q2) t += (q2 < m ? Gu[q * PC + n + q2] : 0.0) * kk[q2];
             Quuk[q] = t;                                             // (:64)
             kprev[q] = kk[q];
         }
@@ -242,7 +372,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
             double col[MM], x2[MM];
 #pragma unroll
             for (int q = 0; q < MM; ++q) { x2[q] = (q < m && lane < n) ? Gu[q * PC + lane] : 0.0; col[q] = ((clamped >> q) & 1u) ? 0.0 : xr[q]; }
-            chol_solve_ri<MM>(m, R, ri, col);
+            solve(col);
 #pragma unroll
             for (int q = 0; q < MM; ++q) col[q] = (((clamped >> q) & 1u) || q >= m || lane >= n) ? 0.0 : -col[q];
             double vx = lane < n ? qxs[lane] : 0.0;
@@ -250,7 +380,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
             for (int q = 0; q < MM; ++q) {
                 double t = 2.0 * x2[q];
 #pragma unroll
-                for (int q2 = 0; q2 < MM; ++q2) t += Quu[q + MM * q2] * col[q2];
+                for (int q2 = 0; q2 < MM; ++q2) t += (q2 < m ? Gu[q * PC + n + q2] : 0.0) * col[q2];
                 vx += col[q] * (Quuk[q] + Qu[q]) + x2[q] * kk[q];
                 if (lane < NR) { Ks[q * NR + lane] = col[q]; Ys[q * NR + lane] = (q < m && lane < n) ? 0.5 * t : 0.0; }
                 if (q < m && lane < n) Kg[nm * i + q + (size_t)m * lane] = col[q];       // (:76)
@@ -287,11 +417,14 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                 vp[0] = g[ti][tj].x; vp[4] = g[ti][tj].y; vp[8] = g[ti][tj].z; vp[12] = g[ti][tj].w;
             }
         wave_sync();
-        for (int e = lane; e < (int)nn; e += DDP_WAVE) {
-            const int r_ = e % n, c_ = e / n;
-            const double v = 0.5 * (Vr[r_ + LDV * c_] + Vr[c_ + LDV * r_]);
-            Vs[r_ + LDV * c_] = v;
-            Vxxg[nn * i + e] = v;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int e = lane + DDP_WAVE * r;
+            if (e < (int)nn) {
+                const double v = 0.5 * (Vr[s_a[r]] + Vr[s_b[r]]);
+                Vs[s_a[r]] = v;
+                Vxxg[nn * i + e] = v;
+            }
         }
         wave_sync();
     }
