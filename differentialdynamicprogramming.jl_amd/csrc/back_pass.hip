@@ -728,7 +728,9 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
     //           batch gives every SIMD a few wavefronts; also the kernel for control limits;
     //   general 64 lanes per trajectory, any n <= 32 / m <= 8 / limits (this file).
     //   row     the same row kernel compiled for PADDED sizes (back_pass_row.hip): any n <= 14, m <= 4, n + m <= 15 that has no exact instantiation;
-    // DDP_BACKPASS=x|q|general|dpp|row|big forces one (A/B timing, tests of every code path).
+    //   tile    the mx kernel with run-time sizes n <= 10, m <= 2 (back_pass_mx.hip, RT), small and medium batches without limits;
+    //   mid     one wave per trajectory with LDS operands (back_pass_mid.hip): n <= 32, m <= 8;
+    // DDP_BACKPASS=x|q|general|dpp|row|tile|mid|big forces one (A/B timing, tests of every code path).
     const char *force_env = ddp_env(h, ENV_BACKPASS);          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
     if (force == 'x' || (force == 0 && d->B < 5120)) {
@@ -750,9 +752,16 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         const int rw = ddp_launch_back_pass_dppw(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rw <= 0) { h->last_kernel[0] = "back_pass_dppw_kernel"; return rw; }
     }
-    if (force != 'g' && force != 'b' && force != 'r') {
+    if (force != 'g' && force != 'b' && force != 'r' && force != 't') {
         const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_dpp_kernel"; return rc; }
+    }
+    // n <= 10, m <= 2 without limits: the fp64 tile kernel with run-time sizes while a SIMD holds one to three waves — its step is half the
+    // row kernel's (0.49 vs 0.99 ms at n=6, m=2, N=1000, B=1024) but costs seven 16x16x4 products whatever n is, so the row kernel
+    // wins once the matrix pipe is the bound (profiles/r05_tile_vs_row.txt: B=3072 1.33 vs 1.47 ms at n=6, 1.21 vs 0.79 at n=3)
+    if (force == 't' || (force == 0 && (d->B <= 1024 || (d->B <= 3072 && d->n >= 5)))) {
+        const int rc = ddp_launch_back_pass_mxr(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mx_kernel<RT>"; return rc; }
     }
     if (force == 0 || force == 'r') {                             // every other shape a 16-lane row holds: the row kernel compiled for padded sizes
         const int rc = ddp_launch_back_pass_row(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);

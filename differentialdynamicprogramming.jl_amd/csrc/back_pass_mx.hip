@@ -35,35 +35,40 @@ namespace {
 
 #include "back_pass_mx_common.h"
 
-template <bool FXTV, bool CTV, bool REG2, bool LCH>
+// RT: run-time sizes nr <= 10, mr <= 2 in the same tile (state j in tile row/column j, rows nr..9 exact zeros, the controls in tile rows
+// 10, 11; for mr = 1 tile entry (11, 11) of H is 1 so that the 2x2 system stays positive definite with K[1,:] = 0), operands and results
+// with run-time strides, results straight to global memory (no step records)
+template <bool FXTV, bool CTV, bool REG2, bool LCH, bool RT>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
 {
     const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
     if (a.active && a.active[b] == 0) return;
     const int N = a.N;
-    constexpr size_t nn = (size_t)n * n, nm = (size_t)n * m, mm = (size_t)m * m;
+    static_assert(!(RT && LCH), "the step records have the layout of the exact shape");
+    const int nr = RT ? a.n : n, mr = RT ? a.m : m;
+    const size_t nn = (size_t)nr * nr, nm = (size_t)nr * mr, mm = (size_t)mr * mr;
 
     __shared__ __attribute__((aligned(16))) double lds[TLD * 16 + 16];      // transpose tile + zero cells
     __shared__ __attribute__((aligned(16))) double lout[LCH ? LOUT + LDUMP_SZ : 2];
     __shared__ __attribute__((aligned(16))) double leb[2][LCH ? 128 : 2];
 
-    const double *cx = a.cx + (size_t)n * N * b, *cu = a.cu + (size_t)m * N * b;
+    const double *cx = a.cx + (size_t)nr * N * b, *cu = a.cu + (size_t)mr * N * b;
     const double *fx = a.fx + (a.fx_batched ? nn * (FXTV ? N : 1) * b : 0);
     const double *fu = a.fu + (a.fx_batched ? nm * (FXTV ? N : 1) * b : 0);
     const double *cxx = a.cxx + (a.cost_batched ? nn * (CTV ? N : 1) * b : 0);
     const double *cxu = a.cxu + (a.cost_batched ? nm * (CTV ? N : 1) * b : 0);
     const double *cuu = a.cuu + (a.cost_batched ? mm * (CTV ? N : 1) * b : 0);
-    double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)m * N * b, *Quug = a.Quu + mm * N * b,
-           *Vxg = a.Vx + (size_t)n * N * b, *Vxxg = a.Vxx + nn * N * b;
+    double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)mr * N * b, *Quug = a.Quu + mm * N * b,
+           *Vxg = a.Vx + (size_t)nr * N * b, *Vxxg = a.Vxx + nn * N * b;
     const double lam = a.lambda[b];
 
     // ---- terminal step (backward_pass.jl:234-236 / :197-199)
     const size_t tl = (size_t)(N - 1);
-    for (int e = lane; e < n * n; e += DDP_WAVE) Vxxg[nn * tl + e] = cxx[(CTV ? nn * tl : 0) + e];
-    if (lane < n) Vxg[(size_t)n * tl + lane] = cx[(size_t)n * tl + lane];
-    if (lane < 4) Quug[mm * tl + lane] = cuu[(CTV ? mm * tl : 0) + lane];
-    if (lane < 2 * n) Kg[nm * tl + lane] = 0.0;
-    if (lane < m) kg[(size_t)m * tl + lane] = 0.0;
+    for (int e = lane; e < nr * nr; e += DDP_WAVE) Vxxg[nn * tl + e] = cxx[(CTV ? nn * tl : 0) + e];
+    if (lane < nr) Vxg[(size_t)nr * tl + lane] = cx[(size_t)nr * tl + lane];
+    if (lane < mr * mr) Quug[mm * tl + lane] = cuu[(CTV ? mm * tl : 0) + lane];
+    if (lane < mr * nr) Kg[nm * tl + lane] = 0.0;
+    if (lane < mr) kg[(size_t)mr * tl + lane] = 0.0;
     if (N < 2) {
         if (lane == 0) { a.dV[2 * b] = 0.0; a.dV[2 * b + 1] = 0.0; a.diverge[b] = 0; }
         return;
@@ -71,19 +76,24 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     for (int e = lane; e < TLD * 16 + 16; e += DDP_WAVE) lds[e] = 0.0;
 
     // ---- per-lane operand streams ------------------------------------------------------------------------------
-    auto h_stream = [&](int row, int col) -> Stream {       // H = [cxx cxu; cxu' cuu] (p x p), zero outside
-        if (col < p && row < p) {
-            if (row < n && col < n) return Stream{(const char *)(cxx + row + n * col), CTV ? (unsigned)(nn * 8) : 0u, nullptr};
-            if (row < n) return Stream{(const char *)(cxu + row + n * (col - n)), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
-            if (col < n) return Stream{(const char *)(cxu + col + n * (row - n)), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
-            return Stream{(const char *)(cuu + (row - n) + m * (col - n)), CTV ? (unsigned)(mm * 8) : 0u, nullptr};
-        }
-        return Stream{(const char *)mx_zero, 0u, nullptr};
+    // tile coordinate -> state index (< nr), control index (tile rows n.. = 10, 11), or nothing (-1)
+    auto six = [&](int r) { return r < nr ? r : -1; };
+    auto uix = [&](int r) { return (r >= n && r < n + mr) ? r - n : -1; };
+    const Stream zeroS = Stream{(const char *)mx_zero, 0u, nullptr};
+    auto h_stream = [&](int row, int col) -> Stream {       // H = [cxx cxu; cxu' cuu] in tile coordinates, zero outside
+        const int sr = six(row), sc = six(col), ur = uix(row), uc = uix(col);
+        if (sr >= 0 && sc >= 0) return Stream{(const char *)(cxx + sr + nr * sc), CTV ? (unsigned)(nn * 8) : 0u, nullptr};
+        if (sr >= 0 && uc >= 0) return Stream{(const char *)(cxu + sr + nr * uc), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
+        if (ur >= 0 && sc >= 0) return Stream{(const char *)(cxu + sc + nr * ur), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
+        if (ur >= 0 && uc >= 0) return Stream{(const char *)(cuu + ur + mr * uc), CTV ? (unsigned)(mm * 8) : 0u, nullptr};
+        if (RT && row == col && row >= n + mr && row < p) return Stream{(const char *)mx_one, 0u, nullptr};     // the unused control of mr = 1
+        return zeroS;
     };
-    auto f_stream = [&](int row, int col) -> Stream {       // F = [fx fu] (n x p), zero outside
-        if (row < n && col < n) return Stream{(const char *)(fx + row + n * col), FXTV ? (unsigned)(nn * 8) : 0u, nullptr};
-        if (row < n && col < p) return Stream{(const char *)(fu + row + n * (col - n)), FXTV ? (unsigned)(nm * 8) : 0u, nullptr};
-        return Stream{(const char *)mx_zero, 0u, nullptr};
+    auto f_stream = [&](int row, int col) -> Stream {       // F = [fx fu] in tile coordinates, zero outside
+        const int sr = six(row), sc = six(col), uc = uix(col);
+        if (sr >= 0 && sc >= 0) return Stream{(const char *)(fx + sr + nr * sc), FXTV ? (unsigned)(nn * 8) : 0u, nullptr};
+        if (sr >= 0 && uc >= 0) return Stream{(const char *)(fu + sr + nr * uc), FXTV ? (unsigned)(nm * 8) : 0u, nullptr};
+        return zeroS;
     };
     // Tile rows 12..15 repeat the u-rows 10, 11, 10, 11 (F columns 12..15 of the A operand of GEMM2 repeat columns 10, 11, and
     // so do the rows of H): accumulator register 3 of G then holds, in EVERY 16-lane row, the u-row with the parity of that row.
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int row = s < 3 ? l4 + 4 * s : urow;
-        hS[s] = l15 == VC ? Stream{(const char *)mx_zero, 0u, nullptr} : h_stream(row, l15);   // C of GEMM2 (column VC: below)
+        hS[s] = l15 == VC ? zeroS : h_stream(row, l15);   // C of GEMM2 (column VC: below)
         if (s < 3) fS[s] = f_stream(l4 + 4 * s, l15 < p ? l15 : n + (l15 & 1));
     }
     // The vector e = [cx; cu] (p entries) of tile column VC costs ONE load per step: lane (l4, j) fetches e[j + l4], so that
@@ -100,8 +110,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     // row — a row broadcast folded into the multiply-add that builds the C operand (register 3: e[10 + (l4&1)] = lane 10
     // of rows 0,1 and lane 8 of rows 2,3).
     const int eidx = l15 + l4 < p ? l15 + l4 : p - 1;
-    Stream eS = eidx < n ? Stream{(const char *)(cx + eidx), (unsigned)(n * 8), nullptr}
-                         : Stream{(const char *)(cu + (eidx - n)), (unsigned)(m * 8), nullptr};
+    Stream eS = six(eidx) >= 0 ? Stream{(const char *)(cx + eidx), (unsigned)(nr * 8), nullptr}
+                               : (uix(eidx) >= 0 ? Stream{(const char *)(cu + (eidx - n)), (unsigned)(mr * 8), nullptr} : zeroS);
 
     // ---- loop-invariant lane constants ---------------------------------------------------------------------------
     const double mask12 = l15 == VC ? 1.0 : 0.0;
@@ -111,19 +121,22 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     const int rdT = l15 == VC ? TZERO : l15 + TLD * l4;      // its transpose (l15, l4+4s): + 4*TLD per register
     const int rdS = l15 == VC ? 0 : 4 * TLD;
     // Vxx | Vx ride on the same three stores: columns < n: Vxx[l4+4s, col]; column VC: Vx[l4+4s]
-    const bool v_act01 = l15 < n || l15 == VC, v_act2 = v_act01 && l4 < 2;
+    const bool v_col = l15 < nr || l15 == VC;
+    const bool v_act01 = v_col, v_act2 = v_col && l4 < 2 && (!RT || l4 + 8 < nr);
     const double vscl = l15 == VC ? 1.0 : 0.5;               // registers hold V + V'; column VC holds Vx itself
-    char *vst = l15 == VC ? (char *)(Vxg + (size_t)n * (tl - 1) + l4) : (char *)(Vxxg + nn * (tl - 1) + l4 + n * (l15 < n ? l15 : 0));
-    const unsigned vst_stride = l15 == VC ? (unsigned)(n * 8) : (unsigned)(nn * 8);
+    char *vst = l15 == VC ? (char *)(Vxg + (size_t)nr * (tl - 1) + l4) : (char *)(Vxxg + nn * (tl - 1) + l4 + nr * (l15 < nr ? l15 : 0));
+    const unsigned vst_stride = l15 == VC ? (unsigned)(nr * 8) : (unsigned)(nn * 8);
     // K | k | Quu ride on one store: lanes of rows 2,3: columns <n: K[a, col]; column VC: k[a]; columns n..n+1: Quu[a, col-n]
     const bool quu_lane = hi2 && (l15 == n || l15 == n + 1);
-    const bool kq_act = hi2 && l15 <= VC;
-    const unsigned long long lanes01 = __builtin_amdgcn_ballot_w64(v_act01), lanes2k = __builtin_amdgcn_ballot_w64(hi2 ? kq_act : v_act2);
     const int a2 = hi2 ? l4 - 2 : 0;
+    const bool kq_act = hi2 && a2 < mr && (l15 < nr || l15 == VC || uix(l15) >= 0);
+    const unsigned long long lanes01 = __builtin_amdgcn_ballot_w64(v_act01), lanes2k = __builtin_amdgcn_ballot_w64(hi2 ? kq_act : v_act2);
+    // RT: the rows l4 and l4 + 4 of a column are stored separately (either may lie in the padding)
+    const unsigned long long lanes0 = __builtin_amdgcn_ballot_w64(v_col && l4 < nr), lanes1 = __builtin_amdgcn_ballot_w64(v_col && l4 + 4 < nr);
     char *kq = !hi2 ? vst + 64
-                    : (l15 < n ? (char *)(Kg + nm * (tl - 1) + a2 + m * l15)
-                               : (l15 == VC ? (char *)(kg + (size_t)m * (tl - 1) + a2) : (char *)(Quug + mm * (tl - 1) + a2 + m * (l15 < p ? l15 - n : 0))));
-    const unsigned kq_stride = !hi2 ? vst_stride : (l15 < n ? (unsigned)(nm * 8) : (l15 == VC ? (unsigned)(m * 8) : (unsigned)(mm * 8)));
+                    : (l15 < nr ? (char *)(Kg + nm * (tl - 1) + a2 + mr * l15)
+                                : (l15 == VC ? (char *)(kg + (size_t)mr * (tl - 1) + a2) : (char *)(Quug + mm * (tl - 1) + a2 + mr * (uix(l15) >= 0 ? l15 - n : 0))));
+    const unsigned kq_stride = !hi2 ? vst_stride : (l15 < nr ? (unsigned)(nm * 8) : (l15 == VC ? (unsigned)(mr * 8) : (unsigned)(mm * 8)));
 
     // ---- LCH: where this lane's results go in a step record, and its share of the write-back of a group
     // accumulator registers 0, 1 (and 2 in 16-lane rows 0, 1): Vxx[l4+4s, l15] | column VC: Vx[l4+4s]; register 2 of rows 2, 3: K | k | Quu
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     const unsigned mstep = mw < 5 ? n * 8u : (mw < 15 ? (unsigned)(nm * 8) : (mw == 15 ? m * 8u : (unsigned)(mm * 8)));     // bytes per time step
     char *pV = nullptr, *pM = nullptr;
     const char *pE = nullptr;
-    if (LCH) {
+    if constexpr (LCH) {
         const long t0 = (long)N - 2 - (PD - 1);              // lowest step of the first group
         pV = (char *)(Vxxg + (long)nn * t0 + 2 * (lane < 50 ? lane : 0));
         char *mb = mw < 5 ? (char *)(Vxg + 2 * mw) : (mw < 15 ? (char *)(Kg + 2 * (mw - 5)) : (mw == 15 ? (char *)kg : (char *)(Quug + 2 * (mw - 16))));
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int row = l4 + 4 * s;
-            S[s] = (l15 < n && row < n) ? 2.0 * hs[s].at((int)tl) : ((l15 == VC && row < n) ? cx[(size_t)n * tl + row] : 0.0);
+            S[s] = (l15 < nr && row < nr) ? 2.0 * hs[s].at((int)tl) : ((l15 == VC && row < nr) ? cx[(size_t)nr * tl + row] : 0.0);
         }
     }
     const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
@@ -323,7 +336,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
             lout[w1 + 4 + REC * tau] = vscl * S[1];
             lout[w2 + REC * tau] = hi2 ? (quu_lane ? Z : Ksel) : vscl * S[2];
         } else {
-            store2_masked(vst, vscl * S[0], vscl * S[1], lanes01);
+            if (RT) { store_masked(vst, vscl * S[0], lanes0); store_masked(vst + 32, vscl * S[1], lanes1); }
+            else store2_masked(vst, vscl * S[0], vscl * S[1], lanes01);
             // rows 8, 9 of Vxx | Vx (16-lane rows 0,1) and K | k | Quu (:75-76) (rows 2,3) share one store
             store_masked(kq, hi2 ? (quu_lane ? Z : Ksel) : vscl * S[2], lanes2k);
             vst -= vst_stride;
@@ -397,8 +411,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
         const size_t ie = (size_t)diverge;          // = i + 1
         __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the garbage of the steps after the failure has landed
         for (size_t e = lane; e < nm * ie; e += DDP_WAVE) Kg[e] = 0.0;
-        for (size_t e = lane; e < (size_t)m * ie; e += DDP_WAVE) kg[e] = 0.0;
-        for (size_t e = lane; e < (size_t)n * ie; e += DDP_WAVE) Vxg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)mr * ie; e += DDP_WAVE) kg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)nr * ie; e += DDP_WAVE) Vxg[e] = 0.0;
         for (size_t e = lane; e < nn * ie; e += DDP_WAVE) Vxxg[e] = 0.0;
         for (size_t e = lane; e < mm * (ie - 1); e += DDP_WAVE) Quug[e] = 0.0;
     }
@@ -410,16 +424,16 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mx_kernel(BPXArgs a)
     if (lane == 0) a.diverge[b] = diverge;
 }
 
-template <bool REG2, bool LCH>
+template <bool REG2, bool LCH, bool RT = false>
 int launch_mx(ddp_handle h, const ddp_bp_desc *d, const BPXArgs &a)
 {
     const dim3 grid(d->B), block(DDP_WAVE);
     const int key = (d->fx_tv ? 2 : 0) | (d->cost_tv ? 1 : 0);
     switch (key) {
-    case 0: hipLaunchKernelGGL((back_pass_mx_kernel<false, false, REG2, LCH>), grid, block, 0, h->stream, a); break;
-    case 1: hipLaunchKernelGGL((back_pass_mx_kernel<false, true, REG2, LCH>), grid, block, 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((back_pass_mx_kernel<true, false, REG2, LCH>), grid, block, 0, h->stream, a); break;
-    case 3: hipLaunchKernelGGL((back_pass_mx_kernel<true, true, REG2, LCH>), grid, block, 0, h->stream, a); break;
+    case 0: hipLaunchKernelGGL((back_pass_mx_kernel<false, false, REG2, LCH, RT>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((back_pass_mx_kernel<false, true, REG2, LCH, RT>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((back_pass_mx_kernel<true, false, REG2, LCH, RT>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((back_pass_mx_kernel<true, true, REG2, LCH, RT>), grid, block, 0, h->stream, a); break;
     }
     DDP_HIP(hipGetLastError());
     return 0;
@@ -435,7 +449,7 @@ int ddp_launch_back_pass_mx(ddp_handle h, const ddp_bp_desc *d, const double *cx
 {
     if (d->has_lims || d->m != 2 || d->n != 10) return 1;
     BPXArgs a;
-    a.N = d->N; a.B = d->B; a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched;
+    a.N = d->N; a.B = d->B; a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.n = d->n; a.m = d->m;
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     // the group write-back needs 16-byte aligned arrays (every per-step size of this shape is a multiple of 16 bytes)
@@ -443,4 +457,18 @@ int ddp_launch_back_pass_mx(ddp_handle h, const ddp_bp_desc *d, const double *cx
     const bool al16 = ((((uintptr_t)cx | (uintptr_t)cu | (uintptr_t)K | (uintptr_t)k | (uintptr_t)Quu | (uintptr_t)Vx | (uintptr_t)Vxx) & 15) == 0);
     if (al16 && !(lv && lv[0] == '0')) return d->regType == 2 ? launch_mx<true, true>(h, d, a) : launch_mx<false, true>(h, d, a);
     return d->regType == 2 ? launch_mx<true, false>(h, d, a) : launch_mx<false, false>(h, d, a);
+}
+
+// The same tile kernel for any n <= 10, m <= 2 without control limits (run-time sizes inside the (10, 2) tile layout); 1 = not applicable
+int ddp_launch_back_pass_mxr(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const double *lambda, const int32_t *active, double *K,
+                             double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge)
+{
+    if (d->has_lims || d->m > 2 || d->n > 10) return 1;
+    BPXArgs a;
+    a.N = d->N; a.B = d->B; a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.n = d->n; a.m = d->m;
+    a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    return d->regType == 2 ? launch_mx<true, false, true>(h, d, a) : launch_mx<false, false, true>(h, d, a);
 }

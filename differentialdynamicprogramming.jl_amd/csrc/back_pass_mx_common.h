@@ -9,6 +9,7 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 struct BPXArgs {
     int N, B;
     int fx_batched, cost_batched;
+    int n, m;                                       // run-time sizes (back_pass_mx_kernel<..., RT = true> only)
     const double *cx, *cu, *cxx, *cxu, *cuu, *fx, *fu, *lambda;
     const int32_t *active;
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
@@ -16,6 +17,7 @@ struct BPXArgs {
 };
 
 __device__ const double mx_zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ const double mx_one[2] = {1.0, 1.0};
 
 constexpr int n = 10, m = 2, p = 12, VC = 12;      // VC: tile column that carries the vectors
 constexpr int PD = 8;                               // prefetch distance (time steps) of the streamed operands

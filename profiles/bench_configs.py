@@ -343,6 +343,7 @@ if __name__ == "__main__":
     if "offA" in which:
         off_shape("offA", 12, 3, 500, 2048, True, False)
     if "offC" in which:                                          # between the row kernels (n <= 14) and n = 64: which kernel should own 15 <= n <= 32?
-        off_shape("offC", int(os.environ.get("DDP_OFFC_N", 24)), int(os.environ.get("DDP_OFFC_M", 4)), 300, 1024, True, False)
+        off_shape("offC", int(os.environ.get("DDP_OFFC_N", 24)), int(os.environ.get("DDP_OFFC_M", 4)), int(os.environ.get("DDP_OFFC_T", 300)),
+                  int(os.environ.get("DDP_OFFC_B", 1024)), os.environ.get("DDP_OFFC_LTI") != "1", False)
     if "offB" in which:
         off_shape("offB", 6, 2, 1000, 4096, False, os.environ.get("DDP_OFF_NOLIMS") != "1")

@@ -1,0 +1,107 @@
+"""The fp64-matrix-core tile kernel with RUN-TIME sizes (csrc/back_pass_mx.hip, `RT`): any n <= 10, m <= 2 without control limits inside the
+(10, 2) tile layout — padded state rows are exact zeros, the unused control of m = 1 is an identity entry of the 2x2 system.  The reference's
+back_pass is size-generic (src/backward_pass.jl:162-252 + :28-42, :64-76): every case against the C oracle on every trajectory, for the three
+rank dispatches, both regularisations, per-trajectory operands, inactive trajectories, a diverging λ, short horizons; the row kernel and the
+exact-shape tile kernel give second opinions."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from test_gpu_row_shapes import _problem, _check, _run
+
+pytestmark = pytest.mark.gpu
+NAME = "back_pass_mx_kernel<RT>"
+SHAPES = [(1, 1), (1, 2), (2, 1), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (7, 1), (7, 2), (8, 2), (9, 1), (9, 2), (10, 1), (10, 2)]
+
+
+@pytest.fixture(scope="module")
+def ddp():
+    import ddp_amd
+    ddp_amd.default_handle()
+    return ddp_amd
+
+
+@pytest.mark.parametrize("n,m", SHAPES)
+@pytest.mark.parametrize("kind", ["lti", "ltv", "tv"])
+def test_tile_kernel_every_shape_vs_oracle(ddp, n, m, kind):
+    rng = np.random.default_rng(2000 * n + 10 * m + len(kind))
+    N, B = 27, 7                                      # N - 1 not a multiple of the prefetch ring (8)
+    args = _problem(rng, n, m, N, B, kind)
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    for regType in (1, 2):
+        out, name = _run(ddp, args, lam, regType, None, "tile")
+        assert name == NAME, name
+        _check(ddp, out, args, lam, regType, None, False)
+
+
+@pytest.mark.parametrize("n,m", [(3, 1), (6, 2), (9, 2), (10, 1)])
+def test_tile_kernel_is_the_default_dispatch_without_limits(ddp, n, m):
+    from ddp_amd import _lib
+    rng = np.random.default_rng(77 * n + m)
+    N, B = 40, 9
+    args = _problem(rng, n, m, N, B, "ltv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, None, x, u)
+    assert _lib.default_handle().last_kernel(0) == NAME
+    ref, name = _run(ddp, args, 0.3, 1, None, "row")
+    assert name == "back_pass_row_kernel"
+    assert np.array_equal(out[0], ref[0])
+    for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4]), (out[1].Σi, ref[1].Σi)):
+        assert relerr(a_, b_) < 1e-10
+    # with limits the shape stays on the row kernel
+    L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
+    ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, L, x, u)
+    assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+
+
+def test_tile_kernel_at_the_exact_shape_agrees_with_the_exact_kernel(ddp):
+    rng = np.random.default_rng(4)
+    args = _problem(rng, 10, 2, 61, 5, "tv")
+    a, na = _run(ddp, args, 0.05, 2, None, "tile")
+    b, nb = _run(ddp, args, 0.05, 2, None, "x")
+    assert na == NAME and nb.startswith("back_pass_mx"), (na, nb)
+    for p_, q_ in ((a[1].K, b[1].K), (a[1].k, b[1].k), (a[2], b[2]), (a[3], b[3]), (a[4], b[4]), (a[1].Σi, b[1].Σi)):
+        assert relerr(p_, q_) < 1e-12
+
+
+@pytest.mark.parametrize("n,m", [(5, 2), (7, 1), (8, 2)])
+def test_tile_kernel_per_trajectory_operands_inactive_and_divergence(ddp, n, m):
+    from ddp_amd import _lib
+    rng = np.random.default_rng(131 * n + m)
+    N, B = 19, 10
+    args = _problem(rng, n, m, N, B, "btv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    lam = np.full(B, 0.2); lam[[1, 6]] = -50.0
+    for regType in (1, 2):
+        out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, None, x, u)
+        assert _lib.default_handle().last_kernel(0) == NAME
+        if regType == 1:
+            assert out[0][1] == N - 1 and out[0][6] == N - 1 and out[0][0] == 0
+        _check(ddp, out, args, lam, regType, None, True)
+    # a λ that fails in the middle of the horizon for some trajectories
+    lam = np.full(B, 0.2); lam[[2, 5]] = -0.12
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 1, None, x, u)
+    _check(ddp, out, args, lam, 1, None, True)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 8, 9, 10, 17])
+@pytest.mark.parametrize("n,m", [(3, 2), (6, 1), (9, 2)])
+def test_tile_kernel_short_horizons(ddp, n, m, N):
+    rng = np.random.default_rng(17 * n + m + N)
+    args = _problem(rng, n, m, N, 5, "tv")
+    out, name = _run(ddp, args, 0.1, 1, None, "tile")
+    assert name == NAME
+    _check(ddp, out, args, 0.1, 1, None, False)
+
+
+def test_tile_kernel_full_size_off_shape(ddp):
+    """off-shape B of bench.py's other_configs without its limits (n=6, m=2, N=1000, B=4096, LTI): a sample of trajectories"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(6262)
+    n, m, N, B = 6, 2, 1000, 4096
+    args = _problem(rng, n, m, N, B, "lti")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.1, 1, None, x, u)
+    assert _lib.default_handle().last_kernel(0) in (NAME, "sh_back_kernel")
+    who = sorted({0, 1, 2, 3, B - 1, B - 2} | set(int(v) for v in rng.integers(0, B, 18)))
+    _check(ddp, out, args, 0.1, 1, None, False, who=who)
