@@ -730,7 +730,8 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
     //   row     the same row kernel compiled for PADDED sizes (back_pass_row.hip): any n <= 14, m <= 4, n + m <= 15 that has no exact instantiation;
     //   tile    the mx kernel with run-time sizes n <= 10, m <= 2 (back_pass_mx.hip, RT), small and medium batches without limits;
     //   mid     one wave per trajectory with LDS operands (back_pass_mid.hip): n <= 32, m <= 8;
-    // DDP_BACKPASS=x|q|general|dpp|row|tile|mid|big forces one (A/B timing, tests of every code path).
+    //   wtile   the tile kernel for n <= 12, m <= 4 (back_pass_mxg.hip), same batches;
+    // DDP_BACKPASS=x|q|general|dpp|row|tile|wtile|mid|big forces one (A/B timing, tests of every code path).
     const char *force_env = ddp_env(h, ENV_BACKPASS);          // read per call so tests can switch paths
     const char force = force_env ? force_env[0] : 0;
     if (force == 'x' || (force == 0 && d->B < 5120)) {
@@ -752,7 +753,7 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         const int rw = ddp_launch_back_pass_dppw(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rw <= 0) { h->last_kernel[0] = "back_pass_dppw_kernel"; return rw; }
     }
-    if (force != 'g' && force != 'b' && force != 'r' && force != 't') {
+    if (force != 'g' && force != 'b' && force != 'r' && force != 't' && force != 'w') {
         const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_dpp_kernel"; return rc; }
     }
@@ -762,6 +763,12 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
     if (force == 't' || (force == 0 && (d->B <= 1024 || (d->B <= 3072 && d->n >= 5)))) {
         const int rc = ddp_launch_back_pass_mxr(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mx_kernel<RT>"; return rc; }
+    }
+    // the same for n <= 12, m <= 4 (back_pass_mxg.hip; profiles/r05_wtile_vs_row.txt: ahead of the row kernel up to B = 4096 — 0.83 vs 1.16 ms at
+    // n=12, m=3, N=500, B=2048; 1.15 vs 1.55 at n=8, m=4, B=4096 — level with it there for n <= 4)
+    if (force == 'w' || (force == 0 && (d->B <= 3072 || (d->B <= 4096 && d->n >= 5)))) {
+        const int rc = ddp_launch_back_pass_mxg(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mxg_kernel"; return rc; }
     }
     if (force == 0 || force == 'r') {                             // every other shape a 16-lane row holds: the row kernel compiled for padded sizes
         const int rc = ddp_launch_back_pass_row(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);

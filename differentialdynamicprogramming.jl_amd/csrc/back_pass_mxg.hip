@@ -1,0 +1,325 @@
+// back_pass_mxg.hip — the fp64-matrix-core TILE backward pass (back_pass_mx.hip) for a RANGE of shapes: any n <= 12, m <= 4 with
+// n + m <= 15, no control limits; one wavefront per trajectory, every matrix of a time step in ONE 16x16 v_mfma_f64_16x16x4_f64 tile.
+// Same arithmetic as src/backward_pass.jl:162-252 + :28-42, :64-76.
+//
+// Tile coordinates (NP = n rounded up to a multiple of 4, a template parameter): state j -> j, control a -> NP + a, vectors in column 15.
+//   * padded state rows/columns (n .. NP-1) are exact zeros in every operand and stay exact zeros through the recursion;
+//   * the controls fill ONE accumulator register: register NP/4 of G = F'W + H holds, in the 16-lane row a, the row [Qux | Quu | Qu] of
+//     control a.  It goes through a 64-entry LDS image so that every lane has all the rows of ITS column; the MS x MS system
+//     (MS = 4, or 3 at NP = 12) is factorised redundantly by every lane (upper Cholesky with reciprocal pivots: the pivots are the
+//     positive-definiteness test of :35-38) and each lane solves its own column — K for the columns < n, k for column 15 (:41-42);
+//     controls m .. MS-1 are an identity block of the system (K rows exactly zero);
+//   * value update (:69-72) in ONE product for any m <= 4:  D = G + K'Y,  Y = (Quu K + Qux) + Qux,  V + V' = D + D'  (the transpose
+//     comes through the padded LDS tile as in back_pass_mx.hip); column 15 is not symmetrised and wants K'(Quu k + Qu) + Qux'k: the
+//     first term is the product with Y[:,15] = Quu k + Qu, the second is added by row broadcasts of G's control columns.
+// Per step: 2·NP/4 + 1 (+ NP/4 for regType 2) dependent matrix instructions, two LDS round trips, ~150 vector instructions.
+// Measured against the 16-lane-row kernel it replaces for small and medium batches: DESIGN.md §3.2.
+#include "ddp_internal.h"
+
+namespace {
+
+#include "back_pass_mx_common.h"
+
+constexpr int VG = 15;                              // tile column of the vectors
+
+template <int NP, bool FXTV, bool CTV, bool REG2>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
+{
+    constexpr int KS = NP / 4, UR = NP / 4, MS = NP == 12 ? 3 : 4;
+    const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+    if (a.active && a.active[b] == 0) return;
+    const int N = a.N, nr = a.n, mr = a.m;
+    const size_t nn = (size_t)nr * nr, nm = (size_t)nr * mr, mm = (size_t)mr * mr;
+
+    __shared__ __attribute__((aligned(16))) double lds[TLD * 16 + 16];      // transpose tile + zero cells
+    __shared__ __attribute__((aligned(16))) double zl[2][64];               // the control rows of G (and of the regularised G): [a][column]
+
+    const double *cx = a.cx + (size_t)nr * N * b, *cu = a.cu + (size_t)mr * N * b;
+    const double *fx = a.fx + (a.fx_batched ? nn * (FXTV ? N : 1) * b : 0);
+    const double *fu = a.fu + (a.fx_batched ? nm * (FXTV ? N : 1) * b : 0);
+    const double *cxx = a.cxx + (a.cost_batched ? nn * (CTV ? N : 1) * b : 0);
+    const double *cxu = a.cxu + (a.cost_batched ? nm * (CTV ? N : 1) * b : 0);
+    const double *cuu = a.cuu + (a.cost_batched ? mm * (CTV ? N : 1) * b : 0);
+    double *Kg = a.K + nm * N * b, *kg = a.k + (size_t)mr * N * b, *Quug = a.Quu + mm * N * b,
+           *Vxg = a.Vx + (size_t)nr * N * b, *Vxxg = a.Vxx + nn * N * b;
+    const double lam = a.lambda[b];
+
+    // ---- terminal step (backward_pass.jl:234-236 / :197-199)
+    const size_t tl = (size_t)(N - 1);
+    for (int e = lane; e < nr * nr; e += DDP_WAVE) Vxxg[nn * tl + e] = cxx[(CTV ? nn * tl : 0) + e];
+    if (lane < nr) Vxg[(size_t)nr * tl + lane] = cx[(size_t)nr * tl + lane];
+    if (lane < mr * mr) Quug[mm * tl + lane] = cuu[(CTV ? mm * tl : 0) + lane];
+    if (lane < mr * nr) Kg[nm * tl + lane] = 0.0;
+    if (lane < mr) kg[(size_t)mr * tl + lane] = 0.0;
+    if (N < 2) {
+        if (lane == 0) { a.dV[2 * b] = 0.0; a.dV[2 * b + 1] = 0.0; a.diverge[b] = 0; }
+        return;
+    }
+    for (int e = lane; e < TLD * 16 + 16; e += DDP_WAVE) lds[e] = 0.0;
+
+    // ---- per-lane operand streams (tile coordinate -> state index, control index, or nothing)
+    auto six = [&](int r) { return r < nr ? r : -1; };
+    auto uix = [&](int r) { return (r >= NP && r < NP + mr) ? r - NP : -1; };
+    const Stream zeroS = Stream{(const char *)mx_zero, 0u, nullptr};
+    auto h_stream = [&](int row, int col) -> Stream {       // H = [cxx cxu; cxu' cuu] in tile coordinates; identity for the unused controls
+        const int sr = six(row), sc = six(col), ur = uix(row), uc = uix(col);
+        if (sr >= 0 && sc >= 0) return Stream{(const char *)(cxx + sr + nr * sc), CTV ? (unsigned)(nn * 8) : 0u, nullptr};
+        if (sr >= 0 && uc >= 0) return Stream{(const char *)(cxu + sr + nr * uc), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
+        if (ur >= 0 && sc >= 0) return Stream{(const char *)(cxu + sc + nr * ur), CTV ? (unsigned)(nm * 8) : 0u, nullptr};
+        if (ur >= 0 && uc >= 0) return Stream{(const char *)(cuu + ur + mr * uc), CTV ? (unsigned)(mm * 8) : 0u, nullptr};
+        if (row == col && row >= NP + mr && row < NP + MS) return Stream{(const char *)mx_one, 0u, nullptr};
+        return zeroS;
+    };
+    auto f_stream = [&](int row, int col) -> Stream {       // F = [fx fu] in tile coordinates, zero outside
+        const int sr = six(row), sc = six(col), uc = uix(col);
+        if (sr >= 0 && sc >= 0) return Stream{(const char *)(fx + sr + nr * sc), FXTV ? (unsigned)(nn * 8) : 0u, nullptr};
+        if (sr >= 0 && uc >= 0) return Stream{(const char *)(fu + sr + nr * uc), FXTV ? (unsigned)(nm * 8) : 0u, nullptr};
+        return zeroS;
+    };
+    auto e_stream = [&](int row) -> Stream {                // column VG of the C operand: [cx; cu] (:239-241)
+        if (six(row) >= 0) return Stream{(const char *)(cx + row), (unsigned)(nr * 8), nullptr};
+        if (uix(row) >= 0) return Stream{(const char *)(cu + (row - NP)), (unsigned)(mr * 8), nullptr};
+        return zeroS;
+    };
+    Stream cS[4], fS[KS];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        cS[s] = l15 == VG ? e_stream(l4 + 4 * s) : h_stream(l4 + 4 * s, l15);
+        if (s < KS) fS[s] = f_stream(l4 + 4 * s, l15);
+    }
+
+    // ---- loop-invariant lane constants
+    const double maskV = l15 == VG ? 1.0 : 0.0;
+    const int wr = l4 + TLD * l15;                           // accumulator register s -> tile element (l4+4s, l15)
+    const int rdT = l15 == VG ? TZERO : l15 + TLD * l4;      // its transpose (l15, l4+4s): + 4*TLD per register
+    const int rdS = l15 == VG ? 0 : 4 * TLD;
+    const bool v_col = l15 < nr || l15 == VG;
+    const double vscl = l15 == VG ? 1.0 : 0.5;               // registers hold V + V'; column VG holds Vx itself
+    char *vst = l15 == VG ? (char *)(Vxg + (size_t)nr * (tl - 1) + l4) : (char *)(Vxxg + nn * (tl - 1) + l4 + nr * (l15 < nr ? l15 : 0));
+    const unsigned vst_stride = l15 == VG ? (unsigned)(nr * 8) : (unsigned)(nn * 8);
+    unsigned long long lanesV[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) lanesV[s] = __builtin_amdgcn_ballot_w64(v_col && l4 + 4 * s < nr);
+    // K | k | Quu ride on one store: lane (a = l4, column): columns < n: K[a, col]; column VG: k[a]; control columns: Quu[a, col - NP]
+    const bool quu_lane = uix(l15) >= 0;
+    const unsigned long long lanesK = __builtin_amdgcn_ballot_w64(l4 < mr && (l15 < nr || l15 == VG || quu_lane));
+    char *kq = l15 < nr ? (char *)(Kg + nm * (tl - 1) + l4 + mr * l15)
+                        : (l15 == VG ? (char *)(kg + (size_t)mr * (tl - 1) + l4) : (char *)(Quug + mm * (tl - 1) + l4 + mr * (quu_lane ? l15 - NP : 0)));
+    const unsigned kq_stride = l15 < nr ? (unsigned)(nm * 8) : (l15 == VG ? (unsigned)(mr * 8) : (unsigned)(mm * 8));
+
+    // ---- register-resident operands: ring of PD steps for what moves in time
+    double F[KS], Fh[KS];                                    // F_s (A of GEMM2), ½F_s (B of GEMM1: A carries V + V')
+    double cr[PD][4], fr[FXTV ? PD : 1][KS];
+    const int i0 = N - 2;
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+        const int t = i0 - j > 0 ? i0 - j : 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            cr[j][s] = cS[s].at(t);
+            if (FXTV && s < KS) fr[j][s] = fS[s].at(t);
+        }
+    }
+    {
+        const int t = i0 - PD > 0 ? i0 - PD : 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { cS[s].seek(t); if (s < KS) fS[s].seek(t); }
+    }
+    if (!FXTV) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { F[s] = fS[s].at(0); Fh[s] = 0.5 * F[s]; }
+    }
+
+    // value function of the terminal step in tile layout: S = 2 Vxx, column VG: Vx
+    double S[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int row = l4 + 4 * s;
+        S[s] = (l15 < nr && row < nr) ? 2.0 * cxx[(CTV ? nn * tl : 0) + row + nr * l15] : ((l15 == VG && row < nr) ? cx[(size_t)nr * tl + row] : 0.0);
+    }
+    const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
+    wave_sync();
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): all set-up loads have landed
+
+    double dVa = 0.0, dVp = 0.0;                    // Σ k'Qu (lanes of column VG) and the per-row parts of Σ k'(Quu k + Qu)
+    int diverge = 0;
+    auto reg = [](const d4 &v, int r) __attribute__((always_inline)) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
+    // One time step; no exits inside (a diverged trajectory steps through garbage until the loop around the step looks at `diverge`;
+    // its outputs below the failing step are zero-filled after the loop).
+    auto step = [&](const int i, auto slot_c) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_c)::value;
+        const bool okp = diverge == 0;
+        const d4 c = d4{cr[slot][0], cr[slot][1], cr[slot][2], cr[slot][3]};
+        if (FXTV) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { F[s] = fr[slot][s]; Fh[s] = 0.5 * F[s]; }
+        }
+        // ================= GEMM1: W = Vxx·F; column VG := Vx (F[:,VG] = 0, S[:,VG] = Vx) ============================
+        d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], Fh[0], zero4, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < KS; ++s) w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[s], Fh[s], w, 0, 0, 0);
+        double W[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) W[s] = fma(S[s], maskV, reg(w, s));
+        // ================= GEMM2: G = F'W + H, column VG: [cx;cu] + F'Vx  (:203-210, :239-247) =====================
+        d4 g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], W[0], c, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < KS; ++s) g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], W[s], g, 0, 0, 0);
+        const double Z = reg(g, UR) + 0.0;                 // lane (a, col): G[control a][col] = Qux | Quu | Qu
+        double gx[KS];                                     // G's rows < NP through the vector ALU (row broadcasts read them below)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) gx[s] = reg(g, s) + 0.0;
+        zl[0][lane] = Z;
+        if (REG2) {                                        // control rows of F'(W + λF) + H: Qux_reg, QuuF (:205-207);  λF = 2λ·(½F)
+            const double lam2 = 2.0 * lam;
+            d4 gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], fma(lam2, Fh[0], W[0]), c, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], fma(lam2, Fh[s], W[s]), gr, 0, 0, 0);
+            zl[1][lane] = reg(gr, UR) + 0.0;
+        }
+        wave_sync();
+        // ================= gains (backward_pass.jl:30-42): every lane factorises QuuF, solves its own column ===========
+        const double *zs = zl[REG2 ? 1 : 0];
+        double Hq[MS * MS], R[MS * MS], ri[MS], q[MS];
+#pragma unroll
+        for (int c2 = 0; c2 < MS; ++c2) {
+            q[c2] = zs[16 * c2 + l15];
+#pragma unroll
+            for (int c1 = 0; c1 <= c2; ++c1) Hq[c1 + MS * c2] = zs[16 * c1 + NP + c2] + ((!REG2 && c1 == c2) ? lam : 0.0);
+        }
+        double Qu[MS];                                     // unregularised rows at my column (dV; column VG: Qu)
+#pragma unroll
+        for (int c2 = 0; c2 < MS; ++c2) Qu[c2] = REG2 ? zl[0][16 * c2 + l15] : q[c2];
+        const int fail = ddp_chol_rinv<MS>(Hq, R, ri);
+        ddp_rsolve_neg<MS>(R, ri, q);                      // q <- -(QuuF)\q: K[:, col] (:42), column VG: k_i (:41)
+        double Ksel = l4 == 0 ? q[0] : (l4 == 1 ? q[1] : (l4 == 2 ? q[2] : (MS > 3 ? q[MS - 1] : 0.0)));
+        // T_a = Quu[a,:]·K + Qux_a (:64) for my row a = l4
+        double Tsel;
+        if (!REG2) {
+            Tsel = -lam * Ksel;                            // regType 1: (Quu + λI) K = -Qux
+        } else {
+            Tsel = Z;
+            static_for<0, MS>([&](auto bc) __attribute__((always_inline)) {
+                constexpr int bb = decltype(bc)::value;
+                if (bb == 0) fmac_bcast<NP + bb, 0xf, true>(Tsel, Z, q[bb]); else fmac_bcast<NP + bb>(Tsel, Z, q[bb]);
+            });
+        }
+        const double Ysel = l15 == VG ? Tsel : Tsel + Z;   // Y = T + Qux; column VG: Quu k + Qu
+        // column VG also wants Qux'k = Σ_a G[:, control a] k_a: row broadcasts of G's control columns, started before the product
+        double xq[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xq[s] = 0.0;
+        static_for<0, MS>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int aa = decltype(ac)::value;
+            const double km = l15 == VG ? q[aa] : 0.0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) fmac_bcast<NP + aa>(xq[s], gx[s], km);
+        });
+        // ================= value update (:69-72): D = G + K'Y =========================================================
+        const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Ksel, Ysel, g, 0, 0, 0);
+        const bool badu = fail != 0;                       // the same in every lane
+        if (__builtin_expect(badu || !okp, 0)) {
+            asm volatile("" ::: "memory");
+            if (okp) diverge = i + 1;                      // diverge = i (:37-38)
+        } else {                                           // column VG: k'Qu and k_a (Quu k + Qu)_a  (:68)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c2 = 0; c2 < MS; ++c2) dVa = fma(q[c2], Qu[c2], dVa);
+            dVp = fma(Ksel, Tsel, dVp);
+        }
+        // ---- V + V' through the transpose tile (column VG: Vx, not symmetrised)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) lds[wr + 4 * s] = reg(v, s);
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) S[s] = (reg(v, s) + lds[rdT + s * rdS]) + xq[s];
+        // Stores are unconditional: a diverged trajectory writes garbage into time steps that are zero-filled after the loop
+#pragma unroll
+        for (int s = 0; s < KS; ++s) store_masked(vst + 32 * s, vscl * S[s], lanesV[s]);
+        store_masked(kq, quu_lane ? Z : Ksel, lanesK);     // K | k | Quu (:75-76)
+        vst -= vst_stride;
+        kq -= kq_stride;
+        wave_sync();                                       // the tile and the image are free again
+        {   // refill the ring slot with the step PD ahead (clamped: always a valid load)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                cr[slot][s] = cS[s].next();
+                if (FXTV && s < KS) fr[slot][s] = fS[s].next();
+            }
+            if (i - PD > 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    cS[s].back();
+                    if (FXTV && s < KS) fS[s].back();
+                }
+            }
+        }
+    };
+    int i = i0;
+    while (i >= PD - 1 && diverge == 0) {
+        static_for<0, PD>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc); });
+        i -= PD;
+    }
+    static_for<0, PD - 1>([&](auto sc) __attribute__((always_inline)) {    // the last (N-1) mod PD steps
+        if (i >= 0 && diverge == 0) { step(i, sc); --i; }
+    });
+
+    if (diverge) {   // outputs earlier in time than the failing step are zero (backward_pass.jl:226-229)
+        const size_t ie = (size_t)diverge;          // = i + 1
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the garbage of the steps after the failure has landed
+        for (size_t e = lane; e < nm * ie; e += DDP_WAVE) Kg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)mr * ie; e += DDP_WAVE) kg[e] = 0.0;
+        for (size_t e = lane; e < (size_t)nr * ie; e += DDP_WAVE) Vxg[e] = 0.0;
+        for (size_t e = lane; e < nn * ie; e += DDP_WAVE) Vxxg[e] = 0.0;
+        for (size_t e = lane; e < mm * (ie - 1); e += DDP_WAVE) Quug[e] = 0.0;
+    }
+    {   // dV (:68): [Σ k'Qu, ½ Σ k'Quu k];  k'Quu k = k'(Quu k + Qu) - k'Qu, the control rows live in lanes VG, 16+VG, 32+VG, 48+VG
+        double kT = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int plo = __builtin_amdgcn_readlane(__double2loint(dVp), 16 * r + VG), phi = __builtin_amdgcn_readlane(__double2hiint(dVp), 16 * r + VG);
+            if (r < MS) kT += __hiloint2double(phi, plo);
+        }
+        if (lane == VG) { a.dV[2 * b] = dVa; a.dV[2 * b + 1] = 0.5 * (kT - dVa); }
+    }
+    if (lane == 0) a.diverge[b] = diverge;
+}
+
+template <int NP, bool REG2>
+int launch_mxg(ddp_handle h, const ddp_bp_desc *d, const BPXArgs &a)
+{
+    const dim3 grid(d->B), block(DDP_WAVE);
+    const int key = (d->fx_tv ? 2 : 0) | (d->cost_tv ? 1 : 0);
+    switch (key) {
+    case 0: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, false, REG2>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, true, REG2>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, false, REG2>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, true, REG2>), grid, block, 0, h->stream, a); break;
+    }
+    DDP_HIP(hipGetLastError());
+    return 0;
+}
+
+}   // namespace
+
+// returns 1 if this shape is not handled here, 0 launched, <0 error
+int ddp_launch_back_pass_mxg(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const double *lambda, const int32_t *active, double *K,
+                             double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge)
+{
+    if (d->has_lims || d->m > 4 || d->n > 12 || d->n + d->m > 15) return 1;
+    const int np = d->n <= 4 ? 4 : (d->n <= 8 ? 8 : 12);
+    if (np == 12 && d->m > 3) return 1;
+    BPXArgs a;
+    a.N = d->N; a.B = d->B; a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.n = d->n; a.m = d->m;
+    a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    const bool r2 = d->regType == 2;
+    switch (np) {
+    case 4: return r2 ? launch_mxg<4, true>(h, d, a) : launch_mxg<4, false>(h, d, a);
+    case 8: return r2 ? launch_mxg<8, true>(h, d, a) : launch_mxg<8, false>(h, d, a);
+    default: return r2 ? launch_mxg<12, true>(h, d, a) : launch_mxg<12, false>(h, d, a);
+    }
+}

@@ -105,3 +105,82 @@ def test_tile_kernel_full_size_off_shape(ddp):
     assert _lib.default_handle().last_kernel(0) in (NAME, "sh_back_kernel")
     who = sorted({0, 1, 2, 3, B - 1, B - 2} | set(int(v) for v in rng.integers(0, B, 18)))
     _check(ddp, out, args, 0.1, 1, None, False, who=who)
+
+
+# ------------------------------------------------------------------------------------- back_pass_mxg.hip: n <= 12, m <= 4 in one tile
+WNAME = "back_pass_mxg_kernel"
+# every padded size NP = 4, 8, 12, every m = 1 .. 4 (m <= 3 above n = 8), odd and even n, the corners (4,4), (8,4), (12,3)
+WSHAPES = [(1, 1), (2, 3), (3, 4), (4, 2), (4, 4), (5, 3), (6, 3), (6, 4), (7, 3), (8, 1), (8, 4), (9, 3), (10, 3), (11, 2), (11, 3), (12, 1), (12, 2),
+           (12, 3)]
+
+
+@pytest.mark.parametrize("n,m", WSHAPES)
+@pytest.mark.parametrize("kind", ["lti", "ltv", "tv"])
+def test_wide_tile_kernel_every_shape_vs_oracle(ddp, n, m, kind):
+    rng = np.random.default_rng(3000 * n + 10 * m + len(kind))
+    N, B = 27, 7
+    args = _problem(rng, n, m, N, B, kind)
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    for regType in (1, 2):
+        out, name = _run(ddp, args, lam, regType, None, "wtile")
+        assert name == WNAME, name
+        _check(ddp, out, args, lam, regType, None, False)
+
+
+@pytest.mark.parametrize("n,m", [(7, 4), (12, 3), (11, 1), (3, 3)])
+def test_wide_tile_kernel_is_the_default_dispatch_without_limits(ddp, n, m):
+    from ddp_amd import _lib
+    rng = np.random.default_rng(177 * n + m)
+    N, B = 40, 9
+    args = _problem(rng, n, m, N, B, "ltv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, None, x, u)
+    assert _lib.default_handle().last_kernel(0) == WNAME
+    ref, name = _run(ddp, args, 0.3, 1, None, "row")
+    assert name == "back_pass_row_kernel"
+    assert np.array_equal(out[0], ref[0])
+    for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4]), (out[1].Σi, ref[1].Σi)):
+        assert relerr(a_, b_) < 1e-10
+    L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
+    ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, L, x, u)
+    assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+
+
+def test_wide_tile_kernel_agrees_with_the_exact_tile_kernel(ddp):
+    rng = np.random.default_rng(5)
+    args = _problem(rng, 10, 2, 61, 5, "tv")
+    for regType in (1, 2):
+        a, na = _run(ddp, args, 0.05, regType, None, "wtile")
+        b, nb = _run(ddp, args, 0.05, regType, None, "x")
+        assert na == WNAME and nb.startswith("back_pass_mx"), (na, nb)
+        for p_, q_ in ((a[1].K, b[1].K), (a[1].k, b[1].k), (a[2], b[2]), (a[3], b[3]), (a[4], b[4]), (a[1].Σi, b[1].Σi)):
+            assert relerr(p_, q_) < 1e-11
+
+
+@pytest.mark.parametrize("n,m", [(5, 3), (8, 4), (12, 3)])
+def test_wide_tile_kernel_per_trajectory_operands_inactive_and_divergence(ddp, n, m):
+    from ddp_amd import _lib
+    rng = np.random.default_rng(231 * n + m)
+    N, B = 19, 10
+    args = _problem(rng, n, m, N, B, "btv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    lam = np.full(B, 0.2); lam[[1, 6]] = -50.0
+    for regType in (1, 2):
+        out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, None, x, u)
+        assert _lib.default_handle().last_kernel(0) == WNAME
+        if regType == 1:
+            assert out[0][1] == N - 1 and out[0][6] == N - 1 and out[0][0] == 0
+        _check(ddp, out, args, lam, regType, None, True)
+    lam = np.full(B, 0.2); lam[[2, 5]] = -0.12
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 1, None, x, u)
+    _check(ddp, out, args, lam, 1, None, True)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 8, 9, 10, 17])
+@pytest.mark.parametrize("n,m", [(3, 3), (7, 4), (12, 3)])
+def test_wide_tile_kernel_short_horizons(ddp, n, m, N):
+    rng = np.random.default_rng(27 * n + m + N)
+    args = _problem(rng, n, m, N, 5, "tv")
+    out, name = _run(ddp, args, 0.1, 1, None, "wtile")
+    assert name == WNAME
+    _check(ddp, out, args, 0.1, 1, None, False)
