@@ -22,7 +22,7 @@ def spd(rng, d, s):
 # every (n, m) the padded row kernels (csrc/back_pass_row.hip, forward_pass_row.hip) hold: n <= 14, m <= 4, n + m <= 15 and their table of
 # padded sizes — the sweep of round 5 draws from these with the row kernel forced, dispatched by default, or the run-time-sized kernel
 ROW_SHAPES = [(n_, m_) for n_ in range(1, 15) for m_ in range(1, 5) if n_ + m_ <= 15 and not (n_ > 12 and m_ > 1) and not (n_ > 10 and m_ > 3)]
-ROW_IMPLS = [None, None, "row", "row", "general"]
+ROW_IMPLS = [None, None, "row", "row", "general", "tile", "wtile", "mid"]       # a forced kernel that does not hold the shape falls through
 
 
 def gen_case(rng, shapes=None, impls=None):

@@ -76,6 +76,16 @@ def _check(ddp, out, args, lam, regType, L, batched, who=None):
             assert not pol.K[:, :, : d - 1, b].any() and not Vxx[:, :, : d - 1, b].any() and not Vx[:, : d - 1, b].any()
 
 
+def _default_kernel(n, m, lims):
+    """what the dispatcher picks for a small batch of a shape without an exact instantiation: without limits the fp64 tile kernels
+    (run-time sizes inside the (10, 2) tile for m <= 2; one tile for n <= 12, m <= 4), with limits the row kernel"""
+    if lims is None and n <= 10 and m <= 2:
+        return "back_pass_mx_kernel<RT>"
+    if lims is None and n <= 12 and m <= (4 if n <= 8 else 3):
+        return "back_pass_mxg_kernel"
+    return "back_pass_row_kernel"
+
+
 def _run(ddp, args, lam, regType, L, force):
     from ddp_amd import _lib
     cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
@@ -140,7 +150,8 @@ def test_row_kernel_per_trajectory_operands_inactive_and_divergence(ddp, n, m):
 
 
 def test_row_kernel_full_size_off_shapes(ddp):
-    """the two off-shape lines of bench.py's other_configs at full size: a sample of trajectories against the oracle"""
+    """the two off-shape lines of bench.py's other_configs at full size (default dispatch: the wide tile kernel for the one without limits,
+    the row kernel for the one with), and the row kernel forced at the first: a sample of trajectories against the oracle"""
     from ddp_amd import _lib
     rng = np.random.default_rng(5150)
     for n, m, N, B, kind, lims in ((12, 3, 500, 2048, "ltv", False), (6, 2, 1000, 4096, "lti", True)):
@@ -148,9 +159,13 @@ def test_row_kernel_full_size_off_shapes(ddp):
         cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
         L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1) if lims else None
         out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.1, 1, L, x, u)
-        assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+        assert _lib.default_handle().last_kernel(0) == _default_kernel(n, m, L)
         who = sorted({0, 1, 2, 3, B - 1, B - 2} | set(int(v) for v in rng.integers(0, B, 18)))
         _check(ddp, out, args, 0.1, 1, L, False, who=who)
+        if not lims:
+            out, name = _run(ddp, args, 0.1, 1, L, "row")
+            assert name == "back_pass_row_kernel"
+            _check(ddp, out, args, 0.1, 1, L, False, who=who)
 
 
 # ------------------------------------------------------------------------------------------------------------------ forward_pass
@@ -261,8 +276,7 @@ def test_row_kernels_short_horizons(ddp, n, m, N):
         L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
         for lims in (None, L):
             out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.2, 1, lims, x, u)
-            tile = lims is None and n <= 10 and m <= 2                       # small batches without limits: the run-time-sized tile kernel
-            assert _lib.default_handle().last_kernel(0) == ("back_pass_mx_kernel<RT>" if tile else "back_pass_row_kernel")
+            assert _lib.default_handle().last_kernel(0) == _default_kernel(n, m, lims)
             _check(ddp, out, args, 0.2, 1, lims, False)
         A, Bm, Q, R = _lq(rng, n, m, N, B, True, False)
         prob = ddp.LQProblem(A, Bm, Q, R)
