@@ -9,10 +9,12 @@
 //     (MS = 4, or 3 at NP = 12) is factorised redundantly by every lane (upper Cholesky with reciprocal pivots: the pivots are the
 //     positive-definiteness test of :35-38) and each lane solves its own column — K for the columns < n, k for column 15 (:41-42);
 //     controls m .. MS-1 are an identity block of the system (K rows exactly zero);
-//   * value update (:69-72) in ONE product for any m <= 4:  D = G + K'Y,  Y = (Quu K + Qux) + Qux,  V + V' = D + D'  (the transpose
+//   * value update (:69-72) for any m <= 4:  D = G + K'Y + Qux'[0 | k],  Y = (Quu K + Qux) + Qux,  V = ½(D + D')  (the transpose
 //     comes through the padded LDS tile as in back_pass_mx.hip); column 15 is not symmetrised and wants K'(Quu k + Qu) + Qux'k: the
-//     first term is the product with Y[:,15] = Quu k + Qu, the second is added by row broadcasts of G's control columns.
-// Per step: 2·NP/4 + 1 (+ NP/4 for regType 2) dependent matrix instructions, two LDS round trips, ~150 vector instructions.
+//     first term is the product with Y[:,15] = Quu k + Qu, the second a product of the control rows of G with k in column 15.
+// Per step: 2·NP/4 + 2 (+ NP/4 for regType 2) dependent matrix instructions, two LDS round trips, ~170 other instructions (the wave
+// is issue-bound: a second wave on the SIMD does not hide anything, so selects are multiplications by lane constants, the stores
+// share exec-mask switches, and what a 64-cycle matrix instruction can replace of > 11 vector instructions goes to the matrix pipe).
 // Measured against the 16-lane-row kernel it replaces for small and medium batches: DESIGN.md §3.2.
 #include "ddp_internal.h"
 
@@ -21,6 +23,29 @@ namespace {
 #include "back_pass_mx_common.h"
 
 constexpr int VG = 15;                              // tile column of the vectors
+#ifndef MXG_EXP
+#define MXG_EXP 0          // timing experiments (wrong results): 1 no result stores, 2 no operand refills, 4 no transpose round trip
+#endif
+
+// the stores of a step under three exec masks (registers 0 .. KS-2 of V | the last one | K, k, Quu): one switch per mask, the row
+// registers 32 bytes apart through the instruction's offset field
+template <int KS>
+__device__ __forceinline__ void store_results(char *vst, const double (&S)[KS], unsigned long long full, unsigned long long last,
+                                              char *kq, double kv, unsigned long long lanesK)
+{
+    if constexpr (KS == 1)
+        asm volatile("s_mov_b64 exec, %2\n\tglobal_store_dwordx2 %0, %1, off\n\ts_mov_b64 exec, %5\n\tglobal_store_dwordx2 %3, %4, off\n\ts_mov_b64 exec, -1"
+                     ::"v"(vst), "v"(S[0]), "s"(last), "v"(kq), "v"(kv), "s"(lanesK) : "memory");
+    else if constexpr (KS == 2)
+        asm volatile("s_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, off\n\ts_mov_b64 exec, %4\n\tglobal_store_dwordx2 %0, %2, off offset:32\n\t"
+                     "s_mov_b64 exec, %7\n\tglobal_store_dwordx2 %5, %6, off\n\ts_mov_b64 exec, -1"
+                     ::"v"(vst), "v"(S[0]), "v"(S[1]), "s"(full), "s"(last), "v"(kq), "v"(kv), "s"(lanesK) : "memory");
+    else
+        asm volatile("s_mov_b64 exec, %4\n\tglobal_store_dwordx2 %0, %1, off\n\tglobal_store_dwordx2 %0, %2, off offset:32\n\t"
+                     "s_mov_b64 exec, %5\n\tglobal_store_dwordx2 %0, %3, off offset:64\n\t"
+                     "s_mov_b64 exec, %8\n\tglobal_store_dwordx2 %6, %7, off\n\ts_mov_b64 exec, -1"
+                     ::"v"(vst), "v"(S[0]), "v"(S[1]), "v"(S[2]), "s"(full), "s"(last), "v"(kq), "v"(kv), "s"(lanesK) : "memory");
+}
 
 template <int NP, bool FXTV, bool CTV, bool REG2>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
@@ -89,17 +114,17 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     }
 
     // ---- loop-invariant lane constants
-    const double maskV = l15 == VG ? 1.0 : 0.0;
+    const double maskV = l15 == VG ? 1.0 : 0.0, maskM = l15 == VG ? 0.0 : 1.0;
+    const double rowm[4] = {l4 == 0 ? 1.0 : 0.0, l4 == 1 ? 1.0 : 0.0, l4 == 2 ? 1.0 : 0.0, (l4 == 3 && MS > 3) ? 1.0 : 0.0};
     const int wr = l4 + TLD * l15;                           // accumulator register s -> tile element (l4+4s, l15)
     const int rdT = l15 == VG ? TZERO : l15 + TLD * l4;      // its transpose (l15, l4+4s): + 4*TLD per register
     const int rdS = l15 == VG ? 0 : 4 * TLD;
     const bool v_col = l15 < nr || l15 == VG;
-    const double vscl = l15 == VG ? 1.0 : 0.5;               // registers hold V + V'; column VG holds Vx itself
+    const double vscl = l15 == VG ? 1.0 : 0.5;               // V = ½(D + D'); column VG: Vx = D[:,VG] (its transposed read is a zero cell)
     char *vst = l15 == VG ? (char *)(Vxg + (size_t)nr * (tl - 1) + l4) : (char *)(Vxxg + nn * (tl - 1) + l4 + nr * (l15 < nr ? l15 : 0));
     const unsigned vst_stride = l15 == VG ? (unsigned)(nr * 8) : (unsigned)(nn * 8);
-    unsigned long long lanesV[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) lanesV[s] = __builtin_amdgcn_ballot_w64(v_col && l4 + 4 * s < nr);
+    // rows 4s .. 4s+3 of the registers s < KS-1 are all states (NP = n rounded up to 4): one mask for them, one for the last register
+    const unsigned long long lanesVf = __builtin_amdgcn_ballot_w64(v_col), lanesVl = __builtin_amdgcn_ballot_w64(v_col && l4 + 4 * (KS - 1) < nr);
     // K | k | Quu ride on one store: lane (a = l4, column): columns < n: K[a, col]; column VG: k[a]; control columns: Quu[a, col - NP]
     const bool quu_lane = uix(l15) >= 0;
     const unsigned long long lanesK = __builtin_amdgcn_ballot_w64(l4 < mr && (l15 < nr || l15 == VG || quu_lane));
@@ -108,7 +133,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     const unsigned kq_stride = l15 < nr ? (unsigned)(nm * 8) : (l15 == VG ? (unsigned)(mr * 8) : (unsigned)(mm * 8));
 
     // ---- register-resident operands: ring of PD steps for what moves in time
-    double F[KS], Fh[KS];                                    // F_s (A of GEMM2), ½F_s (B of GEMM1: A carries V + V')
+    double F[KS];                                            // F_s: B of GEMM1, A of GEMM2
     double cr[PD][4], fr[FXTV ? PD : 1][KS];
     const int i0 = N - 2;
 #pragma unroll
@@ -127,20 +152,33 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     }
     if (!FXTV) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { F[s] = fS[s].at(0); Fh[s] = 0.5 * F[s]; }
+        for (int s = 0; s < KS; ++s) F[s] = fS[s].at(0);
     }
 
-    // value function of the terminal step in tile layout: S = 2 Vxx, column VG: Vx
+    // value function of the terminal step in tile layout: S = Vxx, column VG: Vx
     double S[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int row = l4 + 4 * s;
-        S[s] = (l15 < nr && row < nr) ? 2.0 * cxx[(CTV ? nn * tl : 0) + row + nr * l15] : ((l15 == VG && row < nr) ? cx[(size_t)nr * tl + row] : 0.0);
+        S[s] = (l15 < nr && row < nr) ? cxx[(CTV ? nn * tl : 0) + row + nr * l15] : ((l15 == VG && row < nr) ? cx[(size_t)nr * tl + row] : 0.0);
     }
     const d4 zero4 = d4{0.0, 0.0, 0.0, 0.0};
     wave_sync();
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): all set-up loads have landed
 
+    // MXG_EXP & 8 (timing experiment): contiguous 16-byte pieces of the step's result blocks
+    char *xA = (char *)(Vxxg + nn * (tl - 1)) + 16 * (lane < (int)(nn / 2) ? lane : 0), *xB = xA;
+    unsigned xBs = (unsigned)(nn * 8);
+    int xn2 = 0;
+    if (MXG_EXP & 8) {
+        const int t1 = (int)(nn / 2) - 64 > 0 ? (int)(nn / 2) - 64 : 0, t2 = t1 + (int)(nm / 2), t3 = t2 + nr / 2, t4 = t3 + (mr + 1) / 2, t5 = t4 + (int)(mm / 2);
+        xn2 = t5;
+        if (lane < t1) { xB = (char *)(Vxxg + nn * (tl - 1)) + 1024 + 16 * lane; xBs = (unsigned)(nn * 8); }
+        else if (lane < t2) { xB = (char *)(Kg + nm * (tl - 1)) + 16 * (lane - t1); xBs = (unsigned)(nm * 8); }
+        else if (lane < t3) { xB = (char *)(Vxg + (size_t)nr * (tl - 1)) + 16 * (lane - t2); xBs = nr * 8u; }
+        else if (lane < t4) { xB = (char *)(kg + (size_t)mr * (tl - 1)) + 8 * (lane - t3); xBs = mr * 8u; }
+        else { xB = (char *)(Quug + mm * (tl - 1)) + 16 * (lane < t5 ? lane - t4 : 0); xBs = (unsigned)(mm * 8); }
+    }
     double dVa = 0.0, dVp = 0.0;                    // Σ k'Qu (lanes of column VG) and the per-row parts of Σ k'(Quu k + Qu)
     int diverge = 0;
     auto reg = [](const d4 &v, int r) __attribute__((always_inline)) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
@@ -152,12 +190,12 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
         const d4 c = d4{cr[slot][0], cr[slot][1], cr[slot][2], cr[slot][3]};
         if (FXTV) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) { F[s] = fr[slot][s]; Fh[s] = 0.5 * F[s]; }
+            for (int s = 0; s < KS; ++s) F[s] = fr[slot][s];
         }
         // ================= GEMM1: W = Vxx·F; column VG := Vx (F[:,VG] = 0, S[:,VG] = Vx) ============================
-        d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], Fh[0], zero4, 0, 0, 0);
+        d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], F[0], zero4, 0, 0, 0);
 #pragma unroll
-        for (int s = 1; s < KS; ++s) w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[s], Fh[s], w, 0, 0, 0);
+        for (int s = 1; s < KS; ++s) w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[s], F[s], w, 0, 0, 0);
         double W[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) W[s] = fma(S[s], maskV, reg(w, s));
@@ -165,16 +203,13 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
         d4 g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], W[0], c, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < KS; ++s) g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], W[s], g, 0, 0, 0);
-        const double Z = reg(g, UR) + 0.0;                 // lane (a, col): G[control a][col] = Qux | Quu | Qu
-        double gx[KS];                                     // G's rows < NP through the vector ALU (row broadcasts read them below)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) gx[s] = reg(g, s) + 0.0;
+        // lane (a, col): G[control a][col] = Qux | Quu | Qu  (through the vector ALU where a row broadcast reads it: regType 2)
+        const double Z = REG2 ? reg(g, UR) + 0.0 : reg(g, UR);
         zl[0][lane] = Z;
-        if (REG2) {                                        // control rows of F'(W + λF) + H: Qux_reg, QuuF (:205-207);  λF = 2λ·(½F)
-            const double lam2 = 2.0 * lam;
-            d4 gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], fma(lam2, Fh[0], W[0]), c, 0, 0, 0);
+        if (REG2) {                                        // control rows of F'(W + λF) + H: Qux_reg, QuuF (:205-207)
+            d4 gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], fma(lam, F[0], W[0]), c, 0, 0, 0);
 #pragma unroll
-            for (int s = 1; s < KS; ++s) gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], fma(lam2, Fh[s], W[s]), gr, 0, 0, 0);
+            for (int s = 1; s < KS; ++s) gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], fma(lam, F[s], W[s]), gr, 0, 0, 0);
             zl[1][lane] = reg(gr, UR) + 0.0;
         }
         wave_sync();
@@ -192,7 +227,9 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
         for (int c2 = 0; c2 < MS; ++c2) Qu[c2] = REG2 ? zl[0][16 * c2 + l15] : q[c2];
         const int fail = ddp_chol_rinv<MS>(Hq, R, ri);
         ddp_rsolve_neg<MS>(R, ri, q);                      // q <- -(QuuF)\q: K[:, col] (:42), column VG: k_i (:41)
-        double Ksel = l4 == 0 ? q[0] : (l4 == 1 ? q[1] : (l4 == 2 ? q[2] : (MS > 3 ? q[MS - 1] : 0.0)));
+        double Ksel = q[0] * rowm[0];                      // K[a = l4, col]: a sum with lane constants 1 / 0, no selects
+#pragma unroll
+        for (int c2 = 1; c2 < MS; ++c2) Ksel = fma(q[c2], rowm[c2], Ksel);
         // T_a = Quu[a,:]·K + Qux_a (:64) for my row a = l4
         double Tsel;
         if (!REG2) {
@@ -204,19 +241,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
                 if (bb == 0) fmac_bcast<NP + bb, 0xf, true>(Tsel, Z, q[bb]); else fmac_bcast<NP + bb>(Tsel, Z, q[bb]);
             });
         }
-        const double Ysel = l15 == VG ? Tsel : Tsel + Z;   // Y = T + Qux; column VG: Quu k + Qu
-        // column VG also wants Qux'k = Σ_a G[:, control a] k_a: row broadcasts of G's control columns, started before the product
-        double xq[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) xq[s] = 0.0;
-        static_for<0, MS>([&](auto ac) __attribute__((always_inline)) {
-            constexpr int aa = decltype(ac)::value;
-            const double km = l15 == VG ? q[aa] : 0.0;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) fmac_bcast<NP + aa>(xq[s], gx[s], km);
-        });
-        // ================= value update (:69-72): D = G + K'Y =========================================================
-        const d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Ksel, Ysel, g, 0, 0, 0);
+        const double Ysel = fma(Z, maskM, Tsel);           // Y = T + Qux; column VG: Quu k + Qu
+        // ================= value update (:69-72): D = G + K'Y, column VG also + Qux'k ==================================
+        d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Ksel, Ysel, g, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f64_16x16x4f64(Z, Ksel * maskV, v, 0, 0, 0);     // A[i][a] = G[control a][i], B[a][VG] = k_a
         const bool badu = fail != 0;                       // the same in every lane
         if (__builtin_expect(badu || !okp, 0)) {
             asm volatile("" ::: "memory");
@@ -228,19 +256,27 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
             dVp = fma(Ksel, Tsel, dVp);
         }
         // ---- V + V' through the transpose tile (column VG: Vx, not symmetrised)
+        if (!(MXG_EXP & 4)) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) lds[wr + 4 * s] = reg(v, s);
-        wave_sync();
+            for (int s = 0; s < KS; ++s) lds[wr + 4 * s] = reg(v, s);
+            wave_sync();
+        }
 #pragma unroll
-        for (int s = 0; s < KS; ++s) S[s] = (reg(v, s) + lds[rdT + s * rdS]) + xq[s];
+        for (int s = 0; s < KS; ++s) S[s] = vscl * (reg(v, s) + ((MXG_EXP & 4) ? reg(v, s) : lds[rdT + s * rdS]));
         // Stores are unconditional: a diverged trajectory writes garbage into time steps that are zero-filled after the loop
-#pragma unroll
-        for (int s = 0; s < KS; ++s) store_masked(vst + 32 * s, vscl * S[s], lanesV[s]);
-        store_masked(kq, quu_lane ? Z : Ksel, lanesK);     // K | k | Quu (:75-76)
+        if (!(MXG_EXP & 1)) store_results<KS>(vst, S, lanesVf, lanesVl, kq, quu_lane ? Z : Ksel, lanesK);      // Vxx | Vx, K | k | Quu (:75-76)
+        else asm volatile("" :: "v"(S[0]), "v"(S[KS - 1]), "v"(Z), "v"(Ksel));
+        if (MXG_EXP & 8) {      // the same bytes as two 16-byte-per-lane stores of contiguous blocks (garbage data): what would coalesced results cost?
+            typedef double d2x __attribute__((ext_vector_type(2)));
+            const d2x val = d2x{S[0], Ksel};
+            *(d2x *)xA = val;
+            if (lane < xn2) *(d2x *)xB = val;
+            xA -= nn * 8; xB -= xBs;
+        }
         vst -= vst_stride;
         kq -= kq_stride;
         wave_sync();                                       // the tile and the image are free again
-        {   // refill the ring slot with the step PD ahead (clamped: always a valid load)
+        if (!(MXG_EXP & 2)) {   // refill the ring slot with the step PD ahead (clamped: always a valid load)
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int s = 0; s < 4; ++s) {

@@ -15,7 +15,7 @@ pairs = [("%s/profiles/%s_bench.json" % (tag, tag), "%s_bench.json" % tag), ("%s
          ("%s_shared_lti_ab.txt" % tag, "%s_shared_lti_ab.txt" % tag)]
 for extra in ("sh_ab.txt", "sh_stores.txt", "sh_chain_floor.txt", "sh_phase_before.json", "sh_phase_after.json", "off_shapes.json", "tests_full.txt"):
     pairs.append(("%s_%s" % (tag, extra), "%s_%s" % (tag, extra)))
-for c in ("c3", "c2tv", "c4", "c5", "offA", "offB"):
+for c in ("c3", "c2tv", "c4", "c5", "offA", "offB", "offC"):
     pairs.append(("%s_%s/summary.txt" % (tag, c), "%s_%s_pmc.txt" % (tag, c)))
 for src, dst in pairs:
     s = os.path.join(G, src)
@@ -26,7 +26,7 @@ for src, dst in pairs:
         print("MISSING", src)
 tf = os.path.join(P, "pmc_traffic.json")
 cur = json.load(open(tf)) if os.path.exists(tf) else {}
-for src in ["%s/profiles/pmc_traffic.json" % tag] + ["%s_%s/pmc_traffic_update.json" % (tag, c) for c in ("c3", "c2tv", "c4", "c5", "offA", "offB")]:
+for src in ["%s/profiles/pmc_traffic.json" % tag] + ["%s_%s/pmc_traffic_update.json" % (tag, c) for c in ("c3", "c2tv", "c4", "c5", "offA", "offB", "offC")]:
     s = os.path.join(G, src)
     if os.path.exists(s):
         cur.update(json.load(open(s)))
