@@ -24,8 +24,31 @@ namespace {
 
 constexpr int VG = 15;                              // tile column of the vectors
 #ifndef MXG_EXP
-#define MXG_EXP 0          // timing experiments (wrong results): 1 no result stores, 2 no operand refills, 4 no transpose round trip
+#define MXG_EXP 0          // timing experiments (wrong results): 1 no result stores, 2 no operand refills
 #endif
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) d2 *g2p;            // explicit global accesses (a FLAT access would wait for the LDS too)
+typedef __attribute__((address_space(1))) d2 *g2w;
+typedef __attribute__((address_space(1))) double *g1w;
+constexpr int even_up(int x) { return (x + 1) & ~1; }
+
+// COAL (the default): what moves in time comes and goes in CONTIGUOUS 16-byte pieces.  profiles/r05_mxg_exp.txt: with one 8-byte
+// element per lane (the tile layout: 16 runs of 32 bytes per instruction) the step at n=12, m=3 costs 0.86 ms at B=2048 against 0.48
+// without any memory operation and 0.53 with only the loads or only the stores — the memory system serves the fine-grained mix at
+// ~3.8 TB/s.  Here a step's operand blocks (fx | fu | cx | cu | cxx | cxu | cuu, whichever are time-varying: each contiguous in
+// memory) are fetched as 16-byte pieces PDC steps ahead, dropped into an LDS image one step before use (two images, by the parity of
+// the unrolled slot), and the tile operands are LDS reads; the results of a step are written into an LDS record in memory order
+// (Vxx | K | Vx | k | Quu) and leave as 16-byte pieces (+ one 8-byte piece per block of odd length).  A piece of an odd-length block
+// reads 8 bytes into the NEXT time step of the same array (never the last one: the loop starts at N-2) and ignores them.
+template <int NP> struct MxgLds {                   // doubles
+    static constexpr int MS = NP == 12 ? 3 : 4;
+    static constexpr int HC = 0, ZERO = 16 * VG, CONSTS = 256;        // offset of the time-invariant H tile [row + 16 col] (its column VG is zero), its size
+    static constexpr int IMG = 2 * even_up(NP * NP) + 2 * even_up(NP * MS) + even_up(NP) + even_up(MS) + even_up(MS * MS);
+    static constexpr int BUF = CONSTS + IMG;
+    static constexpr int RECD = even_up(NP * NP) + even_up(NP * MS) + even_up(NP) + even_up(MS) + even_up(MS * MS);
+    static constexpr int REC = RECD + 64;           // + one dump cell per lane
+};
 
 // the stores of a step under three exec masks (registers 0 .. KS-2 of V | the last one | K, k, Quu): one switch per mask, the row
 // registers 32 bytes apart through the instruction's offset field
@@ -47,10 +70,16 @@ __device__ __forceinline__ void store_results(char *vst, const double (&S)[KS], 
                      ::"v"(vst), "v"(S[0]), "v"(S[1]), "v"(S[2]), "s"(full), "s"(last), "v"(kq), "v"(kv), "s"(lanesK) : "memory");
 }
 
-template <int NP, bool FXTV, bool CTV, bool REG2>
+template <int NP, bool FXTV, bool CTV, bool REG2, bool COAL>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
 {
     constexpr int KS = NP / 4, UR = NP / 4, MS = NP == 12 ? 3 : 4;
+    using L = MxgLds<NP>;
+    // 16-byte pieces of a step's time-varying operand blocks / of its result blocks -> vector-memory instructions per step
+    constexpr int LPC = (FXTV ? even_up(NP * NP) / 2 + even_up(NP * MS) / 2 : 0) + even_up(NP) / 2 + even_up(MS) / 2 +
+                        (CTV ? even_up(NP * NP) / 2 + even_up(NP * MS) / 2 + even_up(MS * MS) / 2 : 0);
+    constexpr int NLI = (LPC + 63) / 64, NSI = (L::RECD / 2 + 63) / 64;
+    constexpr int PDC = COAL ? (NLI <= 2 ? 8 : 4) : PD;       // prefetch distance = slots of the unrolled loop (even)
     const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
     if (a.active && a.active[b] == 0) return;
     const int N = a.N, nr = a.n, mr = a.m;
@@ -58,6 +87,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
 
     __shared__ __attribute__((aligned(16))) double lds[TLD * 16 + 16];      // transpose tile + zero cells
     __shared__ __attribute__((aligned(16))) double zl[2][64];               // the control rows of G (and of the regularised G): [a][column]
+    __shared__ __attribute__((aligned(16))) double img[COAL ? 2 * L::BUF : 2];   // two operand buffers: constants | image of a step
+    __shared__ __attribute__((aligned(16))) double rec[COAL ? L::REC : 2];      // the result record of a step
 
     const double *cx = a.cx + (size_t)nr * N * b, *cu = a.cu + (size_t)mr * N * b;
     const double *fx = a.fx + (a.fx_batched ? nn * (FXTV ? N : 1) * b : 0);
@@ -132,27 +163,128 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
                         : (l15 == VG ? (char *)(kg + (size_t)mr * (tl - 1) + l4) : (char *)(Quug + mm * (tl - 1) + l4 + mr * (quu_lane ? l15 - NP : 0)));
     const unsigned kq_stride = l15 < nr ? (unsigned)(nm * 8) : (l15 == VG ? (unsigned)(mr * 8) : (unsigned)(mm * 8));
 
-    // ---- register-resident operands: ring of PD steps for what moves in time
+    // ---- register-resident operands: ring of PDC steps for what moves in time
     double F[KS];                                            // F_s: B of GEMM1, A of GEMM2
-    double cr[PD][4], fr[FXTV ? PD : 1][KS];
+    double cr[COAL ? 1 : PDC][4], fr[(FXTV && !COAL) ? PDC : 1][KS];
     const int i0 = N - 2;
+    if constexpr (!COAL) {
 #pragma unroll
-    for (int j = 0; j < PD; ++j) {
-        const int t = i0 - j > 0 ? i0 - j : 0;
+        for (int j = 0; j < PDC; ++j) {
+            const int t = i0 - j > 0 ? i0 - j : 0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            cr[j][s] = cS[s].at(t);
-            if (FXTV && s < KS) fr[j][s] = fS[s].at(t);
+            for (int s = 0; s < 4; ++s) {
+                cr[j][s] = cS[s].at(t);
+                if (FXTV && s < KS) fr[j][s] = fS[s].at(t);
+            }
         }
-    }
-    {
-        const int t = i0 - PD > 0 ? i0 - PD : 0;
+        const int t = i0 - PDC > 0 ? i0 - PDC : 0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) { cS[s].seek(t); if (s < KS) fS[s].seek(t); }
     }
     if (!FXTV) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) F[s] = fS[s].at(0);
+    }
+    // ---- COAL: piece tables.  lg/lgs/lim: my 16-byte piece of instruction j of a step's operand blocks (global pointer, bytes per
+    // step, byte offset in an image); co/fo: where my tile operands sit in a buffer; wS/wK: where my results go in the record;
+    // sp/sstr/srd: my 16-byte piece of instruction j of the record; tp/tstr/trd: the last element of a block of odd length
+    const char *lg[NLI];
+    unsigned lgs[NLI], lim[NLI], co[4], fo[KS], wS[KS], wK = 0, sstr[NSI], srd[NSI], tstr = 0, trd = 0;
+    char *sp[NSI], *tp = nullptr;
+    bool has4 = false, hast = false;
+    d2 ring[COAL ? PDC : 1][NLI];
+    if constexpr (COAL) {
+        const double *bp[7] = {fx, fu, cx, cu, cxx, cxu, cuu};
+        const int bsz[7] = {(int)nn, (int)nm, nr, mr, (int)nn, (int)nm, (int)mm};
+        const bool bon[7] = {FXTV, FXTV, true, true, CTV, CTV, CTV};
+        int off[7], o = L::CONSTS;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { off[q] = o; if (bon[q]) o += even_up(bsz[q]); }
+#pragma unroll
+        for (int j = 0; j < NLI; ++j) {
+            int pi = lane + 64 * j;
+            bool found = false;
+            lg[j] = (const char *)cx; lgs[j] = nr * 8u; lim[j] = (unsigned)off[2] * 8u;     // lanes past the end repeat piece 0 of cx
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                if (!bon[q]) continue;
+                const int np = (bsz[q] + 1) / 2;
+                if (!found && pi < np) { lg[j] = (const char *)bp[q] + 16 * pi; lgs[j] = (unsigned)bsz[q] * 8u; lim[j] = (unsigned)(off[q] + 2 * pi) * 8u; found = true; }
+                if (!found) pi -= np;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = l4 + 4 * r, sr = six(row), sc = six(l15), ur = uix(row), uc = uix(l15);
+            int e = L::HC + row + 16 * l15;                                                    // the constant tile (zero / identity / time-invariant H)
+            if (l15 == VG) e = sr >= 0 ? off[2] + sr : (ur >= 0 ? off[3] + ur : L::ZERO);
+            else if (CTV) {
+                if (sr >= 0 && sc >= 0) e = off[4] + sr + nr * sc;
+                else if (sr >= 0 && uc >= 0) e = off[5] + sr + nr * uc;
+                else if (ur >= 0 && sc >= 0) e = off[5] + sc + nr * ur;
+                else if (ur >= 0 && uc >= 0) e = off[6] + ur + mr * uc;
+            }
+            co[r] = (unsigned)e * 8u;
+            if (r < KS) fo[r] = (unsigned)((sr >= 0 && sc >= 0) ? off[0] + sr + nr * sc : ((sr >= 0 && uc >= 0) ? off[1] + sr + nr * uc : L::ZERO)) * 8u;
+            // constants of both buffers
+            double hv = 0.0;
+            if (l15 != VG) hv = CTV ? ((row == l15 && row >= NP + mr && row < NP + MS) ? 1.0 : 0.0) : h_stream(row, l15).at(0);
+            img[L::HC + row + 16 * l15] = hv; img[L::BUF + L::HC + row + 16 * l15] = hv;
+        }
+        // the record: Vxx | K | Vx | k | Quu in memory order, every block at an even offset
+        const int rsz[5] = {(int)nn, (int)nm, nr, mr, (int)mm};
+        char *rp[5] = {(char *)(Vxxg + nn * (tl - 1)), (char *)(Kg + nm * (tl - 1)), (char *)(Vxg + (size_t)nr * (tl - 1)), (char *)(kg + (size_t)mr * (tl - 1)),
+                       (char *)(Quug + mm * (tl - 1))};
+        int ro[5], o2 = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { ro[q] = o2; o2 += even_up(rsz[q]); }
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+            const int row = l4 + 4 * s2;
+            wS[s2] = (unsigned)((l15 < nr && row < nr) ? ro[0] + row + nr * l15 : ((l15 == VG && row < nr) ? ro[2] + row : L::RECD + lane)) * 8u;
+        }
+        wK = (unsigned)(l4 < mr ? (l15 < nr ? ro[1] + l4 + mr * l15 : (l15 == VG ? ro[3] + l4 : (uix(l15) >= 0 ? ro[4] + l4 + mr * (l15 - NP) : L::RECD + lane))) : L::RECD + lane) * 8u;
+        int first = -1, ntail = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) if (first < 0 && rsz[q] >= 2) first = q;
+        has4 = first >= 0;
+#pragma unroll
+        for (int j = 0; j < NSI; ++j) {
+            int pi = lane + 64 * j;
+            bool found = false;
+            const int f0 = first >= 0 ? first : 0;
+            sp[j] = rp[f0]; sstr[j] = (unsigned)rsz[f0] * 8u; srd[j] = (unsigned)ro[f0] * 8u;                 // lanes past the end repeat the first piece
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int np = rsz[q] / 2;
+                if (!found && pi < np) { sp[j] = rp[q] + 16 * pi; sstr[j] = (unsigned)rsz[q] * 8u; srd[j] = (unsigned)(ro[q] + 2 * pi) * 8u; found = true; }
+                if (!found) pi -= np;
+            }
+        }
+#pragma unroll
+        for (int q = 4; q >= 0; --q)
+            if (rsz[q] & 1) { ++ntail; }
+        hast = ntail > 0;
+        {
+            int tq = -1, seen = 0, firstodd = -1;
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                if (rsz[q] & 1) { if (firstodd < 0) firstodd = q; if (seen == lane) tq = q; ++seen; }
+            if (tq < 0) tq = firstodd >= 0 ? firstodd : 0;                                                     // lanes past the end repeat the first one
+            tp = rp[tq] + (size_t)(rsz[tq] - 1) * 8; tstr = (unsigned)rsz[tq] * 8u; trd = (unsigned)(ro[tq] + rsz[tq] - 1) * 8u;
+        }
+        // operand pieces of the first PDC steps; the image of step N-2 goes into buffer 0
+#pragma unroll
+        for (int s2 = 0; s2 < PDC; ++s2) {
+            const int t = i0 - s2 > 0 ? i0 - s2 : 0;
+#pragma unroll
+            for (int j = 0; j < NLI; ++j) ring[s2][j] = *(g2p)(lg[j] + (size_t)lgs[j] * (unsigned)t);
+        }
+#pragma unroll
+        for (int j = 0; j < NLI; ++j) {
+            lg[j] += (size_t)lgs[j] * (unsigned)(i0 - PDC > 0 ? i0 - PDC : 0);
+            *(d2 *)((char *)img + lim[j]) = ring[0][j];
+        }
     }
 
     // value function of the terminal step in tile layout: S = Vxx, column VG: Vx
@@ -166,19 +298,6 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     wave_sync();
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): all set-up loads have landed
 
-    // MXG_EXP & 8 (timing experiment): contiguous 16-byte pieces of the step's result blocks
-    char *xA = (char *)(Vxxg + nn * (tl - 1)) + 16 * (lane < (int)(nn / 2) ? lane : 0), *xB = xA;
-    unsigned xBs = (unsigned)(nn * 8);
-    int xn2 = 0;
-    if (MXG_EXP & 8) {
-        const int t1 = (int)(nn / 2) - 64 > 0 ? (int)(nn / 2) - 64 : 0, t2 = t1 + (int)(nm / 2), t3 = t2 + nr / 2, t4 = t3 + (mr + 1) / 2, t5 = t4 + (int)(mm / 2);
-        xn2 = t5;
-        if (lane < t1) { xB = (char *)(Vxxg + nn * (tl - 1)) + 1024 + 16 * lane; xBs = (unsigned)(nn * 8); }
-        else if (lane < t2) { xB = (char *)(Kg + nm * (tl - 1)) + 16 * (lane - t1); xBs = (unsigned)(nm * 8); }
-        else if (lane < t3) { xB = (char *)(Vxg + (size_t)nr * (tl - 1)) + 16 * (lane - t2); xBs = nr * 8u; }
-        else if (lane < t4) { xB = (char *)(kg + (size_t)mr * (tl - 1)) + 8 * (lane - t3); xBs = mr * 8u; }
-        else { xB = (char *)(Quug + mm * (tl - 1)) + 16 * (lane < t5 ? lane - t4 : 0); xBs = (unsigned)(mm * 8); }
-    }
     double dVa = 0.0, dVp = 0.0;                    // Σ k'Qu (lanes of column VG) and the per-row parts of Σ k'(Quu k + Qu)
     int diverge = 0;
     auto reg = [](const d4 &v, int r) __attribute__((always_inline)) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
@@ -187,10 +306,25 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     auto step = [&](const int i, auto slot_c) __attribute__((always_inline)) {
         constexpr int slot = decltype(slot_c)::value;
         const bool okp = diverge == 0;
-        const d4 c = d4{cr[slot][0], cr[slot][1], cr[slot][2], cr[slot][3]};
-        if (FXTV) {
+        d4 c;
+        if constexpr (COAL) {
+            // my tile operands from the image of this step (buffer = parity of the slot), then the image of step i-1 into the other one
+            constexpr int cur = slot & 1, nslot = (slot + 1) % PDC;
+            const char *bufc = (const char *)img + cur * L::BUF * 8;
+            c = d4{*(const double *)(bufc + co[0]), *(const double *)(bufc + co[1]), *(const double *)(bufc + co[2]), *(const double *)(bufc + co[3])};
+            if (FXTV) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) F[s] = fr[slot][s];
+                for (int s = 0; s < KS; ++s) F[s] = *(const double *)(bufc + fo[s]);
+            }
+            char *bufn = (char *)img + (cur ^ 1) * L::BUF * 8;
+#pragma unroll
+            for (int j = 0; j < NLI; ++j) *(d2 *)(bufn + lim[j]) = ring[nslot][j];
+        } else {
+            c = d4{cr[slot][0], cr[slot][1], cr[slot][2], cr[slot][3]};
+            if (FXTV) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) F[s] = fr[slot][s];
+            }
         }
         // ================= GEMM1: W = Vxx·F; column VG := Vx (F[:,VG] = 0, S[:,VG] = Vx) ============================
         d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], F[0], zero4, 0, 0, 0);
@@ -255,49 +389,70 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
             for (int c2 = 0; c2 < MS; ++c2) dVa = fma(q[c2], Qu[c2], dVa);
             dVp = fma(Ksel, Tsel, dVp);
         }
-        // ---- V + V' through the transpose tile (column VG: Vx, not symmetrised)
-        if (!(MXG_EXP & 4)) {
+        // ---- ½(D + D') through the transpose tile (column VG: Vx, not symmetrised)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) lds[wr + 4 * s] = reg(v, s);
-            wave_sync();
-        }
+        for (int s = 0; s < KS; ++s) lds[wr + 4 * s] = reg(v, s);
+        wave_sync();
 #pragma unroll
-        for (int s = 0; s < KS; ++s) S[s] = vscl * (reg(v, s) + ((MXG_EXP & 4) ? reg(v, s) : lds[rdT + s * rdS]));
+        for (int s = 0; s < KS; ++s) S[s] = vscl * (reg(v, s) + lds[rdT + s * rdS]);
         // Stores are unconditional: a diverged trajectory writes garbage into time steps that are zero-filled after the loop
-        if (!(MXG_EXP & 1)) store_results<KS>(vst, S, lanesVf, lanesVl, kq, quu_lane ? Z : Ksel, lanesK);      // Vxx | Vx, K | k | Quu (:75-76)
-        else asm volatile("" :: "v"(S[0]), "v"(S[KS - 1]), "v"(Z), "v"(Ksel));
-        if (MXG_EXP & 8) {      // the same bytes as two 16-byte-per-lane stores of contiguous blocks (garbage data): what would coalesced results cost?
-            typedef double d2x __attribute__((ext_vector_type(2)));
-            const d2x val = d2x{S[0], Ksel};
-            *(d2x *)xA = val;
-            if (lane < xn2) *(d2x *)xB = val;
-            xA -= nn * 8; xB -= xBs;
-        }
-        vst -= vst_stride;
-        kq -= kq_stride;
-        wave_sync();                                       // the tile and the image are free again
-        if (!(MXG_EXP & 2)) {   // refill the ring slot with the step PD ahead (clamped: always a valid load)
-            asm volatile("" ::: "memory");
+        const double kv = quu_lane ? Z : Ksel;             // K | k | Quu (:75-76)
+        if constexpr (COAL) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                cr[slot][s] = cS[s].next();
-                if (FXTV && s < KS) fr[slot][s] = fS[s].next();
+            for (int s = 0; s < KS; ++s) *(double *)((char *)rec + wS[s]) = S[s];
+            *(double *)((char *)rec + wK) = kv;
+            wave_sync();
+            if (!(MXG_EXP & 1)) {
+                if (has4) {
+                    d2 pc[NSI];
+#pragma unroll
+                    for (int j = 0; j < NSI; ++j) pc[j] = *(const d2 *)((const char *)rec + srd[j]);
+#pragma unroll
+                    for (int j = 0; j < NSI; ++j) { *(g2w)sp[j] = pc[j]; sp[j] -= sstr[j]; }
+                }
+                if (hast) {
+                    const double tv = *(const double *)((const char *)rec + trd);
+                    *(g1w)tp = tv; tp -= tstr;
+                }
             }
-            if (i - PD > 0) {
+            wave_sync();                                   // the tile, the image and the record are free again
+            if (!(MXG_EXP & 2)) {   // refill the ring slot with the step PDC ahead (clamped: always a valid load)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < NLI; ++j) ring[slot][j] = *(g2p)lg[j];
+                if (i - PDC > 0) {
+#pragma unroll
+                    for (int j = 0; j < NLI; ++j) lg[j] -= lgs[j];
+                }
+            }
+        } else {
+            if (!(MXG_EXP & 1)) store_results<KS>(vst, S, lanesVf, lanesVl, kq, kv, lanesK);      // Vxx | Vx, K | k | Quu
+            vst -= vst_stride;
+            kq -= kq_stride;
+            wave_sync();                                   // the tile and the image are free again
+            if (!(MXG_EXP & 2)) {   // refill the ring slot with the step PDC ahead (clamped: always a valid load)
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    cS[s].back();
-                    if (FXTV && s < KS) fS[s].back();
+                    cr[slot][s] = cS[s].next();
+                    if (FXTV && s < KS) fr[slot][s] = fS[s].next();
+                }
+                if (i - PDC > 0) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        cS[s].back();
+                        if (FXTV && s < KS) fS[s].back();
+                    }
                 }
             }
         }
     };
     int i = i0;
-    while (i >= PD - 1 && diverge == 0) {
-        static_for<0, PD>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc); });
-        i -= PD;
+    while (i >= PDC - 1 && diverge == 0) {
+        static_for<0, PDC>([&](auto sc) __attribute__((always_inline)) { step(i - decltype(sc)::value, sc); });
+        i -= PDC;
     }
-    static_for<0, PD - 1>([&](auto sc) __attribute__((always_inline)) {    // the last (N-1) mod PD steps
+    static_for<0, PDC - 1>([&](auto sc) __attribute__((always_inline)) {    // the last (N-1) mod PDC steps
         if (i >= 0 && diverge == 0) { step(i, sc); --i; }
     });
 
@@ -322,16 +477,16 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     if (lane == 0) a.diverge[b] = diverge;
 }
 
-template <int NP, bool REG2>
+template <int NP, bool REG2, bool COAL>
 int launch_mxg(ddp_handle h, const ddp_bp_desc *d, const BPXArgs &a)
 {
     const dim3 grid(d->B), block(DDP_WAVE);
     const int key = (d->fx_tv ? 2 : 0) | (d->cost_tv ? 1 : 0);
     switch (key) {
-    case 0: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, false, REG2>), grid, block, 0, h->stream, a); break;
-    case 1: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, true, REG2>), grid, block, 0, h->stream, a); break;
-    case 2: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, false, REG2>), grid, block, 0, h->stream, a); break;
-    case 3: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, true, REG2>), grid, block, 0, h->stream, a); break;
+    case 0: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, false, REG2, COAL>), grid, block, 0, h->stream, a); break;
+    case 1: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, true, REG2, COAL>), grid, block, 0, h->stream, a); break;
+    case 2: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, false, REG2, COAL>), grid, block, 0, h->stream, a); break;
+    case 3: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, true, REG2, COAL>), grid, block, 0, h->stream, a); break;
     }
     DDP_HIP(hipGetLastError());
     return 0;
@@ -353,9 +508,17 @@ int ddp_launch_back_pass_mxg(ddp_handle h, const ddp_bp_desc *d, const double *c
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     const bool r2 = d->regType == 2;
+    const char *ce = ddp_env(h, ENV_MXG_COAL);                  // 0: one 8-byte element per lane straight from / to global memory (A/B, tests)
+    if (ce && ce[0] == '0') {
+        switch (np) {
+        case 4: return r2 ? launch_mxg<4, true, false>(h, d, a) : launch_mxg<4, false, false>(h, d, a);
+        case 8: return r2 ? launch_mxg<8, true, false>(h, d, a) : launch_mxg<8, false, false>(h, d, a);
+        default: return r2 ? launch_mxg<12, true, false>(h, d, a) : launch_mxg<12, false, false>(h, d, a);
+        }
+    }
     switch (np) {
-    case 4: return r2 ? launch_mxg<4, true>(h, d, a) : launch_mxg<4, false>(h, d, a);
-    case 8: return r2 ? launch_mxg<8, true>(h, d, a) : launch_mxg<8, false>(h, d, a);
-    default: return r2 ? launch_mxg<12, true>(h, d, a) : launch_mxg<12, false>(h, d, a);
+    case 4: return r2 ? launch_mxg<4, true, true>(h, d, a) : launch_mxg<4, false, true>(h, d, a);
+    case 8: return r2 ? launch_mxg<8, true, true>(h, d, a) : launch_mxg<8, false, true>(h, d, a);
+    default: return r2 ? launch_mxg<12, true, true>(h, d, a) : launch_mxg<12, false, true>(h, d, a);
     }
 }

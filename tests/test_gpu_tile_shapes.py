@@ -185,3 +185,28 @@ def test_wide_tile_kernel_short_horizons(ddp, n, m, N):
     out, name = _run(ddp, args, 0.1, 1, None, "wtile")
     assert name == WNAME
     _check(ddp, out, args, 0.1, 1, None, False)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 3), (5, 3), (7, 4), (8, 4), (9, 3), (11, 1), (11, 3), (12, 3)])
+@pytest.mark.parametrize("kind", ["lti", "ltv", "tv", "btv"])
+def test_wide_tile_kernel_coalesced_io_is_bit_identical_to_the_element_per_lane_path(ddp, n, m, kind):
+    """DDP_MXG_COAL=0 reads and writes one 8-byte element per lane in the tile layout; the default path moves the same numbers in
+    contiguous 16-byte pieces through LDS images (blocks of odd length: 8-byte tails, over-reads into the next time step) — the
+    arithmetic in between is the same, so every output must agree bit for bit, odd and even block lengths, N not a multiple of the ring"""
+    import os
+    rng = np.random.default_rng(4000 * n + 10 * m + len(kind))
+    for N, B in ((2, 3), (9, 3), (37, 6)):
+        args = _problem(rng, n, m, N, B, kind)
+        lam = 10.0 ** rng.uniform(-2, 0.3, B)
+        lam[0] = -40.0                                          # one diverging trajectory: the zero-fill below the failing step
+        for regType in (1, 2):
+            out, name = _run(ddp, args, lam, regType, None, "wtile")
+            os.environ["DDP_MXG_COAL"] = "0"                     # (the handle re-reads its DDP_* switches when they change)
+            try:
+                ref, _ = _run(ddp, args, lam, regType, None, "wtile")
+            finally:
+                del os.environ["DDP_MXG_COAL"]
+            assert name == WNAME
+            assert np.array_equal(out[0], ref[0])
+            for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4]), (out[1].Σi, ref[1].Σi)):
+                assert np.array_equal(a_, b_)
