@@ -304,7 +304,7 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
               "forward_pass: ddp_problem.diff_wrap = 0x%x needs n <= %d and no bits at or above n = %d (zero-initialise the struct)", p->diff_wrap, DDP_MAX_N_GENERIC, p->n);
     if (p->n > DDP_MAX_N_GENERIC || (p->diff_wrap == 0 && ddp_env(h, ENV_FORWARD) && ddp_env(h, ENV_FORWARD)[0] == 'b')) {   // large states
         const int rc = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
-        if (rc <= 0) { h->last_kernel[1] = "forward_big_kernel"; return rc; }
+        if (rc <= 0) return rc;                             // (the launcher names the kernel)
         DDP_CHECK(p->n <= DDP_MAX_N_GENERIC, "forward_pass: n=%d m=%d has no kernel", p->n, p->m);
     }
     // DDP_FORWARD=group forces the group-of-lanes kernel (A/B timing, tests of both code paths)
@@ -322,11 +322,12 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
         // every other LQ shape a 16-lane row holds: the row kernel compiled for padded sizes (DDP_FORWARD=group keeps the old path)
         const int rr = ddp_launch_forward_row(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
         if (rr <= 0) { h->last_kernel[1] = "forward_row_kernel"; return rr; }
-        // what no row holds (n > 14, m > 4): the one-wave-per-rollout kernel of the large states is 1.4-2.3x the group-of-lanes kernel
-        // there too (n = 24, m = 4, N = 300, B = 1 024 LTV: 3.1 vs 6.0 ms; n = 32, m = 8: 4.4 vs 10.3 ms)
-        if (p->kind == DDP_PROBLEM_LQ && p->n > 14) {
+        // what no row holds (n > 14 or m > 4): one wave per rollout with the operands of a step requested a step ahead
+        // (forward_mid_kernel, n <= 32; n = 24, m = 4, N = 300, B = 1 024 LTV: 0.56 ms against 3.1 on forward_big_kernel and 6.0 on the
+        // group-of-lanes kernel below), forward_big_kernel above n = 32
+        if (p->kind == DDP_PROBLEM_LQ && (p->n > 14 || p->m > 4)) {
             const int rb = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
-            if (rb <= 0) { h->last_kernel[1] = "forward_big_kernel"; return rb; }
+            if (rb <= 0) return rb;
         }
     }
     h->last_kernel[1] = "forward_pass_kernel";

@@ -328,6 +328,199 @@ __global__ __launch_bounds__(DDP_WAVE) void cost_sum_kernel(FBArgs a)
     if (lane == 0) a.csum[rho] = acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 14 < n <= 32, m <= 8 (what no 16-lane row holds): one wave per rollout like forward_big_kernel, organised like the n = 64 kernel —
+// every operand of step i+1 (A_i, B_i, K_i, x_i, ū_i, k_i) is requested before step i is computed (two register buffers, the loop
+// unrolled by 2), so a step no longer waits for n dependent global loads (forward_big_kernel at n = 24, m = 4, N = 300, B = 1 024:
+// 2.65 ms, 8.8 µs per step).  Lane (j, h) = (lane & 31, lane >> 5) holds row j of the columns [h·CA, h·CA + CA) of A_i and
+// [4h, 4h + 4) of B_i (n <= 2·CA: CA = 8, 12, 16); the column halves meet in one v_permlane32_swap per dword.  For K_i·dx the same
+// lanes are (a, p) = (lane >> 3, lane & 7): gain row a, state columns p + 8q, summed over p by three DPP moves.  x̂, dx and u go
+// through zero-padded LDS vectors, so columns past n / m need no select: their (clamped, finite) operands meet a zero.
+// Limits are data (±inf without them: Base.clamp is then the identity); the empty policy skips the gain part (uniform branch).
+// Same arithmetic as forward_big_kernel (src/forward_pass.jl:9-33), the row sums of A x̂ + B u in two halves.
+#ifndef FM_DEPTH
+#define FM_DEPTH 2
+#endif
+template <int CA>
+struct FMBuf { double fa[CA], fb[4], kq[CA / 4], xo, uo, ko; };
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CA>
+__global__ __launch_bounds__(DDP_WAVE) void forward_mid_kernel(FBArgs a)
+{
+    constexpr int CB = 4, KQ = CA / 4, NP = 2 * CA;
+    const int n = a.n, m = a.m, N = a.N, B = a.B;
+    const long rho = blockIdx.x;
+    const int b = (int)(rho % B), ai = (int)(rho / B);
+    if (a.active && a.active[b] == 0) return;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5, ga = lane >> 3, gp = lane & 7;
+    const bool inx = j < n, stx = inx && h == 0, stu = ga < m && gp == 0, pol = a.has_policy != 0;
+    const int jc = inx ? j : n - 1, ac = ga < m ? ga : m - 1;
+    const double alpha = a.alpha[ai];
+    __shared__ __attribute__((aligned(16))) double xs[NP], dxs[NP], us[2 * CB];
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m;
+    const char *ug = (const char *)(a.u + (size_t)m * N * b);
+    const char *xg = pol ? (const char *)(a.x + (size_t)n * N * b) : nullptr;
+    const char *Kg = pol ? (const char *)(a.K + nm * N * b) : nullptr;
+    const char *kg = pol ? (const char *)(a.k + (size_t)m * N * b) : nullptr;
+    char *xo = (char *)(a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai));
+    char *uo = (char *)(a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai));
+    const char *Ab = (const char *)(a.A + (a.dyn_batched ? nn * (a.dyn_tv ? N : 1) * b : 0));
+    const char *Bb = (const char *)(a.Bm + (a.dyn_batched ? nm * (a.dyn_tv ? N : 1) * b : 0));
+    const size_t sA = a.dyn_tv ? nn * 8 : 0, sB = a.dyn_tv ? nm * 8 : 0;
+    const double inf = __builtin_huge_val();
+    const double lo = a.has_lims ? a.lims[ac] : -inf, hi = a.has_lims ? a.lims[ac + m] : inf;
+    // fixed per-lane byte offsets inside a step's block (columns past the end repeat the last one: they meet zeros of xs / us / dxs)
+    unsigned offA[CA], offB[CB], offK[KQ];
+#pragma unroll
+    for (int c = 0; c < CA; ++c) { const int l = h * CA + c; offA[c] = 8u * (unsigned)(jc + n * (l < n ? l : n - 1)); }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) { const int q = h * CB + c; offB[c] = 8u * (unsigned)(jc + n * (q < m ? q : m - 1)); }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) { const int l = gp + 8 * q; offK[q] = 8u * (unsigned)(ac + m * (l < n ? l : n - 1)); }
+    const unsigned offx = 8u * (unsigned)jc, offu = 8u * (unsigned)ac;
+    const int ifl = N >= 2 ? N - 2 : 0;                               // the last step whose A_i, B_i are used (and certainly exist)
+
+    auto fetch = [&](int i, FMBuf<CA> &f) {
+        const int fi = i < ifl ? i : ifl;
+        const char *Ai = Ab + sA * fi, *Bi = Bb + sB * fi;
+#pragma unroll
+        for (int c = 0; c < CA; ++c) f.fa[c] = *(const double *)(Ai + offA[c]);
+#pragma unroll
+        for (int c = 0; c < CB; ++c) f.fb[c] = *(const double *)(Bi + offB[c]);
+        if (pol) {
+            const char *Ki = Kg + nm * 8 * i;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) f.kq[q] = *(const double *)(Ki + offK[q]);
+            f.xo = *(const double *)(xg + (size_t)n * 8 * i + offx);
+            f.ko = *(const double *)(kg + (size_t)m * 8 * i + offu);
+        }
+        f.uo = *(const double *)(ug + (size_t)m * 8 * i + offu);
+    };
+    if (lane < NP) { xs[lane] = 0.0; dxs[lane] = 0.0; }
+    if (lane < 2 * CB) us[lane] = 0.0;
+    double xh = inx ? a.x0[(size_t)n * b + jc] : 0.0;
+    wave_sync();
+    auto step = [&](int i, const FMBuf<CA> &f) {
+        if (stx) {
+            xs[j] = xh;
+            if (pol) dxs[j] = xh - f.xo;
+            *(double *)(xo + (size_t)n * 8 * i + offx) = xh;
+        }
+        wave_sync();
+        // state part of A x̂ + B u (does not wait for the controls)
+        double s0 = 0.0, s1 = 0.0;
+        if (i < N - 1) {
+#pragma unroll
+            for (int c = 0; c < CA; c += 2) {
+                const d2 z = *(const d2 *)(xs + h * CA + c);
+                s0 += f.fa[c] * z.x; s1 += f.fa[c + 1] * z.y;
+            }
+        }
+        // controls (forward_pass.jl:17-24)
+        double v = f.uo;
+        if (pol) {
+            double p0 = 0.0;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) p0 += f.kq[q] * dxs[gp + 8 * q];
+            p0 += dpp_f64<0xB1>(p0);                                  // quad_perm [1,0,3,2]
+            p0 += dpp_f64<0x4E>(p0);                                  // quad_perm [2,3,0,1]
+            p0 += dpp_f64<0x141>(p0);                                 // row_half_mirror: the other quad of the 8 lanes
+            v += f.ko * alpha;                                       // unew .+= k*α
+            v += p0;                                                 // unew .+= K*dx
+        }
+        v = clampd(v, lo, hi);
+        if (v != v) v = 0.0;                                         // u[isnan.(u)] .= 0 inside f
+        if (stu) {
+            us[ga] = v;
+            *(double *)(uo + (size_t)m * 8 * i + offu) = v;
+        }
+        wave_sync();
+        if (i < N - 1) {
+#pragma unroll
+            for (int c = 0; c < CB; c += 2) {
+                const d2 z = *(const d2 *)(us + h * CB + c);
+                s0 += f.fb[c] * z.x; s1 += f.fb[c + 1] * z.y;
+            }
+            const double t = sum_halves(s0 + s1);
+            xh = inx ? t : 0.0;
+        }
+        wave_sync();
+    };
+    const int il = N - 1;
+#if FM_DEPTH == 2
+    // operands two steps ahead (three register buffers, the loop unrolled by 3): one step ahead the wave waited for HBM every step
+    FMBuf<CA> f0, f1, f2;
+    fetch(0, f0);
+    fetch(1 < il ? 1 : il, f1);
+    int i = 0;
+    for (; i + 2 < N; i += 3) {
+        fetch(i + 2, f2);
+        step(i, f0);
+        fetch(i + 3 < il ? i + 3 : il, f0);                          // (re-reads the last step at the end: valid memory, unused)
+        step(i + 1, f1);
+        fetch(i + 4 < il ? i + 4 : il, f1);
+        step(i + 2, f2);
+    }
+    if (i < N) step(i, f0);
+    if (i + 1 < N) step(i + 1, f1);
+#else
+    FMBuf<CA> f0, f1;
+    fetch(0, f0);
+    int i = 0;
+    for (; i + 1 < N; i += 2) {
+        fetch(i + 1, f1);
+        step(i, f0);
+        fetch(i + 2 < il ? i + 2 : il, f0);
+        step(i + 1, f1);
+    }
+    if (i < N) step(i, f0);
+#endif
+}
+
+// cost of those rollouts (LQ family, full Q and R; demo_linear.jl:49 split per step): one wave per (rollout, 64 time steps), lane =
+// time step; the x̂ and u of the 64 steps arrive by coalesced loads into LDS tiles with odd row pitches, Q and R are broadcast reads.
+// Sums in cost_rt_kernel's order (bit-identical to it); the sum over time is cost_sum_kernel's.
+__global__ __launch_bounds__(DDP_WAVE) void cost_mid_kernel(FBArgs a)
+{
+    constexpr int TB = DDP_WAVE;
+    const int n = a.n, m = a.m, N = a.N, B = a.B;
+    const long rho = blockIdx.x;
+    const int b = (int)(rho % B), t0 = blockIdx.y * TB;
+    if (a.active && a.active[b] == 0) return;
+    const int lane = threadIdx.x;
+    const int nt = min(TB, N - t0), pn = n | 1, pm = m | 1;
+    __shared__ double xt[TB * 33], ut[TB * 9], qr[32 * 32 + 8 * 8];
+    const double *x = a.xnew + (size_t)n * N * rho + (size_t)n * t0, *u = a.unew + (size_t)m * N * rho + (size_t)m * t0;
+    for (int e = lane; e < n * nt; e += DDP_WAVE) xt[(e / n) * pn + e % n] = x[e];
+    for (int e = lane; e < m * nt; e += DDP_WAVE) ut[(e / m) * pm + e % m] = u[e];
+    for (int e = lane; e < n * n; e += DDP_WAVE) qr[e] = a.Q[e];
+    for (int e = lane; e < m * m; e += DDP_WAVE) qr[n * n + e] = a.R[e];
+    wave_sync();
+    if (lane >= nt) return;
+    const double *Q = qr, *R = qr + n * n, *xl = xt + lane * pn, *ul = ut + lane * pm;
+    double qx = 0.0, ru = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int jj = 0; jj < n; ++jj) s += Q[i + n * jj] * xl[jj];
+        qx += xl[i] * s;
+    }
+    for (int i = 0; i < m; ++i) {
+        double s = 0.0;
+        for (int jj = 0; jj < m; ++jj) s += R[i + m * jj] * ul[jj];
+        ru += ul[i] * s;
+    }
+    a.cnew[(size_t)N * rho + t0 + lane] = 0.5 * qx + 0.5 * ru;
+}
+
 }   // namespace
 
 // returns 1 when not applicable (caller falls back), 0 launched, <0 error
@@ -336,6 +529,7 @@ int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, 
                            const int32_t *active, double *xnew, double *unew, double *cnew, double *csum)
 {
     if (p->kind != DDP_PROBLEM_LQ || p->n > 64 || p->m > DDP_MAX_M) return 1;
+    h->last_kernel[1] = "forward_big_kernel";                         // (the mid-size branch below renames it)
     FBArgs a;
     a.n = p->n; a.m = p->m; a.N = p->N; a.B = p->B; a.nalpha = nalpha;
     a.dyn_tv = p->dyn_tv; a.dyn_batched = p->dyn_batched; a.has_policy = K != nullptr; a.has_lims = lims != nullptr;
@@ -359,6 +553,17 @@ int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, 
         hipLaunchKernelGGL(cost_big64_kernel, dim3(grid.x, (unsigned)((p->N + 15) / 16)), block, 0, h->stream, a);
         hipLaunchKernelGGL(cost_sum_kernel, grid, block, 0, h->stream, a);
         DDP_HIP(hipGetLastError());
+        return 0;
+    }
+    const char *mid = ddp_env(h, ENV_FORWARD_MID);                     // DDP_FORWARD_MID=0: the run-time-sized kernels below n = 64 too (A/B, tests)
+    if (p->n <= 32 && p->m <= 8 && !(mid && mid[0] == '0')) {
+        if (p->n <= 16) hipLaunchKernelGGL((forward_mid_kernel<8>), grid, block, 0, h->stream, a);
+        else if (p->n <= 24) hipLaunchKernelGGL((forward_mid_kernel<12>), grid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((forward_mid_kernel<16>), grid, block, 0, h->stream, a);
+        hipLaunchKernelGGL(cost_mid_kernel, dim3(grid.x, (unsigned)((p->N + DDP_WAVE - 1) / DDP_WAVE)), block, 0, h->stream, a);
+        hipLaunchKernelGGL(cost_sum_kernel, grid, block, 0, h->stream, a);
+        DDP_HIP(hipGetLastError());
+        h->last_kernel[1] = "forward_mid_kernel";
         return 0;
     }
     hipLaunchKernelGGL(forward_big_kernel, grid, block, 0, h->stream, a);

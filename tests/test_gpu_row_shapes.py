@@ -339,3 +339,114 @@ def test_mid_kernel_short_horizons(ddp, N):
         out, name = _run(ddp, args, 0.3, 1, None, "mid")
         assert name == "back_pass_mid_kernel"
         _check(ddp, out, args, 0.3, 1, None, False)
+
+
+# ------------------------------------------------------------------------------------- 14 < n <= 32 (or m > 4): forward_mid_kernel
+MID_FSHAPES = [(15, 1), (16, 2), (17, 3), (20, 6), (24, 4), (25, 8), (31, 5), (32, 8), (8, 5), (3, 7), (32, 1), (16, 8), (23, 7)]
+
+
+@pytest.mark.parametrize("n,m", MID_FSHAPES)
+def test_forward_mid_kernel_every_shape_vs_oracle(ddp, n, m):
+    """src/forward_pass.jl:9-33 at the sizes no 16-lane row holds (csrc/forward_pass_big.hip, forward_mid_kernel: one wave per rollout,
+    the operands of a step requested a step ahead): 5 step sizes with and without limits, the initial rollout (empty policy), LTI and
+    LTV dynamics, full Q and R; every rollout against the C oracle"""
+    from ddp_amd import _lib
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(91 * n + m)
+    N, B = 23, 4
+    alphas = 10.0 ** np.linspace(0, -3, 5)
+    L = np.stack([-0.4 * np.ones(m), 0.5 * np.ones(m)], 1)
+    for ltv in (False, True):
+        A, Bm, Q, R = _lq(rng, n, m, N, B, ltv, False)
+        prob = ddp.LQProblem(A, Bm, Q, R)
+        po = oc.make_problem("lq", n, m, N, A=A, B=Bm, Q=Q, R=R)
+        x0 = rng.standard_normal((n, B)); u = 0.3 * rng.standard_normal((m, N, B))
+        K = 0.2 * rng.standard_normal((m, n, N, B)) / np.sqrt(n); k = 0.1 * rng.standard_normal((m, N, B))
+        x, u1, c1 = ddp.forward_pass(ddp.GaussianPolicy(), x0, u, None, 1.0, prob, None)
+        assert _lib.default_handle().last_kernel(1) == "forward_mid_kernel"
+        for b in range(B):
+            xr, ur, cr = oc.forward_pass(po, None, x0[:, b], u[..., b], None, 1.0, None)
+            assert relerr(x[..., b], xr) < 1e-10 and relerr(c1[:, b], cr) < 1e-10
+        for lims in (None, L):
+            pol = ddp.GaussianPolicy(N, n, m, K, k)
+            xn, un, cn = ddp.forward_pass(pol, x0, u, x, alphas, prob, lims)
+            assert _lib.default_handle().last_kernel(1) == "forward_mid_kernel"
+            for b in range(B):
+                for ai, al in enumerate(alphas):
+                    xr, ur, cr = oc.forward_pass(po, (K[..., b], k[..., b]), x0[:, b], u[..., b], x[..., b], float(al), lims)
+                    assert relerr(xn[..., b, ai], xr) < RTOL and relerr(un[..., b, ai], ur) < RTOL and relerr(cn[:, b, ai], cr) < RTOL, (n, m, ltv, b, ai)
+
+
+@pytest.mark.parametrize("n,m", [(18, 3), (24, 4), (32, 8), (9, 6)])
+def test_forward_mid_kernel_agrees_with_the_run_time_sized_kernel(ddp, n, m):
+    """DDP_FORWARD_MID=0 keeps forward_big_kernel / cost_rt_kernel: the same rollouts with per-trajectory time-varying dynamics, an
+    a NaN control (zeroed inside f, forward_pass.jl:21), odd and even horizons (one, exactly one and three 64-step cost chunks); the
+    states differ by the order of the row sums only"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(7 * n + m)
+    for N in (33, 64, 130):
+        B = 6
+        A, Bm, Q, R = _lq(rng, n, m, N, B, True, True)
+        prob = ddp.LQProblem(A, Bm, Q, R, dyn_batched=True)
+        x0 = rng.standard_normal((n, B)); u = 0.3 * rng.standard_normal((m, N, B))
+        u[0, 5, 1] = np.nan
+        K = 0.2 * rng.standard_normal((m, n, N, B)) / np.sqrt(n); k = 0.1 * rng.standard_normal((m, N, B))
+        x, _, _ = ddp.forward_pass(ddp.GaussianPolicy(), x0, u, None, 1.0, prob, None)
+        pol = ddp.GaussianPolicy(N, n, m, K, k)
+        al = np.array([1.0, 0.3, 0.01])
+        got = ddp.forward_pass(pol, x0, u, x, al, prob, None)
+        assert _lib.default_handle().last_kernel(1) == "forward_mid_kernel"
+        os.environ["DDP_FORWARD_MID"] = "0"
+        try:
+            ref = ddp.forward_pass(pol, x0, u, x, al, prob, None)
+            assert _lib.default_handle().last_kernel(1) == "forward_big_kernel"
+        finally:
+            del os.environ["DDP_FORWARD_MID"]
+            _lib.default_handle().raw
+        assert np.isfinite(got[0]).all() and got[1][0, 5, 1, 0] == 0.0
+        assert np.array_equal(got[1][..., 0], ref[1][..., 0]) or relerr(got[1], ref[1]) < 1e-11
+        for a_, b_ in zip(got, ref):
+            assert relerr(a_, b_) < 1e-11
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_forward_mid_kernel_short_horizons(ddp, N):
+    from ddp_amd import _lib
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(300 + N)
+    for n, m in ((18, 3), (30, 7)):
+        B = 3
+        A, Bm, Q, R = _lq(rng, n, m, N, B, True, False)
+        prob = ddp.LQProblem(A, Bm, Q, R)
+        po = oc.make_problem("lq", n, m, N, A=A, B=Bm, Q=Q, R=R)
+        x0 = rng.standard_normal((n, B)); uu = 0.3 * rng.standard_normal((m, N, B))
+        K = 0.2 * rng.standard_normal((m, n, N, B)) / np.sqrt(n); k = 0.1 * rng.standard_normal((m, N, B))
+        xr0, _, _ = ddp.forward_pass(ddp.GaussianPolicy(), x0, uu, None, 1.0, prob, None)
+        xn, un, cn = ddp.forward_pass(ddp.GaussianPolicy(N, n, m, K, k), x0, uu, xr0, np.array([1.0, 0.1]), prob, None)
+        assert _lib.default_handle().last_kernel(1) == "forward_mid_kernel"
+        for b in range(B):
+            for ai, al in enumerate((1.0, 0.1)):
+                xr, ur, cr = oc.forward_pass(po, (K[..., b], k[..., b]), x0[:, b], uu[..., b], xr0[..., b], al, None)
+                assert relerr(xn[..., b, ai], xr) < RTOL and relerr(un[..., b, ai], ur) < RTOL and relerr(cn[:, b, ai], cr) < RTOL
+
+
+@pytest.mark.parametrize("n,m", [(18, 3), (24, 4)])
+def test_ilqg_solves_at_a_mid_shape_match_the_oracle(ddp, n, m):
+    """whole iLQG solves (src/iLQG.jl:143-341) at sizes above the 16-lane rows: back_pass_mid_kernel + forward_mid_kernel under the
+    device-resident driver (activity masks, all step sizes per launch)"""
+    from ddp_amd import _lib
+    from oracle import np_restatement as npr
+    from oracle import oracle_ctypes as oc
+    rng = np.random.default_rng(1900 + n)
+    N, B = 40, 4
+    P = npr.make_lq_problem(rng, n=n, m=m, T=N)
+    prob = ddp.LQProblem(P["A"], P["B"], P["Q"], P["R"])
+    x0 = np.ones((n, B)) + 0.1 * rng.standard_normal((n, B)); u0 = 0.1 * rng.standard_normal((m, N, B))
+    x, u, pol, Vx, Vxx, cost, tr = ddp.iLQG(prob, x0, u0)
+    assert _lib.default_handle().last_kernel(1) == "forward_mid_kernel"
+    po = oc.make_problem("lq", n, m, N, A=P["A"], B=P["B"], Q=P["Q"], R=P["R"])
+    for b in range(B):
+        xr, ur, (Kr, kr, Quur), Vxr, Vxxr, cr, info = oc.ilqg(po, x0[:, b], u0[:, :, b])
+        assert int(tr["stats"][0, b]) == info["status"] and abs(int(tr["stats"][1, b]) - info["iter"]) <= 1
+        for got, ref in ((x[..., b], xr), (u[..., b], ur), (cost[:, b], cr)):
+            assert relerr(got, ref) < 1e-7
