@@ -1,3 +1,9 @@
+// back_pass_mid8.hip — the 8 x 8 instantiations (4 < m <= 8) of the mid-size backward kernel in their first form: element-linear staging of
+// [fx fu], the cost terms and gradients requested per row, every lane repeating the m x m factorisation on an LDS image.  The 4 x 4
+// instantiations moved on (back_pass_mid.hip: one straight-line batch of loads per step, no exec-mask branches around the staging, one
+// product for the value update); carried over unchanged here, those changes made THIS size slower (n = 32, m = 8, N = 300, B = 1 024:
+// 8.9 -> 11.5 ms) — its 8 x 8 per-lane arrays already spill, and every reload of a spilled register waits on the same counter as the
+// global loads.  What this size needs is the m x m system with one coordinate per lane (boxqp_rows.h) and K = -Φ Qux on the matrix cores.
 // back_pass_mid.hip — backward pass for the shapes between the 16-lane rows (n <= 14) and the n = 64 matrix-core kernel:
 // any n <= 32, m <= 8 (src/backward_pass.jl:162-252 + :28-79), ONE wave per trajectory, the three products of a step on
 // v_mfma_f64_16x16x4 with their operands in the LDS.  Before this file these shapes ran on the 64-lane vector kernel of back_pass.hip
@@ -15,23 +21,11 @@
 #include "ddp_internal.h"
 #include "boxqp_dev.h"
 
-// -DMID_PROF: s_memtime ticks per phase of a step, summed over the launch by trajectory 0 and left in the first words of its Vxx
-// (profiles/mid_phase_profile.py); a profiling build only
-#ifdef MID_PROF
-#define MP_DECL unsigned long long mp_t = __builtin_amdgcn_s_memtime(), mp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define MP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); mp_acc[k] += t_ - mp_t; mp_t = t_; }
-#define MP_DUMP if (b == 0 && lane == 0) { for (int k = 0; k < 12; ++k) Vxxg[k] = (double)mp_acc[k]; }
-#else
-#define MP_DECL
-#define MP(k)
-#define MP_DUMP
-#endif
-
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-struct BPMidArgs {
+struct BPMid8Args {
     int n, m, N, B, regType;
     long fx_t, fx_b, fu_t, fu_b, cxx_t, cxx_b, cxu_t, cxu_b, cuu_t, cuu_b;      // element strides per time step / per trajectory (0: shared)
     const double *cx, *cu, *cxx, *cxu, *cuu, *fx, *fu, *lambda, *lims, *u;
@@ -43,20 +37,20 @@ struct BPMidArgs {
 __device__ __forceinline__ d4 mf(double x, double y, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); }
 
 template <int NTR, int PT, int MMX>
-struct MidLds {
+struct Mid8Lds {
     static constexpr int NR = 16 * NTR, PC = 16 * PT, LDV = NR + 1, LDF = NR + 1, LDW = PC + 1, MM = MMX, MK = 8;      // MK: k length of the rank update (two k-steps)
     // the W image is dead behind the second product: K, ½Y and the unsymmetrised Vxx_i live there
     static constexpr int WSZ = NR * LDW > 2 * MK * NR + NR * LDV ? NR * LDW : 2 * MK * NR + NR * LDV;
-    static constexpr int oV = 0, oF = oV + NR * LDV, oW = oF + LDF * PC, oGu = oW + WSZ, oQx = oGu + (MK + 1) * PC, oVx = oQx + NR,   // (row MK of Gu: a dump row)
-                         oQuu = oVx + NR, oRs = oQuu + MK * MK, oRi = oRs + MK * MK, oSink = oRi + MK + 2, oGv = oSink + DDP_WAVE, oZero = oGv + DDP_WAVE, oTot = oZero + PC;
+    static constexpr int oV = 0, oF = oV + NR * LDV, oW = oF + LDF * PC, oGu = oW + WSZ, oQx = oGu + MK * PC, oVx = oQx + NR,
+                         oQuu = oVx + NR, oRs = oQuu + MK * MK, oRi = oRs + MK * MK, oTot = oRi + MK + 2;
     static constexpr int oK = oW, oY = oW + MK * NR, oVr = oW + 2 * MK * NR;
 };
 
 // MMX: the size the m x m system is compiled for (4 for m <= 4: a quarter of the registers of the 8 x 8 arrays)
-template <int NTR, int PT, int MMX, bool LIMS, bool CTV>
-__global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
+template <int NTR, int PT, int MMX, bool LIMS>
+__global__ __launch_bounds__(DDP_WAVE) void back_pass_mid8_kernel(BPMid8Args a)
 {
-    using L = MidLds<NTR, PT, MMX>;
+    using L = Mid8Lds<NTR, PT, MMX>;
     constexpr int NR = L::NR, PC = L::PC, LDV = L::LDV, LDF = L::LDF, LDW = L::LDW, MM = L::MM, MK = L::MK, KT = NR / 4;
     const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
     if (a.active && a.active[b] == 0) return;
@@ -98,85 +92,31 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
     for (int q = 0; q < MM; ++q) kprev[q] = 0.0;
     int diverge = 0;
-    // ---- F = [fx fu] by columns: lane (kr, jh) = (lane % NR, lane / NR) moves row kr of the columns CPI r + jh, r = 0, 1, ...: a scalar base +
-    // one 32-bit offset per load (rows / columns past the end repeat the last one), the LDS address one per-lane base + an immediate.
-    // EVERY global load of the time loop sits in ONE straight-line batch (F, the gradients, time-varying cost terms of step i - 1, behind the
-    // second product of step i) and is consumed at the top of the next step: with loads under run-time conditions (the element-linear
-    // loop of the first version, the per-row tests of the gradient loads) the compiler could not count what was outstanding and waited for
-    // EVERYTHING (s_waitcnt vmcnt(0)) right behind the requests it had just issued — profiles/r05_mid_phases.txt: 7 750 of a step's 22 000
-    // cycles in the phase that holds 24 matrix instructions.  Columns n.. of the fx part land on columns the fu part overwrites or nobody reads.
-    constexpr int CPI = DDP_WAVE / NR, RA = NR / CPI, RB = 8 / CPI, RS = (NR * NR + DDP_WAVE - 1) / DDP_WAVE;
-    const int kr = lane % NR, jh = lane / NR, krc = kr < n ? kr : n - 1;
-    unsigned gA[RA], gB[RB];
-    int lB[RB];
+    // ---- per-lane index tables (no division inside the time loop)
+    constexpr int RF = (NR * (NR + 8) + DDP_WAVE - 1) / DDP_WAVE, RS = (NR * NR + DDP_WAVE - 1) / DDP_WAVE;
+    int f_lds[RF];                                                // element e = lane + 64 r of [fx fu] (contiguous in fx, then in fu): its LDS offset
 #pragma unroll
-    for (int r = 0; r < RA; ++r) { const int j = CPI * r + jh; gA[r] = 8u * (unsigned)(krc + n * (j < n ? j : n - 1)); }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int q = CPI * r + jh;
-        gB[r] = 8u * (unsigned)(krc + n * (q < m ? q : m - 1));
-        lB[r] = q < m ? L::oF + kr + LDF * (n + q) : L::oSink + lane;
+    for (int r = 0; r < RF; ++r) {
+        const int e = lane + DDP_WAVE * r, ee = e < n * p ? e : 0;
+        f_lds[r] = e < n * p ? (ee % n) + LDF * (ee / n) : -1;
     }
-    double *const FsA = Fs + kr + LDF * jh;
-    // the gradient [cx_i; cu_i] through an LDS vector (gv; zeros past n + m): one load per lane and step
-    const char *gptr = lane < n ? (const char *)(cx + lane) : (lane < p ? (const char *)(cu + (lane - n)) : (const char *)cx);
-    const unsigned gstride = 8u * (unsigned)(lane < n ? n : (lane < p ? m : 0));
-    double *const gv = lds + L::oGv;
-    int s_a[RS];                                                  // element e of Vxx_i (memory order): its offset in the LDS image
+    int s_a[RS], s_b[RS];                                         // element e of Vxx_i: its LDS offset and the transposed one
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
-        const int e = lane + DDP_WAVE * r, ee = e < (int)nn ? e : (int)nn - 1;
-        s_a[r] = (ee % n) + LDV * (ee / n);
+        const int e = lane + DDP_WAVE * r, ee = e < (int)nn ? e : 0;
+        s_a[r] = (ee % n) + LDV * (ee / n); s_b[r] = (ee / n) + LDV * (ee % n);
     }
-    const int quu_src = lane < (int)mm ? (lane % m) * PC + n + lane / m : 0;      // (no division by a run-time m inside the loop)
-    double pfA[RA], pfB[RB], pg;                                  // F and the gradients of the next step, requested a step ahead
+    double pfF[RF];                                               // F of the next step, requested a step ahead
     auto load_F = [&](int i) {
-        const char *fxi = (const char *)(fx + a.fx_t * i), *fui = (const char *)(fu + a.fu_t * i);
+        const double *fxi = fx + a.fx_t * i, *fui = fu + a.fu_t * i;
 #pragma unroll
-        for (int r = 0; r < RA; ++r) pfA[r] = *(const double *)(fxi + gA[r]);
-#pragma unroll
-        for (int r = 0; r < RB; ++r) pfB[r] = *(const double *)(fui + gB[r]);
-        pg = *(const double *)(gptr + (size_t)gstride * i);
-    };
-    auto store_F = [&]() {
-#pragma unroll
-        for (int r = 0; r < RA; ++r) FsA[LDF * CPI * r] = pfA[r];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) lds[lB[r]] = pfB[r];
-        gv[lane] = lane < p ? pg : 0.0;
-    };
-    // Vxx_i from the LDS image, in memory order: all reads first (under a condition the compiler sank each read into its store's branch: 16
-    // LDS round trips in a row), the lanes past the end repeat the last element (the same value to the same address: no exec mask)
-    const unsigned vmax = 8u * (unsigned)(nn - 1);
-    auto store_Vxx = [&](int i) {
-        double vv[RS];
-#pragma unroll
-        for (int r = 0; r < RS; ++r) vv[r] = Vs[s_a[r]];
-#pragma unroll
-        for (int r = 0; r < RS; ++r) asm volatile("" : "+v"(vv[r]));
-        char *const base = (char *)(Vxxg + nn * i);
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            if (DDP_WAVE * r < (int)nn) {                            // (uniform)
-                const unsigned off = min(8u * (unsigned)lane + 512u * r, vmax);
-                *(double *)(base + off) = vv[r];
-            }
+        for (int r = 0; r < RF; ++r) {
+            const int e = lane + DDP_WAVE * r, ee = e < n * p ? e : 0;
+            pfF[r] = ee < (int)nn ? fxi[ee] : fui[ee - (int)nn];
         }
     };
-    // where the u rows of G go (Gu, row - n) — a dump row for the rest; ½ / 0 and 1 / 0 factors of the symmetrisation (rows / columns < n)
-    int gu_row[PT][4];
-    double hrow[NTR][4], cmask[NTR];
-#pragma unroll
-    for (int ti = 0; ti < PT; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * ti + 4 * r + l4; gu_row[ti][r] = (row >= n && row < p) ? (row - n) * PC : MK * PC; }
-#pragma unroll
-    for (int ti = 0; ti < NTR; ++ti) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hrow[ti][r] = (16 * ti + 4 * r + l4 < n) ? 0.5 : 0.0;
-        cmask[ti] = (16 * ti + l15 < n) ? 1.0 : 0.0;
-    }
     // cost Hessians of this lane's tile elements: registers while they do not vary with time
+    const bool ctv = a.cxx_t != 0 || a.cxu_t != 0 || a.cuu_t != 0;
     double hc[PT][PT][4];
     auto load_H = [&](int i) {
         const double *cxxi = cxx + a.cxx_t * i, *cxui = cxu + a.cxu_t * i, *cuui = cuu + a.cuu_t * i;
@@ -193,17 +133,27 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                     hc[ti][cj][r] = c;
                 }
     };
-    // the gradient column (Qx, Qu: column p of G): the lanes l15 == p % 16 of tile column p / 16 add gv[row]; the others read zeros
-    const double *const gsel = (l15 == p % 16 ? gv : lds + L::oZero) + l4;
-    if (N >= 2) { load_F(N - 2); load_H(CTV ? N - 2 : 0); }
+    // the gradient column (Qx, Qu: column p of G): the lanes l15 == p % 16 of tile column p / 16 hold it; requested a step ahead like F
+    const bool gcol = l15 == p % 16;
+    double gq[PT][4];
+    auto load_g = [&](int i) {
+        const double *cxi = cx + (size_t)n * i, *cui = cu + (size_t)m * i;
+#pragma unroll
+        for (int ti = 0; ti < PT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * r + l4;
+                gq[ti][r] = !gcol ? 0.0 : (row < n ? cxi[row] : (row < p ? cui[row - n] : 0.0));     // Qx (:241), Qu (:240)
+            }
+    };
+    if (N >= 2) { load_F(N - 2); load_g(N - 2); if (!ctv) load_H(0); }
     wave_sync();
-    MP_DECL
     for (int i = N - 2; i >= 0; --i) {
-        MP(7)
         // ---- F_i = [fx fu] into the LDS (k fastest; the memory order of both arrays); the next one is requested behind the products
-        store_F();
+#pragma unroll
+        for (int r = 0; r < RF; ++r) if (f_lds[r] >= 0) Fs[f_lds[r]] = pfF[r];
+        if (ctv) load_H(i);
         wave_sync();
-        MP(0)
         // ================= W = Vxx F ==============================================================================
         {
             d4 acc[NTR][PT];
@@ -211,25 +161,17 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
             for (int ri = 0; ri < NTR; ++ri)
 #pragma unroll
                 for (int cj = 0; cj < PT; ++cj) acc[ri][cj] = d4{0.0, 0.0, 0.0, 0.0};
-            // the operands of k-step ks + 1 are read (unconditionally: past n they are zeros) before the products of k-step ks, which a
-            // uniform test skips when 4 ks >= n — with the reads inside the test every k-step waited for its own LDS round trip
-            double av[2][NTR], bv[2][PT];
-            auto rdW = [&](int ks, int sl) __attribute__((always_inline)) {
-#pragma unroll
-                for (int ri = 0; ri < NTR; ++ri) av[sl][ri] = Vs[(16 * ri + l15) + LDV * (4 * ks + l4)];
-#pragma unroll
-                for (int cj = 0; cj < PT; ++cj) bv[sl][cj] = Fs[(4 * ks + l4) + LDF * (16 * cj + l15)];
-            };
-            rdW(0, 0);
 #pragma unroll
             for (int ks = 0; ks < KT; ++ks) {
-                if (ks + 1 < KT) rdW(ks + 1, (ks + 1) & 1);
-                if (4 * ks < n) {
+                double av[NTR], bv[PT];
 #pragma unroll
-                    for (int ri = 0; ri < NTR; ++ri)
+                for (int ri = 0; ri < NTR; ++ri) av[ri] = Vs[(16 * ri + l15) + LDV * (4 * ks + l4)];
 #pragma unroll
-                        for (int cj = 0; cj < PT; ++cj) acc[ri][cj] = mf(av[ks & 1][ri], bv[ks & 1][cj], acc[ri][cj]);
-                }
+                for (int cj = 0; cj < PT; ++cj) bv[cj] = Fs[(4 * ks + l4) + LDF * (16 * cj + l15)];
+#pragma unroll
+                for (int ri = 0; ri < NTR; ++ri)
+#pragma unroll
+                    for (int cj = 0; cj < PT; ++cj) acc[ri][cj] = mf(av[ri], bv[cj], acc[ri][cj]);
             }
 #pragma unroll
             for (int ri = 0; ri < NTR; ++ri)
@@ -239,100 +181,61 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                     wp[0] = acc[ri][cj].x; wp[4 * LDW] = acc[ri][cj].y; wp[8 * LDW] = acc[ri][cj].z; wp[12 * LDW] = acc[ri][cj].w;
                 }
         }
-        if (lane < n) Ws[lane * LDW + p] = vxs[lane];              // column p of [W | Vx] (behind the tile stores: LDS operations of a wave stay in order)
         wave_sync();
-        MP(1)
+        if (lane < n) Ws[lane * LDW + p] = vxs[lane];              // column p of [W | Vx]
+        wave_sync();
         // ================= G = F'[W | Vx] + cost terms ================================================================
         d4 g[PT][PT];
 #pragma unroll
         for (int ti = 0; ti < PT; ++ti)
 #pragma unroll
             for (int cj = 0; cj < PT; ++cj) g[ti][cj] = d4{0.0, 0.0, 0.0, 0.0};
-        {
-            double fa[2][PT], wb[2][PT];
-            auto rdG = [&](int ks, int sl) __attribute__((always_inline)) {
 #pragma unroll
-                for (int ti = 0; ti < PT; ++ti) fa[sl][ti] = Fs[(4 * ks + l4) + LDF * (16 * ti + l15)];      // A[i][k] = F[k, 16 ti + i]
+        for (int ks = 0; ks < KT; ++ks) {
+            double fa[PT], wb[PT];
 #pragma unroll
-                for (int cj = 0; cj < PT; ++cj) wb[sl][cj] = Ws[(4 * ks + l4) * LDW + 16 * cj + l15];        // B[k][j] = W[k, 16 cj + j]
-            };
-            rdG(0, 0);
+            for (int ti = 0; ti < PT; ++ti) fa[ti] = Fs[(4 * ks + l4) + LDF * (16 * ti + l15)];      // A[i][k] = F[k, 16 ti + i]
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) {
-                if (ks + 1 < KT) rdG(ks + 1, (ks + 1) & 1);
-                if (4 * ks < n) {
+            for (int cj = 0; cj < PT; ++cj) wb[cj] = Ws[(4 * ks + l4) * LDW + 16 * cj + l15];        // B[k][j] = W[k, 16 cj + j]
 #pragma unroll
-                    for (int ti = 0; ti < PT; ++ti)
+            for (int ti = 0; ti < PT; ++ti)
 #pragma unroll
-                        for (int cj = 0; cj < PT; ++cj) g[ti][cj] = mf(fa[ks & 1][ti], wb[ks & 1][cj], g[ti][cj]);
-                }
-            }
+                for (int cj = 0; cj < PT; ++cj) g[ti][cj] = mf(fa[ti], wb[cj], g[ti][cj]);
         }
-        MP(8)
-        {   // cost Hessians and gradients; the u rows leave for the gains (Gu; other rows aim at its dump row), the tile column that holds
-            // column p goes to the (dead) W image whole: Qx_j = Gc[j][p % 16] — no per-element test, no exec-mask branch
+        if (i > 0) load_F(i - 1);                                     // (Fs has been read for the last time unless regType 2 needs it: it stays untouched)
+        {   // cost Hessians and gradients; the u rows and column p leave for the gains
             const int cjp = p / 16;
-            double *const Gc = Ws + l4 * 17 + l15;
 #pragma unroll
-            for (int ti = 0; ti < PT; ++ti) {
-                const bool urows = 16 * ti + 16 > n && 16 * ti < p;                    // (uniform)
+            for (int ti = 0; ti < PT; ++ti)
 #pragma unroll
                 for (int cj = 0; cj < PT; ++cj) {
+                    const int col = 16 * cj + l15;
                     double v[4] = {g[ti][cj].x, g[ti][cj].y, g[ti][cj].z, g[ti][cj].w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += hc[ti][cj][r];
-                    if (cj == cjp) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += gsel[16 * ti + 4 * r];       // (zeros outside the lanes of column p; hc is zero in them)
-                        if (ti < NTR) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) Gc[(16 * ti + 4 * r) * 17] = v[r];
-                        }
-                    }
-                    if (urows) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Gu[gu_row[ti][r] + 16 * cj + l15] = v[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ti + 4 * r + l4;
+                        v[r] += (cj == cjp && gcol) ? gq[ti][r] : hc[ti][cj][r];
+                        if (row >= n && row < p) Gu[(row - n) * PC + col] = v[r];
+                        if (row < n && col == p) qxs[row] = v[r];
                     }
                     g[ti][cj] = d4{v[0], v[1], v[2], v[3]};
                 }
-            }
+            if (i > 0) load_g(i - 1);
         }
-        // Vxx_{i+1} leaves from the image it is still in (its stores have the rest of the step to land before anything waits on the
-        // memory counter), then the one batch of loads for step i - 1 (step 0 asks for itself once more: no branch around the requests)
-        MP(9)
-        store_Vxx(i + 1);
-        MP(10)
-        load_F(i > 0 ? i - 1 : 0);
-        if (CTV) load_H(i > 0 ? i - 1 : 0);
         wave_sync();
-        MP(2)
         // ================= gains (backward_pass.jl:30-62), every lane the m x m system ==================================
         // RL: the m x m system of the 8 x 8 instantiation WITHOUT limits lives in the LDS (Hs, Rs, ris: every lane runs the same scalar
         // factorisation on them — identical values to identical addresses — and solves its own right-hand side with broadcast reads):
         // three 64-element register arrays per lane spilled to scratch (n = 32, m = 8: 35 us per step).  The 4 x 4 instantiation and the
         // box-QP keep the register routines of boxqp_dev.h.
         constexpr bool RL = MM == 8 && !LIMS;
-        double H[RL ? 1 : MM * MM], R[RL ? 1 : MM * MM], Qu[MM], kk[MM], ri[RL ? 1 : MM];
-        // Quu: registers for the 4 x 4 system (every read of the step issued at once, zeros past m), LDS broadcasts (Gu[q][n + q2]) for 8 x 8
-        constexpr bool QR = MM == 4;
-        double Quu[QR ? MM * MM : 1];
-        if constexpr (QR) {
-#pragma unroll
-            for (int e = 0; e < MM * MM; ++e) Quu[e] = Gu[(e % MM) * PC + n + e / MM];
-#pragma unroll
-            for (int e = 0; e < MM * MM; ++e) Quu[e] = (e % MM < m && e / MM < m) ? Quu[e] : 0.0;
-        }
-        auto quu = [&](int q, int q2) __attribute__((always_inline)) -> double {
-            if constexpr (QR) return Quu[q + MM * q2];
-            else return q2 < m ? Gu[q * PC + n + q2] : 0.0;
-        };
+        double H[RL ? 1 : MM * MM], R[RL ? 1 : MM * MM], Qu[MM], kk[MM], ri[RL ? 1 : MM];      // (Quu itself stays in the LDS: Gu[q][n + q2])
         unsigned clamped = 0u;
 #pragma unroll
         for (int c2 = 0; c2 < MM; ++c2) Qu[c2] = c2 < m ? Gu[c2 * PC + p] : 0.0;
-        const int lc = lane < n ? lane : n - 1;                    // (lanes past n repeat column n - 1 and drop the result: no branch around the reads)
-        double xr[MM];                                            // Qux_reg[:, lane]; rows q >= m of Gu are never written: zeros
+        double xr[MM];                                            // Qux_reg[:, lane]
 #pragma unroll
-        for (int q = 0; q < MM; ++q) xr[q] = Gu[q * PC + lc];
+        for (int q = 0; q < MM; ++q) xr[q] = (q < m && lane < n) ? Gu[q * PC + lane] : 0.0;
         if (regType == 2) {                                       // Vxx_reg = Vxx + λI: λ fu'fx on Qux_reg (:246)
 #pragma unroll
             for (int q = 0; q < MM; ++q) {
@@ -367,7 +270,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                     }
                 }
             } else {
-                chol_solve_ri<MM>(MM, R, ri, bv);
+                chol_solve_ri<MM>(m, R, ri, bv);
             }
         };
         if constexpr (RL) {
@@ -422,7 +325,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
             for (int c2 = 0; c2 < MM; ++c2)
 #pragma unroll
-                for (int r2 = 0; r2 < MM; ++r2) H[r2 + MM * c2] = (r2 < m && c2 < m) ? (QR ? quu(r2, c2) : Gu[r2 * PC + n + c2]) : (r2 == c2 ? 1.0 : 0.0);   // identity past m: the system is solved at its compiled size, no run-time bounds in the factorisation and the solves
+                for (int r2 = 0; r2 < MM; ++r2) H[r2 + MM * c2] = (r2 < m && c2 < m) ? Gu[r2 * PC + n + c2] : 0.0;
             if (regType == 2) {                                   // λ fu'fu on QuuF (:247)
 #pragma unroll
                 for (int q = 0; q < MM; ++q)
@@ -439,35 +342,29 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                 for (int q = 0; q < MM; ++q) H[q + MM * q] += (q < m) ? lam : 0.0;
             }
             if (!LIMS || nolims) {
-                fail = chol_masked_ri<MM>(MM, H, 0u, R, ri);           // cholesky(Hermitian(QuuF))  (:35)
+                fail = chol_masked_ri<MM>(m, H, 0u, R, ri);            // cholesky(Hermitian(QuuF))  (:35)
 #pragma unroll
                 for (int q = 0; q < MM; ++q) kk[q] = Qu[q];
                 solve(kk);
 #pragma unroll
                 for (int q = 0; q < MM; ++q) kk[q] = -kk[q];         // k_i = -(R\Qu)  (:41)
             } else {
-                // coordinates past m: gradient 1 on the interval [0, 0] — clamped in every iteration (x == lower, grad > 0), so they add
-                // nothing to any sum and the all-clamped exit (:98) still means "every control"
-                double lo[MM], up[MM], gqp[MM];
+                double lo[MM], up[MM];
 #pragma unroll
-                for (int q = 0; q < MM; ++q) {
-                    const double uq = q < m ? ug[(size_t)m * i + q] : 0.0;
-                    lo[q] = q < m ? limlo[q] - uq : 0.0; up[q] = q < m ? limhi[q] - uq : 0.0; gqp[q] = q < m ? Qu[q] : 1.0;      // (:45-46)
-                }
+                for (int q = 0; q < MM; ++q) { const double uq = q < m ? ug[(size_t)m * i + q] : 0.0; lo[q] = limlo[q] - uq; up[q] = limhi[q] - uq; }   // (:45-46)
                 int iters;
-                const int result = boxqp_dev_ri<MM>(MM, H, gqp, lo, up, kprev, qpo, kk, R, ri, clamped, iters);    // (:49), warm start k[:, min(i+1, N-1)]
+                const int result = boxqp_dev_ri<MM>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);      // (:49), warm start k[:, min(i+1, N-1)]
                 fail = (result < 1);                                 // (:53)
             }
         }
-        if (lane < (int)mm) Quug[mm * i + lane] = Gu[quu_src];     // assigned before a failure upstream too
+        if (lane < (int)mm) Quug[mm * i + lane] = Gu[(lane % m) * PC + n + lane / m];     // assigned before a failure upstream too
         if (fail) { diverge = i + 1; break; }                        // (:37-38, :54-55): wave-uniform
-        MP(3)
         double Quuk[MM];
 #pragma unroll
         for (int q = 0; q < MM; ++q) {
             double t = 0.0;
 #pragma unroll
-            for (int q2 = 0; q2 < MM; ++q2) t += quu(q, q2) * kk[q2];
+            for (int q2 = 0; q2 < MM; ++q2) t += (q2 < m ? Gu[q * PC + n + q2] : 0.0) * kk[q2];
             Quuk[q] = t;                                             // (:64)
             kprev[q] = kk[q];
         }
@@ -478,32 +375,23 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
             dV0 += kQu; dV1 += 0.5 * kQuuk;                          // (:68)
         }
         {   // K_i column `lane`, Y = Quu K + 2 Qux, Vx_i  (:42 / :57-61, :69)
-            double col[MM], x2[MM], yy[MM];
+            double col[MM], x2[MM];
 #pragma unroll
-            for (int q = 0; q < MM; ++q) { x2[q] = Gu[q * PC + lc]; col[q] = ((clamped >> q) & 1u) ? 0.0 : xr[q]; }
-            double vx = Ws[lc * 17 + (p & 15)];                      // Qx_j from the tile column of column p (the epilogue above)
+            for (int q = 0; q < MM; ++q) { x2[q] = (q < m && lane < n) ? Gu[q * PC + lane] : 0.0; col[q] = ((clamped >> q) & 1u) ? 0.0 : xr[q]; }
             solve(col);
 #pragma unroll
-            for (int q = 0; q < MM; ++q) col[q] = (((clamped >> q) & 1u) || q >= m) ? 0.0 : -col[q];
+            for (int q = 0; q < MM; ++q) col[q] = (((clamped >> q) & 1u) || q >= m || lane >= n) ? 0.0 : -col[q];
+            double vx = lane < n ? qxs[lane] : 0.0;
 #pragma unroll
             for (int q = 0; q < MM; ++q) {
                 double t = 2.0 * x2[q];
 #pragma unroll
-                for (int q2 = 0; q2 < MM; ++q2) t += quu(q, q2) * col[q2];
+                for (int q2 = 0; q2 < MM; ++q2) t += (q2 < m ? Gu[q * PC + n + q2] : 0.0) * col[q2];
                 vx += col[q] * (Quuk[q] + Qu[q]) + x2[q] * kk[q];
-                yy[q] = t;
+                if (lane < NR) { Ks[q * NR + lane] = col[q]; Ys[q * NR + lane] = (q < m && lane < n) ? 0.5 * t : 0.0; }
+                if (q < m && lane < n) Kg[nm * i + q + (size_t)m * lane] = col[q];       // (:76)
             }
-            const bool ln = lane < n;
-            if (lane < NR) {
-#pragma unroll
-                for (int q = 0; q < MM; ++q) { Ks[q * NR + lane] = ln ? col[q] : 0.0; Ys[q * NR + lane] = ln ? yy[q] : 0.0; }   // (rows q >= m: zeros)
-            }
-            if (ln) {
-#pragma unroll
-                for (int q = 0; q < MM; ++q)
-                    if (q < m) Kg[nm * i + q + (size_t)m * lane] = col[q];       // (:76)
-                Vxg[(size_t)n * i + lane] = vx; vxs[lane] = vx;
-            }
+            if (lane < n) { Vxg[(size_t)n * i + lane] = vx; vxs[lane] = vx; }
             if (lane < m) {
                 double kv = kk[0];
 #pragma unroll
@@ -512,9 +400,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
             }
         }
         wave_sync();
-        MP(4)
-        // ================= Vxx_i = Qxx + ½(K'Y + Y'K)  (:70-72): P = Qxx + K'Y on the xx tiles, then ½(P + P') — the symmetric part of
-        // K'Y is ½(K'Y + Y'K), so ONE product per tile and k-step instead of two ============================================
+        // ================= Vxx_i = Qxx + ½(K'Y + Y'K)  (:70-72): rank-2m update of the xx tiles, then ½(V + V') ==========
 #pragma unroll
         for (int ks = 0; ks < MM / 4; ++ks) {                           // (rows q >= MM of K, Y do not exist: MM / 4 k-steps)
             double ka[NTR], ya[NTR];
@@ -523,7 +409,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
             for (int ti = 0; ti < NTR; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < NTR; ++tj) g[ti][tj] = mf(ka[ti], ya[tj], g[ti][tj]);      // K'Y: its symmetric part is ½(K'Y + Y'K)
+                for (int tj = 0; tj < NTR; ++tj) {
+                    g[ti][tj] = mf(ka[ti], ya[tj], g[ti][tj]);           // K'(½Y)
+                    g[ti][tj] = mf(ya[ti], ka[tj], g[ti][tj]);           // (½Y)'K
+                }
         }
         wave_sync();                                                   // K, Y have been read: the region takes the unsymmetrised Vxx_i
 #pragma unroll
@@ -534,26 +423,17 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                 vp[0] = g[ti][tj].x; vp[4] = g[ti][tj].y; vp[8] = g[ti][tj].z; vp[12] = g[ti][tj].w;
             }
         wave_sync();
-        MP(5)
-        // ½(P + P') in the accumulator layout: the transposed element of (row, col) = (16 ti + 4 r + l4, 16 tj + l15) is one LDS read at a
-        // per-lane base + an immediate; rows / columns past n become exact zeros by their ½ / 0 and 1 / 0 factors (the image stays padded)
-        {
-            const double *tp = Vr + l15 + LDV * l4;
 #pragma unroll
-            for (int ti = 0; ti < NTR; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < NTR; ++tj) {
-                    const double own[4] = {g[ti][tj].x, g[ti][tj].y, g[ti][tj].z, g[ti][tj].w};
-                    double *vp = Vs + (16 * ti + l4) + LDV * (16 * tj + l15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vp[4 * r] = ((own[r] + tp[16 * tj + LDV * (16 * ti + 4 * r)]) * hrow[ti][r]) * cmask[tj];
-                }
+        for (int r = 0; r < RS; ++r) {
+            const int e = lane + DDP_WAVE * r;
+            if (e < (int)nn) {
+                const double v = 0.5 * (Vr[s_a[r]] + Vr[s_b[r]]);
+                Vs[s_a[r]] = v;
+                Vxxg[nn * i + e] = v;
+            }
         }
         wave_sync();
-        MP(6)
     }
-    if (!diverge) store_Vxx(0);                                       // (the last image; the terminal one when N = 1)
-    MP_DUMP
     if (diverge) {                                                      // outputs earlier in time than a failing step are zero (:37-38 with :226-229)
         const size_t ie = (size_t)diverge;
         for (size_t e = lane; e < nm * ie; e += DDP_WAVE) Kg[e] = 0.0;
@@ -565,29 +445,26 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
     if (lane == 0) { a.dV[2 * b] = dV0; a.dV[2 * b + 1] = dV1; a.diverge[b] = diverge; }
 }
 
-template <int NTR, int PT, int MMX, bool LIMS, bool CTV>
-int launch_mid2(ddp_handle h, const ddp_bp_desc *d, const BPMidArgs &a)
+template <int NTR, int PT, int MMX>
+int launch_mid8(ddp_handle h, const ddp_bp_desc *d, const BPMid8Args &a)
 {
-    const size_t bytes = (size_t)MidLds<NTR, PT, MMX>::oTot * sizeof(double);
+    const size_t bytes = (size_t)Mid8Lds<NTR, PT, MMX>::oTot * sizeof(double);
     const dim3 grid((unsigned)d->B), block(DDP_WAVE);
-    DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mid_kernel<NTR, PT, MMX, LIMS, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL((back_pass_mid_kernel<NTR, PT, MMX, LIMS, CTV>), grid, block, bytes, h->stream, a);
+    if (d->has_lims) {
+        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mid8_kernel<NTR, PT, MMX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL((back_pass_mid8_kernel<NTR, PT, MMX, true>), grid, block, bytes, h->stream, a);
+    } else {
+        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mid8_kernel<NTR, PT, MMX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL((back_pass_mid8_kernel<NTR, PT, MMX, false>), grid, block, bytes, h->stream, a);
+    }
     DDP_HIP(hipGetLastError());
     return 0;
-}
-
-template <int NTR, int PT, int MMX>
-int launch_mid(ddp_handle h, const ddp_bp_desc *d, const BPMidArgs &a)
-{
-    const bool ctv = a.cxx_t != 0 || a.cxu_t != 0 || a.cuu_t != 0;       // cost terms that vary with time: requested per step with the batch
-    if (d->has_lims) return ctv ? launch_mid2<NTR, PT, MMX, true, true>(h, d, a) : launch_mid2<NTR, PT, MMX, true, false>(h, d, a);
-    return ctv ? launch_mid2<NTR, PT, MMX, false, true>(h, d, a) : launch_mid2<NTR, PT, MMX, false, false>(h, d, a);
 }
 
 }   // namespace
 
 // returns 1 if the shape is not handled here (n > 32, m > 8, n + m + 1 > 48), 0 launched, < 0 error
-int ddp_launch_back_pass_mid(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+int ddp_launch_back_pass_mid8(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
                              const double *fu, const double *lambda, const double *lims, const double *u,
                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
@@ -596,7 +473,7 @@ int ddp_launch_back_pass_mid(ddp_handle h, const ddp_bp_desc *d, const double *c
     const int n = d->n, m = d->m;
     if (n < 1 || m < 1 || n > 32 || m > 8) return 1;
     const long N = d->N;
-    BPMidArgs a;
+    BPMid8Args a;
     a.n = n; a.m = m; a.N = d->N; a.B = d->B; a.regType = d->regType;
     const long nn = (long)n * n, nm = (long)n * m, mm = (long)m * m;
     a.fx_t = d->fx_tv ? nn : 0; a.fx_b = d->fx_batched ? nn * (d->fx_tv ? N : 1) : 0;
@@ -608,8 +485,7 @@ int ddp_launch_back_pass_mid(ddp_handle h, const ddp_bp_desc *d, const double *c
     a.u = u; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     const int ntr = n <= 16 ? 1 : 2, pt = (n + m + 1 + 15) / 16;           // pt = 1 only for n + m <= 15: the row kernels' range, padded to 2 here
-    if (m > 4)                                                            // the 8 x 8 system: back_pass_mid8.hip (the first form of this kernel)
-        return ddp_launch_back_pass_mid8(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
-    if (ntr == 1) return launch_mid<1, 2, 4>(h, d, a);
-    return pt <= 2 ? launch_mid<2, 2, 4>(h, d, a) : launch_mid<2, 3, 4>(h, d, a);
+    if (m <= 4) return 1;                                                 // (back_pass_mid.hip)
+    if (ntr == 1) return launch_mid8<1, 2, 8>(h, d, a);
+    return pt <= 2 ? launch_mid8<2, 2, 8>(h, d, a) : launch_mid8<2, 3, 8>(h, d, a);
 }
