@@ -8,12 +8,17 @@
 //   W  = Vxx F            NTR x PT tiles, NR / 4 k-steps (A: Vs, B: Fs)                       (:165 / :203 / :240, the products with Vxx)
 //   Ws[:, p] := Vx        the column behind the last one of F, so that
 //   G  = F' [W | Vx] + [H | c]   PT x PT tiles: Qxx, Qux, Quu and, in column p, Qx and Qu     (:165-169 / :203-210 / :240-244)
-//   gains                 every lane factorises QuuF (run-time-sized routines of boxqp_dev.h, as the vector kernel), lane c solves column c of K
-//   Vxx_i = Qxx + ½(K'Y + Y'K), Y = Quu K + 2 Qux     rank-2m update on the xx tiles: 4 NTR² more products (:69-72), then ½(V + V') exactly
+//   gains                 m <= 4: every lane the identity-padded 4 x 4 system on registers (boxqp_dev.h), lane c solves column c of K;
+//                         4 < m <= 8: one coordinate per lane (boxqp_rows.h), Φ = QuuF^-1 from 8 unit-vector solves, K = -Φ Qux_reg and
+//                         Y = Quu K + 2 Qux as 4 NTR more products
+//   Vxx_i = Qxx + ½(K'Y + Y'K)    P = Qxx + K'Y on the xx tiles (NTR² products per k-step), then ½(P + P') exactly (:69-72)
+// Round 5 (profiles/r05_mid_phases.txt): every global load of a step in ONE straight-line batch behind the second product, consumed at the
+// top of the next step; Vxx_{i+1} stored from its LDS image just in front of that batch; no exec-mask branch per element anywhere.
 // Operands with run-time strides (one instantiation for the LTI / LTV / TV-cost methods).  Accumulator layout of the instruction:
 // register r of lane (l4, l15) holds row 4r + l4, column l15 of a tile; A operand lane = A[i = l15][k = l4], B = B[k = l4][j = l15].
 #include "ddp_internal.h"
 #include "boxqp_dev.h"
+#include "boxqp_rows.h"
 
 // -DMID_PROF: s_memtime ticks per phase of a step, summed over the launch by trajectory 0 and left in the first words of its Vxx
 // (profiles/mid_phase_profile.py); a profiling build only
@@ -48,7 +53,7 @@ struct MidLds {
     // the W image is dead behind the second product: K, ½Y and the unsymmetrised Vxx_i live there
     static constexpr int WSZ = NR * LDW > 2 * MK * NR + NR * LDV ? NR * LDW : 2 * MK * NR + NR * LDV;
     static constexpr int oV = 0, oF = oV + NR * LDV, oW = oF + LDF * PC, oGu = oW + WSZ, oQx = oGu + (MK + 1) * PC, oVx = oQx + NR,   // (row MK of Gu: a dump row)
-                         oQuu = oVx + NR, oRs = oQuu + MK * MK, oRi = oRs + MK * MK, oSink = oRi + MK + 2, oGv = oSink + DDP_WAVE, oZero = oGv + DDP_WAVE, oTot = oZero + PC;
+                         oQuu = oVx + NR, oRs = oQuu + MK * MK, oRi = oRs + MK * MK, oSink = oRi + 2 * MK, oGv = oSink + DDP_WAVE, oZero = oGv + DDP_WAVE, oUv = oZero + PC, oTot = oUv + 8;
     static constexpr int oK = oW, oY = oW + MK * NR, oVr = oW + 2 * MK * NR;
 };
 
@@ -94,7 +99,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
         for (int e = lane; e < (int)nm; e += DDP_WAVE) Kg[nm * tl + e] = 0.0;
         if (lane < m) kg[(size_t)m * tl + lane] = 0.0;
     }
-    double dV0 = 0.0, dV1 = 0.0, kprev[MM];
+    double dV0 = 0.0, dV1 = 0.0, kprev[MM], kprev8 = 0.0;
+    const double lim_lo = (LIMS && (l15 & 7) < m) ? a.lims[l15 & 7] : -1.0, lim_hi = (LIMS && (l15 & 7) < m) ? a.lims[(l15 & 7) + m] : 1.0;
+    int k_src[4];                                                 // element e of K_i (memory order, m x n): its place in the LDS image Ks[q][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int e = lane + DDP_WAVE * r, ee = e < (int)nm ? e : 0; k_src[r] = (ee % m) * NR + ee / m; }
 #pragma unroll
     for (int q = 0; q < MM; ++q) kprev[q] = 0.0;
     int diverge = 0;
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
         s_a[r] = (ee % n) + LDV * (ee / n);
     }
     const int quu_src = lane < (int)mm ? (lane % m) * PC + n + lane / m : 0;      // (no division by a run-time m inside the loop)
-    double pfA[RA], pfB[RB], pg;                                  // F and the gradients of the next step, requested a step ahead
+    double pfA[RA], pfB[RB], pg, pu = 0.0;                        // F, the gradients (and, with limits, u) of the next step, requested a step ahead
+    double *const uvec = lds + L::oUv;
     auto load_F = [&](int i) {
         const char *fxi = (const char *)(fx + a.fx_t * i), *fui = (const char *)(fu + a.fu_t * i);
 #pragma unroll
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
         for (int r = 0; r < RB; ++r) pfB[r] = *(const double *)(fui + gB[r]);
         pg = *(const double *)(gptr + (size_t)gstride * i);
+        if constexpr (LIMS) pu = ug[(size_t)m * i + (lane < m ? lane : 0)];
     };
     auto store_F = [&]() {
 #pragma unroll
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 #pragma unroll
         for (int r = 0; r < RB; ++r) lds[lB[r]] = pfB[r];
         gv[lane] = lane < p ? pg : 0.0;
+        if constexpr (LIMS) { if (lane < 8) uvec[lane] = lane < m ? pu : 0.0; }
     };
     // Vxx_i from the LDS image, in memory order: all reads first (under a condition the compiler sank each read into its store's branch: 16
     // LDS round trips in a row), the lanes past the end repeat the last element (the same value to the same address: no exec mask)
@@ -270,9 +282,9 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
         }
         MP(8)
         {   // cost Hessians and gradients; the u rows leave for the gains (Gu; other rows aim at its dump row), the tile column that holds
-            // column p goes to the (dead) W image whole: Qx_j = Gc[j][p % 16] — no per-element test, no exec-mask branch
+            // column p goes to a free region whole: Qx_j = Gc[j][p % 16] — no per-element test, no exec-mask branch
             const int cjp = p / 16;
-            double *const Gc = Ws + l4 * 17 + l15;
+            double *const Gc = Vr + l4 * 17 + l15;                     // (the region of the unsymmetrised Vxx_i: free until the value update)
 #pragma unroll
             for (int ti = 0; ti < PT; ++ti) {
                 const bool urows = 16 * ti + 16 > n && 16 * ti < p;                    // (uniform)
@@ -306,26 +318,131 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
         if (CTV) load_H(i > 0 ? i - 1 : 0);
         wave_sync();
         MP(2)
-        // ================= gains (backward_pass.jl:30-62), every lane the m x m system ==================================
-        // RL: the m x m system of the 8 x 8 instantiation WITHOUT limits lives in the LDS (Hs, Rs, ris: every lane runs the same scalar
-        // factorisation on them — identical values to identical addresses — and solves its own right-hand side with broadcast reads):
-        // three 64-element register arrays per lane spilled to scratch (n = 32, m = 8: 35 us per step).  The 4 x 4 instantiation and the
-        // box-QP keep the register routines of boxqp_dev.h.
-        constexpr bool RL = MM == 8 && !LIMS;
-        double H[RL ? 1 : MM * MM], R[RL ? 1 : MM * MM], Qu[MM], kk[MM], ri[RL ? 1 : MM];
-        // Quu: registers for the 4 x 4 system (every read of the step issued at once, zeros past m), LDS broadcasts (Gu[q][n + q2]) for 8 x 8
-        constexpr bool QR = MM == 4;
-        double Quu[QR ? MM * MM : 1];
-        if constexpr (QR) {
-#pragma unroll
-            for (int e = 0; e < MM * MM; ++e) Quu[e] = Gu[(e % MM) * PC + n + e / MM];
-#pragma unroll
-            for (int e = 0; e < MM * MM; ++e) Quu[e] = (e % MM < m && e / MM < m) ? Quu[e] : 0.0;
+        // ================= gains (backward_pass.jl:30-62) ==============================================================================
+        if constexpr (MM == 8) {
+        // ---- 4 < m <= 8: the m x m system with ONE COORDINATE PER LANE (boxqp_rows.h: lane i of every 16-lane row holds row / column i of
+        // QuuF and of its factor; products, factorisation and solves are runs of v_fmac_f64_dpp row_newbcast), identity past m; the gains
+        // K = -Φ Qux_reg and Y = Quu K + 2 Qux on the matrix cores with Φ = QuuF^-1 (masked by the clamped set) from 8 unit-vector solves,
+        // four per pass (one per 16-lane row).  The first form let every lane repeat the 8 x 8 system on per-lane arrays: 500-1 500 bytes
+        // of scratch per lane, 9 - 13 000 cycles for the gains and as many for K, Y of a step (profiles/r05_mid_phases.txt).
+        double *const Ph = Rs, *const kv8 = ris, *const wv8 = ris + 8;
+        const int ci = l15 & 7;
+        const bool in8 = l15 < 8;
+        {   // QuuF (:247): one element per lane, identity past m
+            const int r2 = lane & 7, c2 = lane >> 3;
+            double v = r2 == c2 ? 1.0 : 0.0;
+            if (r2 < m && c2 < m) {
+                v = Gu[r2 * PC + n + c2];
+                if (regType == 2) {
+                    double sv = 0.0;
+                    for (int k2 = 0; k2 < n; ++k2) sv += Fs[k2 + LDF * (n + r2)] * Fs[k2 + LDF * (n + c2)];
+                    v += lam * sv;
+                } else if (r2 == c2) v += lam;
+            }
+            Hs[lane] = v;
         }
-        auto quu = [&](int q, int q2) __attribute__((always_inline)) -> double {
-            if constexpr (QR) return Quu[q + MM * q2];
-            else return q2 < m ? Gu[q * PC + n + q2] : 0.0;
-        };
+        const double *Qxr = Gu;                                   // Qux_reg, rows q < 8 with pitch PC (:246)
+        if (regType == 2) {                                       // Vxx_reg = Vxx + λI: λ fu'fx on Qux_reg — its own image
+            double *const Gr = lds + L::oTot;                          // (8 x PC doubles the launcher adds to the allocation for regType 2)
+            const int lcq = lane < n ? lane : 0;
+            for (int q = 0; q < m; ++q) {
+                double sx = 0.0;
+                for (int k2 = 0; k2 < n; ++k2) sx += Fs[k2 + LDF * (n + q)] * Fs[k2 + LDF * lcq];
+                if (lane < NR) Gr[q * PC + lane] = lane < n ? Gu[q * PC + lane] + lam * sx : 0.0;
+            }
+            for (int q = m; q < 8; ++q) if (lane < NR) Gr[q * PC + lane] = 0.0;
+            Qxr = Gr;
+        }
+        wave_sync();
+        bqr::Rows<8> qr;
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) { qr.Hrow[j2] = Hs[ci + 8 * j2]; qr.Hcol[j2] = Hs[j2 + 8 * ci]; }
+        const double Qui = ci < m ? Gu[ci * PC + p] : 0.0;          // Qu_i
+        double quurow[8];                                         // Quu[i, :] (unregularised; zeros past m)
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) quurow[j2] = Gu[ci * PC + n + j2];
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) quurow[j2] = (ci < m && j2 < m) ? quurow[j2] : 0.0;
+        unsigned clamped = 0u;
+        int fail;
+        double ki;
+        if (!LIMS || nolims) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) { qr.Rcol[k2] = 0.0; qr.Rrow[k2] = 0.0; qr.ri[k2] = 0.0; }
+            fail = bqr::factor<8>(qr, 0u, l15, in8);                 // cholesky(Hermitian(QuuF))  (:35)
+            ki = -bqr::solve<8>(qr, in8 ? Qui : 0.0, l15);          // k_i = -(R\(R'\Qu))  (:41)
+        } else {
+            // coordinates past m: gradient 1 on the interval [0, 0] — clamped in every iteration (x == lower, grad > 0)
+            const double uq = uvec[ci];
+            const double lo = ci < m ? lim_lo - uq : 0.0, up = ci < m ? lim_hi - uq : 0.0, gq8 = ci < m ? Qui : 1.0;      // (:45-46)
+            int iters;
+            const int result = bqr::boxqp_rows<8>(qr, gq8, lo, up, kprev8, qpo, l15, ki, clamped, iters);            // (:49)
+            fail = (result < 1);                                     // (:53)
+        }
+        if (lane < (int)mm) Quug[mm * i + lane] = Gu[quu_src];        // assigned before a failure upstream too
+        if (fail) { diverge = i + 1; break; }                        // (:37-38, :54-55): wave-uniform
+        MP(3)
+        kprev8 = ki;
+        {   // Φ = (masked QuuF)^-1 without the clamped rows / columns: column c = 4 pass + (lane >> 4) per 16-lane row
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int c = 4 * ps + l4;
+                const double y = bqr::solve<8>(qr, (in8 && l15 == c && !((clamped >> c) & 1u)) ? 1.0 : 0.0, l15);
+                if (in8) Ph[l15 + 8 * c] = ((clamped >> l15) & 1u) ? 0.0 : y;
+            }
+        }
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
+        const double Quuki = bqr::rowdot<8>(in8 ? ki : 0.0, quurow);       // (Quu k)_i  (:64)
+        dV0 += bqr::rowsum<8>(in8 ? ki * Qui : 0.0, one);                   // (:68)
+        dV1 += 0.5 * bqr::rowsum<8>(in8 ? ki * Quuki : 0.0, one);
+        if (lane < 8) { kv8[lane] = ki; wv8[lane] = Quuki + Qui; }
+        if (lane < m) kg[(size_t)m * i + lane] = ki;                                   // (:75)
+        wave_sync();
+        {   // K = -Φ Qux_reg, Y = Quu K + 2 Qux: rows 4 r + l4 < 8 of the accumulators (r = 0, 1); K in the accumulator layout IS the B operand of Y
+            const double *const phA = in8 ? Ph + l15 : lds + L::oZero;      // A[i = l15][k]: Φ[l15][k], zero rows past 8
+            const int phs = in8 ? 8 : 0;
+#pragma unroll
+            for (int tj = 0; tj < NTR; ++tj) {
+                d4 kacc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    kacc = mf(phA[phs * (4 * ks + l4)], Qxr[(4 * ks + l4) * PC + 16 * tj + l15], kacc);
+                const double k0 = -kacc.x, k1 = -kacc.y;            // K[l4][col], K[4 + l4][col]
+                d4 yacc = d4{2.0 * Gu[l4 * PC + 16 * tj + l15], 2.0 * Gu[(4 + l4) * PC + 16 * tj + l15], 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const double qa = Gu[(in8 ? l15 : 0) * PC + n + 4 * ks + l4];
+                    yacc = mf((in8 && 4 * ks + l4 < m) ? qa : 0.0, ks == 0 ? k0 : k1, yacc);
+                }
+                Ks[l4 * NR + 16 * tj + l15] = k0; Ks[(4 + l4) * NR + 16 * tj + l15] = k1;
+                Ys[l4 * NR + 16 * tj + l15] = yacc.x; Ys[(4 + l4) * NR + 16 * tj + l15] = yacc.y;
+            }
+        }
+        wave_sync();
+        {   // Vx_i (:69) and K_i in memory order (:76)
+            const int lc = lane < n ? lane : n - 1;
+            double vx = Vr[lc * 17 + (p & 15)];                      // Qx_j
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vx += Ks[q * NR + lc] * wv8[q] + Gu[q * PC + lc] * kv8[q];
+            if (lane < n) { Vxg[(size_t)n * i + lane] = vx; vxs[lane] = vx; }
+            double kvv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kvv[r] = Ks[k_src[r]];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (lane + DDP_WAVE * r < (int)nm) Kg[nm * i + lane + DDP_WAVE * r] = kvv[r];
+        }
+        // (columns n.. of the K, Y images carry finite products of the u columns of Gu: the value update's rows / columns past n are zeroed by its factors)
+        } else {
+        // ---- m <= 4: every lane the (identity-padded) 4 x 4 system on registers (boxqp_dev.h)
+        double H[MM * MM], R[MM * MM], Qu[MM], kk[MM], ri[MM];
+        double Quu[MM * MM];                                       // every read of the step issued at once, zeros past m
+#pragma unroll
+        for (int e = 0; e < MM * MM; ++e) Quu[e] = Gu[(e % MM) * PC + n + e / MM];
+#pragma unroll
+        for (int e = 0; e < MM * MM; ++e) Quu[e] = (e % MM < m && e / MM < m) ? Quu[e] : 0.0;
+        auto quu = [&](int q, int q2) __attribute__((always_inline)) -> double { return Quu[q + MM * q2]; };
         unsigned clamped = 0u;
 #pragma unroll
         for (int c2 = 0; c2 < MM; ++c2) Qu[c2] = c2 < m ? Gu[c2 * PC + p] : 0.0;
@@ -344,85 +461,12 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
             }
         }
         int fail;
-        // forward / back substitution with the factor in registers or in the LDS; b <- (R'R)\b
-        auto solve = [&](double (&bv)[MM]) __attribute__((always_inline)) {
-            if constexpr (RL) {
-#pragma unroll
-                for (int i2 = 0; i2 < MM; ++i2) {
-                    if (i2 < m) {
-                        double sv = bv[i2];
-#pragma unroll
-                        for (int k2 = 0; k2 < i2; ++k2) sv -= Rs[k2 + MM * i2] * bv[k2];
-                        bv[i2] = sv * ris[i2];
-                    }
-                }
-#pragma unroll
-                for (int i2 = MM - 1; i2 >= 0; --i2) {
-                    if (i2 < m) {
-                        double sv = bv[i2];
-#pragma unroll
-                        for (int k2 = i2 + 1; k2 < MM; ++k2)
-                            if (k2 < m) sv -= Rs[i2 + MM * k2] * bv[k2];
-                        bv[i2] = sv * ris[i2];
-                    }
-                }
-            } else {
-                chol_solve_ri<MM>(MM, R, ri, bv);
-            }
-        };
-        if constexpr (RL) {
-            {   // QuuF (:247): one element per lane
-                const int r2 = lane & 7, c2 = lane >> 3;
-                double v = 0.0;
-                if (r2 < m && c2 < m) {
-                    v = Gu[r2 * PC + n + c2];
-                    if (regType == 2) {
-                        double sv = 0.0;
-                        for (int k2 = 0; k2 < n; ++k2) sv += Fs[k2 + LDF * (n + r2)] * Fs[k2 + LDF * (n + c2)];
-                        v += lam * sv;
-                    } else if (r2 == c2) v += lam;
-                }
-                Hs[lane] = v;
-            }
-            wave_sync();
-            fail = 0;                                              // chol_masked_ri's statements (boxqp_dev.h) on the LDS image, nothing clamped;
-            // unrolled with guards like the original: the reads of a column are independent and go out together (run-time loops made
-            // every one of the ~100 inner iterations an LDS round trip)
-#pragma unroll
-            for (int j2 = 0; j2 < MM; ++j2) {
-                if (j2 < m) {
-                    double cj_[MM];                               // column j2 of R above the diagonal
-#pragma unroll
-                    for (int k2 = 0; k2 < j2; ++k2) cj_[k2] = Rs[k2 + MM * j2];
-                    double ajj = Hs[j2 + MM * j2];
-#pragma unroll
-                    for (int k2 = 0; k2 < j2; ++k2) ajj -= cj_[k2] * cj_[k2];
-                    if (!(ajj > 0.0) && fail == 0) fail = j2 + 1;
-                    const double rr = ddp_rsqrt(ajj);
-                    ris[j2] = rr;
-                    Rs[j2 + MM * j2] = ajj * rr;
-#pragma unroll
-                    for (int i2 = j2 + 1; i2 < MM; ++i2) {
-                        if (i2 < m) {
-                            double sv = Hs[j2 + MM * i2];
-#pragma unroll
-                            for (int k2 = 0; k2 < j2; ++k2) sv -= cj_[k2] * Rs[k2 + MM * i2];
-                            Rs[j2 + MM * i2] = sv * rr;
-                        }
-                    }
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (int q = 0; q < MM; ++q) kk[q] = Qu[q];
-            solve(kk);
-#pragma unroll
-            for (int q = 0; q < MM; ++q) kk[q] = -kk[q];             // k_i = -(R\Qu)  (:41)
-        } else {
+        auto solve = [&](double (&bv)[MM]) __attribute__((always_inline)) { chol_solve_ri<MM>(MM, R, ri, bv); };      // b <- (R'R)\b
+        {
 #pragma unroll
             for (int c2 = 0; c2 < MM; ++c2)
 #pragma unroll
-                for (int r2 = 0; r2 < MM; ++r2) H[r2 + MM * c2] = (r2 < m && c2 < m) ? (QR ? quu(r2, c2) : Gu[r2 * PC + n + c2]) : (r2 == c2 ? 1.0 : 0.0);   // identity past m: the system is solved at its compiled size, no run-time bounds in the factorisation and the solves
+                for (int r2 = 0; r2 < MM; ++r2) H[r2 + MM * c2] = (r2 < m && c2 < m) ? quu(r2, c2) : (r2 == c2 ? 1.0 : 0.0);   // identity past m: the system is solved at its compiled size, no run-time bounds in the factorisation and the solves
             if (regType == 2) {                                   // λ fu'fu on QuuF (:247)
 #pragma unroll
                 for (int q = 0; q < MM; ++q)
@@ -451,7 +495,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                 double lo[MM], up[MM], gqp[MM];
 #pragma unroll
                 for (int q = 0; q < MM; ++q) {
-                    const double uq = q < m ? ug[(size_t)m * i + q] : 0.0;
+                    const double uq = uvec[q];                      // (u_i came with the step's batch of loads; zeros past m)
                     lo[q] = q < m ? limlo[q] - uq : 0.0; up[q] = q < m ? limhi[q] - uq : 0.0; gqp[q] = q < m ? Qu[q] : 1.0;      // (:45-46)
                 }
                 int iters;
@@ -481,7 +525,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
             double col[MM], x2[MM], yy[MM];
 #pragma unroll
             for (int q = 0; q < MM; ++q) { x2[q] = Gu[q * PC + lc]; col[q] = ((clamped >> q) & 1u) ? 0.0 : xr[q]; }
-            double vx = Ws[lc * 17 + (p & 15)];                      // Qx_j from the tile column of column p (the epilogue above)
+            double vx = Vr[lc * 17 + (p & 15)];                      // Qx_j from the tile column of column p (the epilogue above)
             solve(col);
 #pragma unroll
             for (int q = 0; q < MM; ++q) col[q] = (((clamped >> q) & 1u) || q >= m) ? 0.0 : -col[q];
@@ -510,6 +554,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
                 for (int q = 1; q < MM; ++q) kv = (lane == q) ? kk[q] : kv;
                 kg[(size_t)m * i + lane] = kv;                                           // (:75)
             }
+        }
         }
         wave_sync();
         MP(4)
@@ -568,7 +613,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mid_kernel(BPMidArgs a)
 template <int NTR, int PT, int MMX, bool LIMS, bool CTV>
 int launch_mid2(ddp_handle h, const ddp_bp_desc *d, const BPMidArgs &a)
 {
-    const size_t bytes = (size_t)MidLds<NTR, PT, MMX>::oTot * sizeof(double);
+    const size_t bytes = ((size_t)MidLds<NTR, PT, MMX>::oTot + ((MMX == 8 && a.regType == 2) ? 8 * MidLds<NTR, PT, MMX>::PC : 0)) * sizeof(double);
     const dim3 grid((unsigned)d->B), block(DDP_WAVE);
     DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mid_kernel<NTR, PT, MMX, LIMS, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL((back_pass_mid_kernel<NTR, PT, MMX, LIMS, CTV>), grid, block, bytes, h->stream, a);
@@ -608,8 +653,10 @@ int ddp_launch_back_pass_mid(ddp_handle h, const ddp_bp_desc *d, const double *c
     a.u = u; a.active = active;
     a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
     const int ntr = n <= 16 ? 1 : 2, pt = (n + m + 1 + 15) / 16;           // pt = 1 only for n + m <= 15: the row kernels' range, padded to 2 here
-    if (m > 4)                                                            // the 8 x 8 system: back_pass_mid8.hip (the first form of this kernel)
-        return ddp_launch_back_pass_mid8(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
-    if (ntr == 1) return launch_mid<1, 2, 4>(h, d, a);
-    return pt <= 2 ? launch_mid<2, 2, 4>(h, d, a) : launch_mid<2, 3, 4>(h, d, a);
+    if (m <= 4) {
+        if (ntr == 1) return launch_mid<1, 2, 4>(h, d, a);
+        return pt <= 2 ? launch_mid<2, 2, 4>(h, d, a) : launch_mid<2, 3, 4>(h, d, a);
+    }
+    if (ntr == 1) return launch_mid<1, 2, 8>(h, d, a);
+    return pt <= 2 ? launch_mid<2, 2, 8>(h, d, a) : launch_mid<2, 3, 8>(h, d, a);
 }

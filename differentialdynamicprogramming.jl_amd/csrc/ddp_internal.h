@@ -138,11 +138,6 @@ int ddp_launch_back_pass_mid(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const double *fu, const double *lambda, const double *lims, const double *u,
                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge);
-int ddp_launch_back_pass_mid8(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
-                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
-                              const double *fu, const double *lambda, const double *lims, const double *u,
-                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
-                              double *Vxx, double *dV, int32_t *diverge);      // back_pass_mid8.hip: 4 < m <= 8
 // forward_pass_row.hip: the 16-lane-row rollout compiled for padded sizes (LQ problems, n <= 14, m <= 4); 1 = not applicable
 int ddp_launch_forward_row(ddp_handle h, const ddp_problem *p, const double *K, const double *k, const double *x0,
                            const double *u, const double *x, const double *alpha, int nalpha, const double *lims,
