@@ -368,9 +368,13 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_mid_kernel(FBArgs a)
     __shared__ __attribute__((aligned(16))) double xs[NP], dxs[NP], us[2 * CB];
     const size_t nn = (size_t)n * n, nm = (size_t)n * m;
     const char *ug = (const char *)(a.u + (size_t)m * N * b);
-    const char *xg = pol ? (const char *)(a.x + (size_t)n * N * b) : nullptr;
-    const char *Kg = pol ? (const char *)(a.K + nm * N * b) : nullptr;
-    const char *kg = pol ? (const char *)(a.k + (size_t)m * N * b) : nullptr;
+    // without a policy the gain / nominal-state / k requests aim at u_0 with stride 0 (their values are never used): NO branch around a
+    // load — under a run-time condition the compiler cannot count what is outstanding and waits for everything (s_waitcnt vmcnt(0)) at
+    // the first use, i.e. for the requests of two steps ahead it has just issued
+    const char *xg = pol ? (const char *)(a.x + (size_t)n * N * b) : ug;
+    const char *Kg = pol ? (const char *)(a.K + nm * N * b) : ug;
+    const char *kg = pol ? (const char *)(a.k + (size_t)m * N * b) : ug;
+    const size_t sK = pol ? nm * 8 : 0, sx = pol ? (size_t)n * 8 : 0, sk = pol ? (size_t)m * 8 : 0;
     char *xo = (char *)(a.xnew + (size_t)n * N * ((size_t)b + (size_t)B * ai));
     char *uo = (char *)(a.unew + (size_t)m * N * ((size_t)b + (size_t)B * ai));
     const char *Ab = (const char *)(a.A + (a.dyn_batched ? nn * (a.dyn_tv ? N : 1) * b : 0));
@@ -385,8 +389,8 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_mid_kernel(FBArgs a)
 #pragma unroll
     for (int c = 0; c < CB; ++c) { const int q = h * CB + c; offB[c] = 8u * (unsigned)(jc + n * (q < m ? q : m - 1)); }
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) { const int l = gp + 8 * q; offK[q] = 8u * (unsigned)(ac + m * (l < n ? l : n - 1)); }
-    const unsigned offx = 8u * (unsigned)jc, offu = 8u * (unsigned)ac;
+    for (int q = 0; q < KQ; ++q) { const int l = gp + 8 * q; offK[q] = pol ? 8u * (unsigned)(ac + m * (l < n ? l : n - 1)) : 0u; }
+    const unsigned offx = 8u * (unsigned)jc, offu = 8u * (unsigned)ac, offxp = pol ? offx : 0u, offkp = pol ? offu : 0u;
     const int ifl = N >= 2 ? N - 2 : 0;                               // the last step whose A_i, B_i are used (and certainly exist)
 
     auto fetch = [&](int i, FMBuf<CA> &f) {
@@ -396,13 +400,11 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_mid_kernel(FBArgs a)
         for (int c = 0; c < CA; ++c) f.fa[c] = *(const double *)(Ai + offA[c]);
 #pragma unroll
         for (int c = 0; c < CB; ++c) f.fb[c] = *(const double *)(Bi + offB[c]);
-        if (pol) {
-            const char *Ki = Kg + nm * 8 * i;
+        const char *Ki = Kg + sK * i;
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) f.kq[q] = *(const double *)(Ki + offK[q]);
-            f.xo = *(const double *)(xg + (size_t)n * 8 * i + offx);
-            f.ko = *(const double *)(kg + (size_t)m * 8 * i + offu);
-        }
+        for (int q = 0; q < KQ; ++q) f.kq[q] = *(const double *)(Ki + offK[q]);
+        f.xo = *(const double *)(xg + sx * i + offxp);
+        f.ko = *(const double *)(kg + sk * i + offkp);
         f.uo = *(const double *)(ug + (size_t)m * 8 * i + offu);
     };
     if (lane < NP) { xs[lane] = 0.0; dxs[lane] = 0.0; }
