@@ -489,35 +489,50 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_mid_kernel(FBArgs a)
 }
 
 // cost of those rollouts (LQ family, full Q and R; demo_linear.jl:49 split per step): one wave per (rollout, 64 time steps), lane =
-// time step; the x̂ and u of the 64 steps arrive by coalesced loads into LDS tiles with odd row pitches, Q and R are broadcast reads.
-// Sums in cost_rt_kernel's order (bit-identical to it); the sum over time is cost_sum_kernel's.
+// time step; the x̂ and u of the 64 steps arrive by coalesced loads into LDS tiles with odd row pitches; the lane's x̂ sits in NPC >= n
+// registers (zeros past n), Q' zero-padded to NPC x NPC in the LDS so that a row of it is NPC / 2 16-byte broadcast reads — with
+// run-time loop bounds the kernel spent two LDS reads and a loop iteration per product (0.11 ms at n = 24, N = 300, B = 1 024).
+// Sums in cost_rt_kernel's order (the padding adds zeros); the sum over time is cost_sum_kernel's.
+template <int NPC>
 __global__ __launch_bounds__(DDP_WAVE) void cost_mid_kernel(FBArgs a)
 {
-    constexpr int TB = DDP_WAVE;
+    constexpr int TB = DDP_WAVE, PX = NPC + 1;
     const int n = a.n, m = a.m, N = a.N, B = a.B;
     const long rho = blockIdx.x;
     const int b = (int)(rho % B), t0 = blockIdx.y * TB;
     if (a.active && a.active[b] == 0) return;
     const int lane = threadIdx.x;
-    const int nt = min(TB, N - t0), pn = n | 1, pm = m | 1;
-    __shared__ double xt[TB * 33], ut[TB * 9], qr[32 * 32 + 8 * 8];
+    const int nt = min(TB, N - t0), pm = m | 1;
+    __shared__ __attribute__((aligned(16))) double qt[NPC * NPC], xt[TB * PX], ut[TB * 9], rr[8 * 8];
     const double *x = a.xnew + (size_t)n * N * rho + (size_t)n * t0, *u = a.unew + (size_t)m * N * rho + (size_t)m * t0;
-    for (int e = lane; e < n * nt; e += DDP_WAVE) xt[(e / n) * pn + e % n] = x[e];
+    for (int e = lane; e < TB * PX; e += DDP_WAVE) xt[e] = 0.0;
+    for (int e = lane; e < NPC * NPC; e += DDP_WAVE) { const int jj = e % NPC, i = e / NPC; qt[e] = (i < n && jj < n) ? a.Q[i + n * jj] : 0.0; }   // qt[jj + NPC i] = Q[i, jj]
+    for (int e = lane; e < m * m; e += DDP_WAVE) rr[e] = a.R[e];
+    wave_sync();
+    for (int e = lane; e < n * nt; e += DDP_WAVE) xt[(e / n) * PX + e % n] = x[e];
     for (int e = lane; e < m * nt; e += DDP_WAVE) ut[(e / m) * pm + e % m] = u[e];
-    for (int e = lane; e < n * n; e += DDP_WAVE) qr[e] = a.Q[e];
-    for (int e = lane; e < m * m; e += DDP_WAVE) qr[n * n + e] = a.R[e];
     wave_sync();
     if (lane >= nt) return;
-    const double *Q = qr, *R = qr + n * n, *xl = xt + lane * pn, *ul = ut + lane * pm;
+    double xr[NPC];
+#pragma unroll
+    for (int jj = 0; jj < NPC; ++jj) xr[jj] = xt[lane * PX + jj];
     double qx = 0.0, ru = 0.0;
-    for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
         double s = 0.0;
-        for (int jj = 0; jj < n; ++jj) s += Q[i + n * jj] * xl[jj];
-        qx += xl[i] * s;
+#pragma unroll
+        for (int jj = 0; jj < NPC; jj += 2) {
+            const d2 q2 = *(const d2 *)(qt + NPC * i + jj);
+            s += q2.x * xr[jj];
+            s += q2.y * xr[jj + 1];
+        }
+        qx += xr[i] * s;
+        asm volatile("" : "+v"(qx) :: "memory");                   // (row by row: with every read of Q' hoisted to the front a few hundred registers spilled)
     }
+    const double *ul = ut + lane * pm;
     for (int i = 0; i < m; ++i) {
         double s = 0.0;
-        for (int jj = 0; jj < m; ++jj) s += R[i + m * jj] * ul[jj];
+        for (int jj = 0; jj < m; ++jj) s += rr[i + m * jj] * ul[jj];
         ru += ul[i] * s;
     }
     a.cnew[(size_t)N * rho + t0 + lane] = 0.5 * qx + 0.5 * ru;
@@ -562,7 +577,10 @@ int ddp_launch_forward_big(ddp_handle h, const ddp_problem *p, const double *K, 
         if (p->n <= 16) hipLaunchKernelGGL((forward_mid_kernel<8>), grid, block, 0, h->stream, a);
         else if (p->n <= 24) hipLaunchKernelGGL((forward_mid_kernel<12>), grid, block, 0, h->stream, a);
         else hipLaunchKernelGGL((forward_mid_kernel<16>), grid, block, 0, h->stream, a);
-        hipLaunchKernelGGL(cost_mid_kernel, dim3(grid.x, (unsigned)((p->N + DDP_WAVE - 1) / DDP_WAVE)), block, 0, h->stream, a);
+        const dim3 cgrid(grid.x, (unsigned)((p->N + DDP_WAVE - 1) / DDP_WAVE));
+        if (p->n <= 16) hipLaunchKernelGGL((cost_mid_kernel<16>), cgrid, block, 0, h->stream, a);
+        else if (p->n <= 24) hipLaunchKernelGGL((cost_mid_kernel<24>), cgrid, block, 0, h->stream, a);
+        else hipLaunchKernelGGL((cost_mid_kernel<32>), cgrid, block, 0, h->stream, a);
         hipLaunchKernelGGL(cost_sum_kernel, grid, block, 0, h->stream, a);
         DDP_HIP(hipGetLastError());
         h->last_kernel[1] = "forward_mid_kernel";

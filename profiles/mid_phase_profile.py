@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddp_amd as ddp
 
 names = ["F -> LDS", "W = Vxx F", "G = F'W + cost", "gains", "K, Y, Vx", "K'Y product", "sym -> image", "loop head", "(G: products", "epilogue", "Vxx store", "= G total incl. load batch + sync)"]
-for n, m, lims in [(24, 4, False), (16, 2, False), (24, 4, True), (32, 8, False)]:
+for n, m, lims in [(24, 4, False), (16, 2, False), (24, 4, True), (32, 8, False), (24, 8, False), (20, 6, True)]:
     N, B = 300, 1024
     rng = np.random.default_rng(1)
     fx = np.ascontiguousarray(np.eye(n)[:, :, None, None] * 0.98 + 0.02 * rng.standard_normal((n, n, N, B)))
