@@ -714,6 +714,8 @@ int ddp_launch_back_pass_dppw(ddp_handle h, const ddp_bp_desc *d, const double *
                               const double *fu, const double *lambda, const int32_t *active, double *K,
                               double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
 
+constexpr int MXG_LIMS_MAX_B = 2048;             // (measured cross-over with the row kernels: profiles/r05_lims_sweep.sh)
+
 static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                          const double *cxx, const double *cxu, const double *cuu, const double *fx,
                          const double *fu, const double *lambda, const double *lims, const double *u,
@@ -753,6 +755,13 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         const int rw = ddp_launch_back_pass_dppw(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rw <= 0) { h->last_kernel[0] = "back_pass_dppw_kernel"; return rw; }
     }
+    // control limits at small and medium batches (any n <= 12, m <= 4): one WAVE per trajectory with the box-QP as a wave-uniform solve
+    // (back_pass_mxg.hip) instead of 16 lanes per trajectory with a divergent one — at B = 1 024 the row kernels leave three quarters of
+    // the SIMDs without a wave (n=10, m=2, N=1000 with limits: 2.8 ms there; profiles/r05_lims_sweep.sh)
+    if (d->has_lims && (force == 'w' || (force == 0 && d->B <= MXG_LIMS_MAX_B))) {
+        const int rc = ddp_launch_back_pass_mxg(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mxg_kernel"; return rc; }
+    }
     if (force != 'g' && force != 'b' && force != 'r' && force != 't' && force != 'w') {
         const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_dpp_kernel"; return rc; }
@@ -767,7 +776,7 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
     // the same for n <= 12, m <= 4 (back_pass_mxg.hip; profiles/r05_wtile_vs_row.txt: ahead of the row kernel up to B = 4096 — 0.83 vs 1.16 ms at
     // n=12, m=3, N=500, B=2048; 1.15 vs 1.55 at n=8, m=4, B=4096 — level with it there for n <= 4)
     if (force == 'w' || (force == 0 && (d->B <= 3072 || (d->B <= 4096 && d->n >= 5)))) {
-        const int rc = ddp_launch_back_pass_mxg(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        const int rc = ddp_launch_back_pass_mxg(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mxg_kernel"; return rc; }
     }
     if (force == 0 || force == 'r') {                             // every other shape a 16-lane row holds: the row kernel compiled for padded sizes

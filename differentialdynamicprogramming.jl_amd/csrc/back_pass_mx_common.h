@@ -14,6 +14,7 @@ struct BPXArgs {
     const int32_t *active;
     double *K, *k, *Quu, *Vx, *Vxx, *dV;
     int32_t *diverge;
+    const double *lims, *u;                         // control limits (back_pass_mxg_kernel<..., LIMS = true> only)
 };
 
 __device__ const double mx_zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

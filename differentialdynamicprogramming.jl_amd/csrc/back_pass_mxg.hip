@@ -17,6 +17,7 @@
 // share exec-mask switches, and what a 64-cycle matrix instruction can replace of > 11 vector instructions goes to the matrix pipe).
 // Measured against the 16-lane-row kernel it replaces for small and medium batches: DESIGN.md §3.2.
 #include "ddp_internal.h"
+#include "boxqp_dev.h"
 
 namespace {
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ void store_results(char *vst, const double (&S)[KS], 
                      ::"v"(vst), "v"(S[0]), "v"(S[1]), "v"(S[2]), "s"(full), "s"(last), "v"(kq), "v"(kv), "s"(lanesK) : "memory");
 }
 
-template <int NP, bool FXTV, bool CTV, bool REG2, bool COAL>
+template <int NP, bool FXTV, bool CTV, bool REG2, bool COAL, bool LIMS = false>
 __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
 {
     constexpr int KS = NP / 4, UR = NP / 4, MS = NP == 12 ? 3 : 4;
@@ -298,6 +299,21 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     wave_sync();
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): all set-up loads have landed
 
+    // ---- control limits (backward_pass.jl:43-62): the box-QP on the MS x MS system — the same solve on the same (LDS-broadcast) data in every
+    // lane, so its branches are wave-uniform (boxqp_dev.h); controls past m: gradient 1 on [0, 0], clamped in every iteration.  u_i comes
+    // by scalar loads a step ahead.
+    bool nolims = true;
+    double limlo[MS], limhi[MS], ucur[MS], kprev[MS];
+#pragma unroll
+    for (int c2 = 0; c2 < MS; ++c2) { limlo[c2] = 0.0; limhi[c2] = 0.0; ucur[c2] = 0.0; kprev[c2] = 0.0; }
+    const double *ug = LIMS ? a.u + (size_t)mr * N * b : nullptr;
+    if constexpr (LIMS) {
+        nolims = a.lims[0] > a.lims[mr];                    // backward_pass.jl:31
+#pragma unroll
+        for (int c2 = 0; c2 < MS; ++c2)
+            if (c2 < mr) { limlo[c2] = a.lims[c2]; limhi[c2] = a.lims[c2 + mr]; ucur[c2] = ug[(size_t)mr * i0 + c2]; }
+    }
+    const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};       // boxQP.jl:30-35
     double dVa = 0.0, dVp = 0.0;                    // Σ k'Qu (lanes of column VG) and the per-row parts of Σ k'(Quu k + Qu)
     int diverge = 0;
     auto reg = [](const d4 &v, int r) __attribute__((always_inline)) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
 #pragma unroll
         for (int s = 1; s < KS; ++s) g = __builtin_amdgcn_mfma_f64_16x16x4f64(F[s], W[s], g, 0, 0, 0);
         // lane (a, col): G[control a][col] = Qux | Quu | Qu  (through the vector ALU where a row broadcast reads it: regType 2)
-        const double Z = REG2 ? reg(g, UR) + 0.0 : reg(g, UR);
+        const double Z = (REG2 || LIMS) ? reg(g, UR) + 0.0 : reg(g, UR);
         zl[0][lane] = Z;
         if (REG2) {                                        // control rows of F'(W + λF) + H: Qux_reg, QuuF (:205-207)
             d4 gr = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], fma(lam, F[0], W[0]), c, 0, 0, 0);
@@ -359,15 +375,54 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
         double Qu[MS];                                     // unregularised rows at my column (dV; column VG: Qu)
 #pragma unroll
         for (int c2 = 0; c2 < MS; ++c2) Qu[c2] = REG2 ? zl[0][16 * c2 + l15] : q[c2];
-        const int fail = ddp_chol_rinv<MS>(Hq, R, ri);
-        ddp_rsolve_neg<MS>(R, ri, q);                      // q <- -(QuuF)\q: K[:, col] (:42), column VG: k_i (:41)
+        int fail;
+        if (!LIMS || nolims) {
+            fail = ddp_chol_rinv<MS>(Hq, R, ri);
+            ddp_rsolve_neg<MS>(R, ri, q);                  // q <- -(QuuF)\q: K[:, col] (:42), column VG: k_i (:41)
+        } else {
+            double Hf[MS * MS], gq[MS], lo[MS], up[MS], kk[MS];
+#pragma unroll
+            for (int c2 = 0; c2 < MS; ++c2) {
+#pragma unroll
+                for (int c1 = 0; c1 <= c2; ++c1) { Hf[c1 + MS * c2] = Hq[c1 + MS * c2]; Hf[c2 + MS * c1] = Hq[c1 + MS * c2]; }
+                gq[c2] = c2 < mr ? zl[0][16 * c2 + VG] : 1.0;                      // Qu (the gradient column of the unregularised rows)
+                lo[c2] = c2 < mr ? limlo[c2] - ucur[c2] : 0.0; up[c2] = c2 < mr ? limhi[c2] - ucur[c2] : 0.0;      // (:45-46)
+            }
+            unsigned clamped = 0u;
+            int iters, result;
+            if (mr <= 2) {                                 // (uniform) the usual sizes as a 2 x 2 problem: half the work of the padded MS x MS one
+                double H2[4] = {Hf[0], Hf[1], Hf[MS], Hf[1 + MS]}, g2[2] = {gq[0], gq[1]}, lo2[2] = {lo[0], lo[1]}, up2[2] = {up[0], up[1]},
+                       x02[2] = {kprev[0], kprev[1]}, k2[2], R2[4], ri2[2];
+                result = boxqp_dev_ri<2>(2, H2, g2, lo2, up2, x02, qpo, k2, R2, ri2, clamped, iters);          // (:49), warm start k[:, min(i+1, N-1)]
+#pragma unroll
+                for (int e = 0; e < MS * MS; ++e) R[e] = 0.0;
+#pragma unroll
+                for (int c2 = 0; c2 < MS; ++c2) { R[c2 + MS * c2] = 1.0; ri[c2] = 1.0; kk[c2] = 0.0; }
+                R[0] = R2[0]; R[MS] = R2[2]; R[1 + MS] = R2[3]; ri[0] = ri2[0]; ri[1] = ri2[1]; kk[0] = k2[0]; kk[1] = k2[1];
+                clamped |= ((1u << MS) - 1u) & ~3u;        // the controls past 2: clamped
+            } else {
+                result = boxqp_dev_ri<MS>(MS, Hf, gq, lo, up, kprev, qpo, kk, R, ri, clamped, iters);
+            }
+            fail = result < 1;                             // (:53)
+#pragma unroll
+            for (int c2 = 0; c2 < MS; ++c2) { kprev[c2] = kk[c2]; q[c2] = ((clamped >> c2) & 1u) ? 0.0 : q[c2]; }
+            chol_solve_ri<MS>(MS, R, ri, q);               // K[free, col] = -(R'R)\Qux_reg[free, col], clamped rows zero (:57-61)
+#pragma unroll
+            for (int c2 = 0; c2 < MS; ++c2) {
+                const double kq_ = ((clamped >> c2) & 1u) ? 0.0 : -q[c2];
+                q[c2] = l15 == VG ? kk[c2] : kq_;          // column VG: k_i from the QP (bounds included)
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < MS; ++c2)                // u_{i-1} for the next step (scalar loads: their latency is the rest of this step)
+                if (c2 < mr) ucur[c2] = ug[(size_t)mr * (i > 0 ? i - 1 : 0) + c2];
+        }
         double Ksel = q[0] * rowm[0];                      // K[a = l4, col]: a sum with lane constants 1 / 0, no selects
 #pragma unroll
         for (int c2 = 1; c2 < MS; ++c2) Ksel = fma(q[c2], rowm[c2], Ksel);
         // T_a = Quu[a,:]·K + Qux_a (:64) for my row a = l4
         double Tsel;
-        if (!REG2) {
-            Tsel = -lam * Ksel;                            // regType 1: (Quu + λI) K = -Qux
+        if (!REG2 && (!LIMS || nolims)) {
+            Tsel = -lam * Ksel;                            // regType 1: (Quu + λI) K = -Qux (not so for clamped rows or the k of a box-QP)
         } else {
             Tsel = Z;
             static_for<0, MS>([&](auto bc) __attribute__((always_inline)) {
@@ -482,6 +537,18 @@ int launch_mxg(ddp_handle h, const ddp_bp_desc *d, const BPXArgs &a)
 {
     const dim3 grid(d->B), block(DDP_WAVE);
     const int key = (d->fx_tv ? 2 : 0) | (d->cost_tv ? 1 : 0);
+    if constexpr (COAL) {
+        if (d->has_lims) {
+            switch (key) {
+            case 0: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, false, REG2, true, true>), grid, block, 0, h->stream, a); break;
+            case 1: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, true, REG2, true, true>), grid, block, 0, h->stream, a); break;
+            case 2: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, false, REG2, true, true>), grid, block, 0, h->stream, a); break;
+            case 3: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, true, true, REG2, true, true>), grid, block, 0, h->stream, a); break;
+            }
+            DDP_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     switch (key) {
     case 0: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, false, REG2, COAL>), grid, block, 0, h->stream, a); break;
     case 1: hipLaunchKernelGGL((back_pass_mxg_kernel<NP, false, true, REG2, COAL>), grid, block, 0, h->stream, a); break;
@@ -497,19 +564,21 @@ int launch_mxg(ddp_handle h, const ddp_bp_desc *d, const BPXArgs &a)
 // returns 1 if this shape is not handled here, 0 launched, <0 error
 int ddp_launch_back_pass_mxg(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
-                             const double *fu, const double *lambda, const int32_t *active, double *K,
+                             const double *fu, const double *lambda, const double *lims, const double *u, const int32_t *active, double *K,
                              double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge)
 {
-    if (d->has_lims || d->m > 4 || d->n > 12 || d->n + d->m > 15) return 1;
+    if (d->m > 4 || d->n > 12 || d->n + d->m > 15) return 1;
+    if (d->has_lims && !(lims && u)) return 1;
     const int np = d->n <= 4 ? 4 : (d->n <= 8 ? 8 : 12);
     if (np == 12 && d->m > 3) return 1;
     BPXArgs a;
     a.N = d->N; a.B = d->B; a.fx_batched = d->fx_batched; a.cost_batched = d->cost_batched; a.n = d->n; a.m = d->m;
     a.cx = cx; a.cu = cu; a.cxx = cxx; a.cxu = cxu; a.cuu = cuu; a.fx = fx; a.fu = fu; a.lambda = lambda; a.active = active;
-    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge;
+    a.K = K; a.k = k; a.Quu = Quu; a.Vx = Vx; a.Vxx = Vxx; a.dV = dV; a.diverge = diverge; a.lims = lims; a.u = u;
     const bool r2 = d->regType == 2;
     const char *ce = ddp_env(h, ENV_MXG_COAL);                  // 0: one 8-byte element per lane straight from / to global memory (A/B, tests)
     if (ce && ce[0] == '0') {
+        if (d->has_lims) return 1;                                // (limits: the piece-wise path only)
         switch (np) {
         case 4: return r2 ? launch_mxg<4, true, false>(h, d, a) : launch_mxg<4, false, false>(h, d, a);
         case 8: return r2 ? launch_mxg<8, true, false>(h, d, a) : launch_mxg<8, false, false>(h, d, a);

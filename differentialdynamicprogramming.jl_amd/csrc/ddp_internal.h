@@ -112,10 +112,10 @@ int ddp_launch_back_pass_mxr(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const double *fu, const double *lambda, const int32_t *active, double *K,
                              double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
 
-// back_pass_mxg.hip: the tile kernel for any n <= 12, m <= 4 (m <= 3 above n = 8) without limits; 1 = not applicable
+// back_pass_mxg.hip: the tile kernel for any n <= 12, m <= 4 (m <= 3 above n = 8), with or without limits; 1 = not applicable
 int ddp_launch_back_pass_mxg(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                              const double *cxx, const double *cxu, const double *cuu, const double *fx,
-                             const double *fu, const double *lambda, const int32_t *active, double *K,
+                             const double *fu, const double *lambda, const double *lims, const double *u, const int32_t *active, double *K,
                              double *k, double *Quu, double *Vx, double *Vxx, double *dV, int32_t *diverge);
 
 // the same tile arithmetic with a chain wave + a write-back wave per trajectory (back_pass_mx2.hip); 1 = not applicable

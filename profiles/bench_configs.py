@@ -348,5 +348,8 @@ if __name__ == "__main__":
                   int(os.environ.get("DDP_OFFC_B", 1024)), os.environ.get("DDP_OFFC_LTI") != "1", False)
     if "offD" in which:                                          # the 8 x 8 control system (4 < m <= 8): one coordinate per lane, gains on the matrix cores
         off_shape("offD", 32, 8, 300, 1024, True, False)
+    if "offX" in which:                                          # any shape from the environment (experiments): DDP_OFFX="n m N B ltv lims"
+        n_, m_, N_, B_, ltv_, lims_ = (int(v) for v in os.environ.get("DDP_OFFX", "10 2 1000 1024 0 1").split())
+        off_shape("offX", n_, m_, N_, B_, bool(ltv_), bool(lims_))
     if "offB" in which:
         off_shape("offB", 6, 2, 1000, 4096, False, os.environ.get("DDP_OFF_NOLIMS") != "1")

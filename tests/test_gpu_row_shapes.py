@@ -77,11 +77,11 @@ def _check(ddp, out, args, lam, regType, L, batched, who=None):
 
 
 def _default_kernel(n, m, lims):
-    """what the dispatcher picks for a small batch of a shape without an exact instantiation: without limits the fp64 tile kernels
-    (run-time sizes inside the (10, 2) tile for m <= 2; one tile for n <= 12, m <= 4), with limits the row kernel"""
+    """what the dispatcher picks for a small batch of a shape without an exact instantiation: the fp64 tile kernels (run-time sizes inside
+    the (10, 2) tile for m <= 2 without limits; one tile for n <= 12, m <= 4, with or without limits), else the row kernel"""
     if lims is None and n <= 10 and m <= 2:
         return "back_pass_mx_kernel<RT>"
-    if lims is None and n <= 12 and m <= (4 if n <= 8 else 3):
+    if n <= 12 and m <= (4 if n <= 8 else 3) and n + m <= 15:          # with limits too (small batches): the box-QP as a wave-uniform solve
         return "back_pass_mxg_kernel"
     return "back_pass_row_kernel"
 
@@ -115,7 +115,8 @@ def test_row_kernel_every_shape_vs_oracle(ddp, n, m, kind):
 
 @pytest.mark.parametrize("n,m", [(3, 1), (5, 2), (6, 3), (9, 2), (12, 3), (13, 1)])
 def test_row_kernel_is_the_default_dispatch(ddp, n, m):
-    """no switch set: these shapes must land on the row kernel, and agree with the general kernel far below the oracle tolerance"""
+    """no switch set, control limits: up to n = 12 the wide tile kernel takes a small batch (the box-QP as a wave-uniform solve), the row
+    kernel the rest; both agree with the general kernel far below the oracle tolerance"""
     from ddp_amd import _lib
     rng = np.random.default_rng(7 * n + m)
     N, B = 40, 9
@@ -123,7 +124,11 @@ def test_row_kernel_is_the_default_dispatch(ddp, n, m):
     cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
     L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
     out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, L, x, u)
-    assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+    assert _lib.default_handle().last_kernel(0) == _default_kernel(n, m, L)
+    row, name = _run(ddp, args, 0.3, 1, L, "row")
+    assert name == "back_pass_row_kernel"
+    for a_, b_ in ((out[1].K, row[1].K), (out[1].k, row[1].k), (out[2], row[2]), (out[3], row[3]), (out[4], row[4])):
+        assert relerr(a_, b_) < 1e-10
     ref, name = _run(ddp, args, 0.3, 1, L, "general")
     assert name == "back_pass_kernel"
     assert np.array_equal(out[0], ref[0])

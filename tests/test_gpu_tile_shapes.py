@@ -48,10 +48,10 @@ def test_tile_kernel_is_the_default_dispatch_without_limits(ddp, n, m):
     assert np.array_equal(out[0], ref[0])
     for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4]), (out[1].Σi, ref[1].Σi)):
         assert relerr(a_, b_) < 1e-10
-    # with limits the shape stays on the row kernel
+    # with limits a small batch goes to the wide tile kernel (the box-QP as a wave-uniform solve), DDP_BACKPASS=row keeps the row kernel
     L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
     ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, L, x, u)
-    assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+    assert _lib.default_handle().last_kernel(0) == "back_pass_mxg_kernel"
 
 
 def test_tile_kernel_at_the_exact_shape_agrees_with_the_exact_kernel(ddp):
@@ -144,7 +144,9 @@ def test_wide_tile_kernel_is_the_default_dispatch_without_limits(ddp, n, m):
         assert relerr(a_, b_) < 1e-10
     L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1)
     ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.3, 1, L, x, u)
-    assert _lib.default_handle().last_kernel(0) == "back_pass_row_kernel"
+    assert _lib.default_handle().last_kernel(0) == "back_pass_mxg_kernel"
+    _, name = _run(ddp, args, 0.3, 1, L, "row")
+    assert name == "back_pass_row_kernel"
 
 
 def test_wide_tile_kernel_agrees_with_the_exact_tile_kernel(ddp):
@@ -210,3 +212,66 @@ def test_wide_tile_kernel_coalesced_io_is_bit_identical_to_the_element_per_lane_
             assert np.array_equal(out[0], ref[0])
             for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4]), (out[1].Σi, ref[1].Σi)):
                 assert np.array_equal(a_, b_)
+
+
+# ------------------------------------------------------------------------------------------------- control limits on the wide tile kernel
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (3, 1), (4, 4), (5, 2), (6, 2), (6, 3), (7, 4), (8, 4), (9, 2), (10, 2), (11, 3), (12, 3), (12, 1)])
+@pytest.mark.parametrize("kind", ["lti", "ltv", "tv"])
+def test_wide_tile_kernel_with_limits_vs_oracle(ddp, n, m, kind):
+    """backward_pass.jl:43-62 on back_pass_mxg.hip: the box-QP runs as ONE wave-uniform solve per trajectory (boxqp_dev.h on LDS-broadcast
+    data), clamped rows of K are zero, k comes from the QP; tight bounds (most controls clamped), loose bounds (none), both regularisations,
+    the default dispatch of a small batch — every trajectory against the C oracle"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(5000 * n + 10 * m + len(kind))
+    N, B = 27, 6
+    args = _problem(rng, n, m, N, B, kind)
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    lam = 10.0 ** rng.uniform(-3, 0.5, B)
+    for regType, width in ((1, 0.05), (2, 0.3), (1, 50.0)):
+        L = np.stack([-width * np.ones(m), 1.2 * width * np.ones(m)], 1)
+        out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, L, x, u)
+        assert _lib.default_handle().last_kernel(0) == "back_pass_mxg_kernel"
+        _check(ddp, out, args, lam, regType, L, False)
+
+
+@pytest.mark.parametrize("n,m", [(6, 2), (10, 2), (12, 3)])
+def test_wide_tile_kernel_with_limits_inactive_divergence_inverted_bounds(ddp, n, m):
+    """per-trajectory operands, an inactive trajectory, λ < 0 (no positive pivot: diverge at the first step, :54-55), inverted bounds
+    (lims[1,1] > lims[1,2]: the Cholesky branch, :31) — against the oracle and the row kernel"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(77 * n + m)
+    N, B = 19, 7
+    args = _problem(rng, n, m, N, B, "btv")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    lam = np.full(B, 0.2); lam[[2, 5]] = -50.0
+    L = np.stack([-0.2 * np.ones(m), 0.25 * np.ones(m)], 1)
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, 1, L, x, u)
+    assert _lib.default_handle().last_kernel(0) == "back_pass_mxg_kernel"
+    assert out[0][2] == N - 1 and out[0][5] == N - 1 and out[0][0] == 0
+    _check(ddp, out, args, lam, 1, L, True)
+    Li = np.stack([0.3 * np.ones(m), -0.3 * np.ones(m)], 1)
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, np.abs(lam), 1, Li, x, u)
+    assert _lib.default_handle().last_kernel(0) == "back_pass_mxg_kernel"
+    ref, name = _run(ddp, args, np.abs(lam), 1, Li, "row")
+    assert name == "back_pass_row_kernel"
+    for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4])):
+        assert relerr(a_, b_) < 1e-10
+
+
+def test_wide_tile_kernel_with_limits_full_size_c2(ddp):
+    """the C2 shape (n=10, m=2, N=1000, B=1024) with control limits ±0.05 on the default dispatch: a sample of trajectories against the
+    oracle, the rest against the row kernel"""
+    from ddp_amd import _lib
+    rng = np.random.default_rng(99)
+    n, m, N, B = 10, 2, 1000, 1024
+    args = _problem(rng, n, m, N, B, "lti")
+    cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
+    L = 0.05 * np.stack([-np.ones(m), np.ones(m)], 1)
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.1, 1, L, x, u)
+    assert _lib.default_handle().last_kernel(0) == "back_pass_mxg_kernel"
+    _check(ddp, out, args, 0.1, 1, L, False, who=[0, 1, 511, 1023])
+    ref, name = _run(ddp, args, 0.1, 1, L, "row")
+    assert name in ("back_pass_row_kernel", "back_pass_dpp_kernel")
+    assert np.array_equal(out[0], ref[0])
+    for a_, b_ in ((out[1].K, ref[1].K), (out[1].k, ref[1].k), (out[2], ref[2]), (out[3], ref[3]), (out[4], ref[4])):
+        assert relerr(a_, b_) < 1e-9
