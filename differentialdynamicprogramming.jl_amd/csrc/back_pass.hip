@@ -775,7 +775,7 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
     }
     // the same for n <= 12, m <= 4 (back_pass_mxg.hip; profiles/r05_wtile_vs_row.txt: ahead of the row kernel up to B = 4096 — 0.83 vs 1.16 ms at
     // n=12, m=3, N=500, B=2048; 1.15 vs 1.55 at n=8, m=4, B=4096 — level with it there for n <= 4)
-    if (force == 'w' || (force == 0 && (d->B <= 3072 || (d->B <= 4096 && d->n >= 5)))) {
+    if (force == 'w' || (force == 0 && !d->has_lims && (d->B <= 3072 || (d->B <= 4096 && d->n >= 5)))) {      // (with limits: the block above, up to MXG_LIMS_MAX_B)
         const int rc = ddp_launch_back_pass_mxg(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mxg_kernel"; return rc; }
     }

@@ -76,12 +76,12 @@ def _check(ddp, out, args, lam, regType, L, batched, who=None):
             assert not pol.K[:, :, : d - 1, b].any() and not Vxx[:, :, : d - 1, b].any() and not Vx[:, : d - 1, b].any()
 
 
-def _default_kernel(n, m, lims):
+def _default_kernel(n, m, lims, B=1):
     """what the dispatcher picks for a small batch of a shape without an exact instantiation: the fp64 tile kernels (run-time sizes inside
     the (10, 2) tile for m <= 2 without limits; one tile for n <= 12, m <= 4, with or without limits), else the row kernel"""
     if lims is None and n <= 10 and m <= 2:
         return "back_pass_mx_kernel<RT>"
-    if n <= 12 and m <= (4 if n <= 8 else 3) and n + m <= 15:          # with limits too (small batches): the box-QP as a wave-uniform solve
+    if n <= 12 and m <= (4 if n <= 8 else 3) and n + m <= 15 and (lims is None or B <= 2048):   # with limits up to B = 2 048: the box-QP as a wave-uniform solve
         return "back_pass_mxg_kernel"
     return "back_pass_row_kernel"
 
@@ -164,7 +164,7 @@ def test_row_kernel_full_size_off_shapes(ddp):
         cx, cu, cxx, cxu, cuu, fx, fu, x, u = args
         L = np.stack([-0.3 * np.ones(m), 0.3 * np.ones(m)], 1) if lims else None
         out = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, 0.1, 1, L, x, u)
-        assert _lib.default_handle().last_kernel(0) == _default_kernel(n, m, L)
+        assert _lib.default_handle().last_kernel(0) == _default_kernel(n, m, L, B)
         who = sorted({0, 1, 2, 3, B - 1, B - 2} | set(int(v) for v in rng.integers(0, B, 18)))
         _check(ddp, out, args, 0.1, 1, L, False, who=who)
         if not lims:
