@@ -758,7 +758,10 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
     // control limits at small and medium batches (any n <= 12, m <= 4): one WAVE per trajectory with the box-QP as a wave-uniform solve
     // (back_pass_mxg.hip) instead of 16 lanes per trajectory with a divergent one — at B = 1 024 the row kernels leave three quarters of
     // the SIMDs without a wave (n=10, m=2, N=1000 with limits: 2.8 ms there; profiles/r05_lims_sweep.sh)
-    if (d->has_lims && (force == 'w' || (force == 0 && d->B <= MXG_LIMS_MAX_B))) {
+    // (measured cross-over, profiles/r05_lims_threshold.txt: a wave-uniform QP is bound by its own latency, so the time doubles with a
+    // second wave on a SIMD; the row kernels hold their time up to B = 4 096 — n=6, m=2: 1.53 vs 2.31 ms at B = 1 024, 3.0 vs 2.45 at 1 536)
+    const int mxg_lims_max = d->m == 1 ? 512 : ((d->n > 8 || d->m >= 3 || d->n <= 4) ? MXG_LIMS_MAX_B : 1024);   // (m = 1: the row kernels' straight-line QP — 0.73 vs 0.81 ms at n=3, B = 1 024)
+    if (d->has_lims && (force == 'w' || (force == 0 && d->B <= mxg_lims_max))) {
         const int rc = ddp_launch_back_pass_mxg(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mxg_kernel"; return rc; }
     }

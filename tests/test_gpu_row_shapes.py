@@ -81,7 +81,8 @@ def _default_kernel(n, m, lims, B=1):
     the (10, 2) tile for m <= 2 without limits; one tile for n <= 12, m <= 4, with or without limits), else the row kernel"""
     if lims is None and n <= 10 and m <= 2:
         return "back_pass_mx_kernel<RT>"
-    if n <= 12 and m <= (4 if n <= 8 else 3) and n + m <= 15 and (lims is None or B <= 2048):   # with limits up to B = 2 048: the box-QP as a wave-uniform solve
+    wide_lims = 512 if m == 1 else (2048 if (n > 8 or m >= 3 or n <= 4) else 1024)   # (back_pass.hip: measured cross-over with the row kernels)
+    if n <= 12 and m <= (4 if n <= 8 else 3) and n + m <= 15 and (lims is None or B <= wide_lims):   # with limits: the box-QP as a wave-uniform solve
         return "back_pass_mxg_kernel"
     return "back_pass_row_kernel"
 
