@@ -26,7 +26,7 @@ for src, dst in pairs:
         print("MISSING", src)
 tf = os.path.join(P, "pmc_traffic.json")
 cur = json.load(open(tf)) if os.path.exists(tf) else {}
-for src in ["%s/profiles/pmc_traffic.json" % tag] + ["%s_%s/pmc_traffic_update.json" % (tag, c) for c in ("c3", "c2tv", "c4", "c5", "offA", "offB", "offC")]:
+for src in ["%s/profiles/pmc_traffic.json" % tag] + ["%s_%s/pmc_traffic_update.json" % (tag, c) for c in ("c3", "c2tv", "c4", "c5", "offA", "offB", "offC", "offD", "offL")]:
     s = os.path.join(G, src)
     if os.path.exists(s):
         cur.update(json.load(open(s)))
