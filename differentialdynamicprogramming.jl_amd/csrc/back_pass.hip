@@ -650,12 +650,21 @@ __global__ __launch_bounds__(256) void unpad2d_kernel(const double *src, double 
 }
 }   // namespace
 
+// the embedded problem's work space in bytes (operands and results at the padded sizes)
+static size_t padded_bytes(const ddp_bp_desc *d, int np_, int mp)
+{
+    const size_t N = d->N, B = d->B, cf = (d->fx_tv ? N : 1) * (d->fx_batched ? B : 1), cc = (d->cost_tv ? N : 1) * (d->cost_batched ? B : 1), NB = N * B;
+    return 8 * ((size_t)np_ * NB * 2 + (size_t)mp * NB * 3 + ((size_t)np_ * np_ + (size_t)np_ * mp + (size_t)mp * mp) * cc + ((size_t)np_ * np_ + (size_t)np_ * mp) * cf +
+                ((size_t)mp * np_ + (size_t)mp * mp + (size_t)np_ * np_) * NB) + 16 * 256;
+}
+
+// (np_, mp): the sizes the problem is embedded in — the next even ones for back_pass_big_kernel, or (64, 8) for the matrix-core kernel
 static int launch_back_pass_padded(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu, const double *cxx, const double *cxu,
                                    const double *cuu, const double *fx, const double *fu, const double *lambda, const double *lims,
                                    const double *u, const int32_t *active, double *K, double *k, double *Quu, double *Vx, double *Vxx,
-                                   double *dV, int32_t *diverge)
+                                   double *dV, int32_t *diverge, int np_, int mp, bool to_mfma)
 {
-    const int n = d->n, m = d->m, np_ = n + (n & 1), mp = m + (m & 1);
+    const int n = d->n, m = d->m;
     const long N = d->N, B = d->B;
     const long cf = (d->fx_tv ? N : 1) * (d->fx_batched ? B : 1), cc = (d->cost_tv ? N : 1) * (d->cost_batched ? B : 1), NB = N * B;
     auto al = [](size_t b_) { return (b_ + 255) & ~(size_t)255; };
@@ -695,8 +704,10 @@ static int launch_back_pass_padded(ddp_handle h, const ddp_bp_desc *d, const dou
     }
     ddp_bp_desc dp = *d;
     dp.n = np_; dp.m = mp;
-    const int rc = ddp_launch_back_pass_big(h, &dp, pcx, pcu, pcxx, pcxu, pcuu, pfx, pfu, lambda, lims ? pl : nullptr, u ? pu : nullptr, active,
-                                            pK, pk, pQuu, pVx, pVxx, dV, diverge);
+    const int rc = to_mfma ? ddp_launch_back_pass_mfma(h, &dp, pcx, pcu, pcxx, pcxu, pcuu, pfx, pfu, lambda, lims ? pl : nullptr, u ? pu : nullptr, active,
+                                                       pK, pk, pQuu, pVx, pVxx, dV, diverge)
+                           : ddp_launch_back_pass_big(h, &dp, pcx, pcu, pcxx, pcxu, pcuu, pfx, pfu, lambda, lims ? pl : nullptr, u ? pu : nullptr, active,
+                                                      pK, pk, pQuu, pVx, pVxx, dV, diverge);
     if (rc) return rc < 0 ? rc : -1;
     auto unpad = [&](const double *src, double *dst, int r, int c, int rp, int cp) {
         const long tot = (long)r * c * NB;
@@ -805,12 +816,19 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         const int rc = ddp_launch_back_pass_mfma(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mfma_kernel"; return rc; }
     }
+    // 32 < n < 64 (or n = 64 with m < 8): embedded in the (64, 8) problem of the matrix-core kernel — zero rows / columns of the
+    // Jacobians and cost terms, an identity block of cuu, controls free inside [-1, 1] — while the padded copies fit in 48 GB.  The
+    // 256-thread vector kernel below takes 27-36 ms at N = 300, B = 1 024 there (n = 33 was 9x slower than n = 32, 4x slower than n = 64).
+    if (force == 0 && d->n > DDP_MAX_N_GENERIC && d->n <= 64 && d->m <= 8 && padded_bytes(d, 64, 8) <= ((size_t)48 << 30)) {
+        const int rc = launch_back_pass_padded(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge, 64, 8, true);
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mfma_kernel"; return rc; }
+    }
     if (d->n > DDP_MAX_N_GENERIC || force == 'b') {               // large states: 256-thread work-group per trajectory
         const int rc = ddp_launch_back_pass_big(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_big_kernel"; return rc; }
     }
     if (d->n > DDP_MAX_N_GENERIC && d->n <= 64 && ((d->n | d->m) & 1))      // odd n or m: embed in the next even sizes
-        return launch_back_pass_padded(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+        return launch_back_pass_padded(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge, d->n + (d->n & 1), d->m + (d->m & 1), false);
     DDP_CHECK(d->n <= DDP_MAX_N_GENERIC, "back_pass: n=%d m=%d has no kernel (n <= %d with m <= %d, or n <= 64)", d->n, d->m, DDP_MAX_N_GENERIC, DDP_MAX_M);
     return launch_nm<0, 0>(h, d, a);
 #else
