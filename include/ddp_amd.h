@@ -92,8 +92,9 @@ typedef struct {
  * outputs: K[m,n,N,B] k[m,N,B] Quu[m,m,N,B] Vx[n,N,B] Vxx[n,n,N,B] dV[2,B] diverge int32[B]
  *          (diverge: 0 ok, else the 1-based failing time index; outputs earlier in time than the
  *          failing step are zero like the reference's zero-initialised arrays)
- * shapes : m <= DDP_MAX_M (8); n <= 64 (n = 10/m = 2, n = 4/m = 1 and n = 64/m = 8 have their own kernels; odd n > 32 or an odd m with
- *          n > 32 runs embedded in the next even sizes through a pad buffer of the handle).  Larger n or m: return code < 0.
+ * shapes : m <= DDP_MAX_M (8); n <= 64 (kernel families by size: n = 10/m = 2, n = 4/m = 1, any n <= 12/m <= 4, n <= 14/m <= 4, n <= 32/m <= 8,
+ *          n = 64/m = 8; 32 < n < 64 runs embedded in the (64, 8) problem through a pad buffer of the handle — zero rows / columns, an
+ *          identity block of cuu — or, beyond 48 GB of padded copies, in the next even sizes).  Larger n or m: return code < 0.
  *          back_pass_gps: n <= 32.                                                                     */
 int ddp_back_pass_f64_dev(ddp_handle h, const ddp_bp_desc *d,
                           const double *cx, const double *cu, const double *cxx, const double *cxu,
