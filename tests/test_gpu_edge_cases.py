@@ -563,5 +563,5 @@ def test_torch_imported_after_the_library_still_finds_the_gpu():
             "x2, u2, c2 = ddp_amd.forward_pass(None, np.array([3.0, 0, 0, 0]), np.zeros((1, 8)), None, 1.0, ddp_amd.PendcartProblem(), None)\n"
             "assert np.array_equal(c, c2); print('both ok')") % root
     env = dict(os.environ); env.pop("DDP_AMD_SHARE_TORCH_HIP", None)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "both ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
