@@ -25,6 +25,16 @@ def pytest_collection_finish(session):
             torch.cuda.init()
         except Exception:
             pass
+        # a fresh GPU box is still paging its image in: the first test file (the bench contract) starts rocprofv3 children under a time
+        # limit — touch the profiler once here so that its start-up is not part of theirs
+        try:
+            import shutil
+            import subprocess
+            rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+            if os.path.exists(rp):
+                subprocess.run([rp, "--help"], capture_output=True, timeout=300)
+        except Exception:
+            pass
 
 
 def load_golden(name):
