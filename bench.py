@@ -443,7 +443,7 @@ def measure_traffic(kernel, B, N):
             cmd = [rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--steps", "3", "--warmup", "1", "--preheat", "0", "--batch", str(B), "--horizon", str(N), "--no-cpu-baseline", "--no-other-configs",
                    "--fill-batch", "0", "--no-traffic"]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", DDP_BENCH_CHILD="1"), capture_output=True, text=True, timeout=420)       # (a box whose image is still paging in takes minutes to start rocprofv3 + torch)
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", DDP_BENCH_CHILD="1"), capture_output=True, text=True, timeout=180)       # (some boxes take longer than this to start rocprofv3 + torch: the caller then replays the committed figure and says so)
             acc = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
