@@ -469,7 +469,7 @@ def other_configs():
     env.setdefault("DDP_BC_STEPS", "40")
     out = []
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c2tv", "c4", "c5", "offA", "offB", "offC", "offD", "offL"], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c2tv", "c4", "c5", "offA", "offB", "offC", "offD", "offE", "offL"], env=env, capture_output=True,
                            text=True, timeout=400)
         for line in r.stdout.splitlines():
             if line.startswith("{"):
