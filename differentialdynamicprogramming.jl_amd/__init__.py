@@ -160,15 +160,25 @@ def _lims(lims):
 
 # ---------------------------------------------------------------------------------- back_pass
 def back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u, *, fx_batched=None, cost_batched=None,
-              handle=None):
+              batched_dynamics=None, batched_cost=None, handle=None):
     """Drop-in for ``back_pass(cx,cu,cxx,cxu,cuu,fx,fu,λ,regType,lims,x,u)`` (backward_pass.jl:217).
 
     Dispatch on array rank like the reference (``fx`` 2-D → LTI :217, 3-D → LTV :162, ``cxx`` 3-D →
     time-varying cost :179).  ``cx`` of rank 3 means a batch ``cx[n,N,B]``; then ``λ`` may be a vector
     of length B and ``fx``/``cxx`` of rank 4 are per-trajectory.
     Returns ``(diverge, GaussianPolicy, Vx, Vxx, dV)``; with a batch every output carries a trailing
-    batch axis and ``diverge`` is an int32 vector."""
+    batch axis and ``diverge`` is an int32 vector.
+
+    Per-trajectory TIME-INVARIANT operands (``fx[n,n,B]``, ``cxx[n,n,B]``) have the rank of the reference's time-varying ones and are
+    never guessed from ``shape[2] == B``: pass ``batched_dynamics=True`` / ``batched_cost=True`` (``DDPAmd.back_pass`` has the same
+    keywords; ``fx_batched`` / ``cost_batched`` are the older names of the same switches)."""
     h = handle or default_handle()
+    if batched_dynamics is not None:
+        assert fx_batched is None or bool(fx_batched) == bool(batched_dynamics), "fx_batched and batched_dynamics disagree"
+        fx_batched = bool(batched_dynamics)
+    if batched_cost is not None:
+        assert cost_batched is None or bool(cost_batched) == bool(batched_cost), "cost_batched and batched_cost disagree"
+        cost_batched = bool(batched_cost)
     cx, cu, u = _lib.f64(cx), _lib.f64(cu), _lib.f64(u)
     batched = cx.ndim == 3
     n, N = cx.shape[0], cx.shape[1]

@@ -118,7 +118,13 @@ const NULLI = Ptr{Int32}(C_NULL)
 
 # ---- handle ---------------------------------------------------------------------------------------
 last_error() = unsafe_string(@ccall libddp.ddp_last_error()::Cstring)
-check(rc) = rc == 0 ? nothing : error("libddp_amd: $(last_error()) (rc=$rc)")   # there is no CPU fallback
+"a call the library refused or that failed on the device (the Python mirror's `DDPError`); `rc` is the C return code"
+struct DDPError <: Exception
+    rc::Int
+    msg::String
+end
+Base.showerror(io::IO, e::DDPError) = print(io, "libddp_amd: ", e.msg, " (rc=", e.rc, ")")
+check(rc) = rc == 0 ? nothing : throw(DDPError(Int(rc), last_error()))   # there is no CPU fallback inside the library
 
 mutable struct Handle
     ptr::Ptr{Cvoid}
@@ -274,17 +280,23 @@ _ptr_or_null(a::Array{Float64}) = isempty(a) ? NULLF : pointer(a)
 
 Same signature, dispatch (array rank selects LTI / LTV / time-varying cost) and return values as the reference's linear-system
 `back_pass` methods (src/backward_pass.jl:162,179,217).  `cx[n,N,B]` solves a batch: `λ` may then be a vector, `fx`/`cxx` of
-one more rank are per trajectory, every output carries the batch axis and `diverge` is a vector.
+rank 4 are per trajectory and time-varying, every output carries the batch axis and `diverge` is a vector.  Per-trajectory
+TIME-INVARIANT operands (`fx[n,n,B]`, `cxx[n,n,B]`) have the rank of the reference's time-varying ones: say so with
+`batched_dynamics=true` / `batched_cost=true` (the last axis is then the batch, not time).
 """
-function back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u; handle::Handle=default_handle(), policy=GaussianPolicy{Float64})
+function back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u; handle::Handle=default_handle(), policy=GaussianPolicy{Float64},
+                   batched_dynamics::Union{Nothing,Bool}=nothing, batched_cost::Union{Nothing,Bool}=nothing)
     batched = ndims(cx) == 3
     n, N = size(cx, 1), size(cx, 2)
     m = size(cu, 1)
     B = batched ? size(cx, 3) : 1
     cx, cu, cxx, cxu, fx, fu, u = map(_f64, (cx, cu, cxx, cxu, fx, fu, u))
     cuu = reshape(_f64(cuu), m, m, size(_f64(cuu))[3:end]...)
-    fx_batched = ndims(fx) == 4 || (batched && ndims(fx) == 3 && size(fx, 3) == B && B != N)
-    cost_batched = ndims(cxx) == 4
+    # rank 4 is per trajectory AND time-varying; a rank-3 `fx` is read as time-varying (the reference's :162 method) unless the caller
+    # says `batched_dynamics=true` (per-trajectory, time-invariant: `fx[n,n,B]`) — no guess from `size(fx,3) == B` (wrong when B == N)
+    fx_batched = batched_dynamics === nothing ? ndims(fx) == 4 : batched_dynamics
+    cost_batched = batched_cost === nothing ? ndims(cxx) == 4 : batched_cost
+    (fx_batched || cost_batched) && !batched && error("batched_dynamics / batched_cost need a batch: cx[n,N,B]")
     fx_tv = (ndims(fx) - (fx_batched ? 1 : 0)) == 3
     cost_tv = (ndims(cxx) - (cost_batched ? 1 : 0)) == 3
     @assert size(cu) == (m, N, (batched ? (B,) : ())...) "size(cu) should be (m, N)"
@@ -521,25 +533,79 @@ function iLQG_mpc(problem::RegisteredProblem, x0::AbstractMatrix, u0::AbstractAr
 end
 
 # ---- the drop-in entry point ------------------------------------------------------------------------------------------
-const _ref = Ref{Any}(nothing)         # the reference module once `install!` has rebound its back_pass
+const _ref = Ref{Any}(nothing)         # the reference module once `install!` has added the GPU methods to its back_pass
+const _installed = Method[]            # the methods `install!` added (what `uninstall!` deletes)
+const MAX_N = 64                       # include/ddp_amd.h: the backward kernels take n <= 64, m <= 8
+const MAX_M = 8
+
+# What the GPU methods accept: dense Float64 arrays (and the `Diagonal` / vector cost terms of the reference's demos).  Everything else —
+# Float32, BigFloat, dual numbers, views, sparse or static arrays — stays on the reference's own `AbstractArray{T}` methods, which
+# `install!` leaves in place: the methods below are strictly MORE SPECIFIC than backward_pass.jl:162,179,217, not replacements.
+const DenseCost2 = Union{Matrix{Float64},Diagonal{Float64,Vector{Float64}}}
+const DenseCost3 = Array{Float64,3}
+
+# the reference's own method for these arguments, by its declared signature (`invoke` does not see the narrower GPU method)
+_ref_sig(::Val{:ltv_ti}) = Tuple{Any,Any,AbstractArray{Float64,2},Any,Any,AbstractArray{Float64,3},Any,Any,Any,Any,Any,Any}    # :162
+_ref_sig(::Val{:ltv_tv}) = Tuple{Any,Any,AbstractArray{Float64,3},Any,Any,AbstractArray{Float64,3},Any,Any,Any,Any,Any,Any}    # :179
+_ref_sig(::Val{:lti})    = Tuple{Any,Any,AbstractArray{Float64,2},Any,Any,AbstractMatrix{Float64},Any,Any,Any,Any,Any,Any}      # :217
+
+# true when the C library takes this call (sizes in range, every operand a Float64 array)
+function _gpu_takes(cx, cu, cxu, cuu, fu, x, u)
+    n, m = size(cx, 1), size(cu, 1)
+    (1 <= n <= MAX_N && 1 <= m <= MAX_M) || return false
+    return all(a -> a isa AbstractArray{Float64}, (cx, cu, cxu, cuu, fu, x, u))
+end
 
 """
     install!(ref::Module = Main.DifferentialDynamicProgramming)
 
-Rebinds the three linear-system `back_pass` methods of the loaded reference package (src/backward_pass.jl:162,179,217) to
-`DDPAmd.back_pass`, so that the reference's own `iLQG(f,costfun,df,x0,u0; ...)` — arbitrary Julia closures, its own line search,
-trace and printing — runs STEP 2 (iLQG.jl:235-251) on the GPU.  Returns policies of the reference's own `GaussianPolicy` type.
+ADDS three methods to the loaded reference package's `back_pass`, on signatures strictly narrower than its own linear-system methods
+(src/backward_pass.jl:162,179,217: `cxx::AbstractArray{T,2|3}`, `fx::AbstractArray{T,3}` / `AbstractMatrix{T}` — here `Matrix{Float64}` /
+`Diagonal{Float64}` / `Array{Float64,3}`), so that the reference's own `iLQG(f,costfun,df,x0,u0; ...)` — arbitrary Julia closures, its own
+line search, trace and printing — runs STEP 2 (iLQG.jl:235-251) on the GPU.  The reference's methods are NOT overwritten: they remain the
+fallback, reached by dispatch for every other element or array type and by `invoke` from the GPU methods when the problem is outside
+the kernels' range (n > $MAX_N, m > $MAX_M, a non-`Float64` operand) or the library refuses the shape (`DDPError`).  The second-order
+methods (`fxx, fxu, fuu`, :81,:132) have another arity and are untouched.  Returns policies of the reference's own `GaussianPolicy` type.
+`uninstall!` removes the three methods again.
 """
 function install!(ref::Module=getfield(Main, :DifferentialDynamicProgramming))
+    _ref[] === ref && !isempty(_installed) && return ref
+    isempty(_installed) || uninstall!()
     pol(N, n, m, K, k, Σ, Σi) = ref.GaussianPolicy(N, n, m, K, k, Σ, Σi)
-    bp(args...) = back_pass(args...; policy=pol)
-    @eval ref begin
-        back_pass(cx, cu, cxx::AbstractArray{T,2}, cxu, cuu, fx::AbstractArray{T,3}, fu, λ, regType, lims, x, u) where {T} = $bp(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
-        back_pass(cx, cu, cxx::AbstractArray{T,3}, cxu, cuu, fx::AbstractArray{T,3}, fu, λ, regType, lims, x, u) where {T} = $bp(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
-        back_pass(cx, cu, cxx::AbstractArray{T,2}, cxu, cuu, fx::AbstractMatrix{T}, fu, λ, regType, lims, x, u) where {T} = $bp(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+    function bp(kind::Val, cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+        fallback() = invoke(ref.back_pass, _ref_sig(kind), cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+        _gpu_takes(cx, cu, cxu, cuu, fu, x, u) || return fallback()
+        try
+            return back_pass(cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u; policy=pol)
+        catch err
+            err isa DDPError || rethrow()
+            return fallback()             # a shape the library refuses: the reference's own method, as before `install!`
+        end
     end
+    before = Set(methods(ref.back_pass))
+    @eval ref begin
+        back_pass(cx, cu, cxx::$DenseCost2, cxu, cuu, fx::Array{Float64,3}, fu, λ, regType, lims, x, u) = $bp(Val(:ltv_ti), cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+        back_pass(cx, cu, cxx::$DenseCost3, cxu, cuu, fx::Array{Float64,3}, fu, λ, regType, lims, x, u) = $bp(Val(:ltv_tv), cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+        back_pass(cx, cu, cxx::$DenseCost2, cxu, cuu, fx::Matrix{Float64}, fu, λ, regType, lims, x, u) = $bp(Val(:lti), cx, cu, cxx, cxu, cuu, fx, fu, λ, regType, lims, x, u)
+    end
+    append!(_installed, (mth for mth in methods(ref.back_pass) if !(mth in before)))
+    length(_installed) == 3 || @warn "install!: expected three new back_pass methods" length(_installed)
     _ref[] = ref
     return ref
+end
+
+"""
+    uninstall!()
+
+Deletes the methods `install!` added; the reference's `back_pass` dispatches as it did before.
+"""
+function uninstall!()
+    for mth in _installed
+        Base.delete_method(mth)
+    end
+    empty!(_installed)
+    _ref[] = nothing
+    return nothing
 end
 
 """

@@ -246,3 +246,68 @@ def test_public_entry_points_are_real_definitions():
     assert m, "function iLQG(...) not found"
     for kw in ("lims", "α", "tol_fun", "tol_grad", "max_iter", "λ", "dλ", "λfactor", "λmax", "λmin", "regType", "reduce_ratio_min", "diff_fun"):
         assert re.search(rf"\b{kw}\s*=", m.group(1)), f"iLQG lost its keyword {kw}"
+
+
+# ---- install! is a SAFE drop-in (missing 3) ------------------------------------------------------------------------------
+# the annotations of the reference's three linear-system methods, /root/reference/src/backward_pass.jl:162,179,217 (cxx, fx)
+REF_BACK_PASS_ANNOTATIONS = {("AbstractArray{T,2}", "AbstractArray{T,3}"), ("AbstractArray{T,3}", "AbstractArray{T,3}"),
+                             ("AbstractArray{T,2}", "AbstractMatrix{T}")}
+
+
+def _ddpamd_src():
+    return open(os.path.join(ROOT, "differentialdynamicprogramming.jl_amd", "julia", "DDPAmd.jl"), encoding="utf-8").read()
+
+
+def _function_body(src, name):
+    m = re.search(rf"^function {re.escape(name)}\(.*?^end\n", src, flags=re.S | re.M)
+    assert m, f"function {name} not found"
+    return m.group(0)
+
+
+def test_install_adds_narrower_methods_and_keeps_the_reference_ones():
+    """`install!` must not overwrite backward_pass.jl:162,179,217: its three methods carry annotations that are strictly narrower than the
+    reference's (concrete Float64 array types), so the reference's own `AbstractArray{T}` methods stay the fallback."""
+    body = _function_body(_ddpamd_src(), "install!")
+    sigs = re.findall(r"^\s*back_pass\(cx, cu, cxx::(.+?), cxu, cuu, fx::(.+?), fu, λ, regType, lims, x, u\)\s*=", body, flags=re.M)
+    assert len(sigs) == 3, sigs
+    for cxx_t, fx_t in sigs:
+        assert (cxx_t.strip(), fx_t.strip()) not in REF_BACK_PASS_ANNOTATIONS, "install! would OVERWRITE a reference method: %s / %s" % (cxx_t, fx_t)
+        assert "AbstractArray{T" not in cxx_t + fx_t and "AbstractMatrix{T" not in fx_t
+        assert "Float64" in fx_t and ("Float64" in cxx_t or cxx_t.strip().startswith("$Dense")), (cxx_t, fx_t)
+    assert " where " not in "".join(l for l in body.splitlines() if l.lstrip().startswith("back_pass(")), "no type parameter: Float64 only"
+    src = _ddpamd_src()
+    assert re.search(r"^const DenseCost2 = Union\{Matrix\{Float64\},\s*Diagonal\{Float64", src, flags=re.M)
+    assert re.search(r"^const DenseCost3 = Array\{Float64,3\}", src, flags=re.M)
+
+
+def test_install_has_a_fallback_to_the_reference_methods():
+    """n > 64, m > 8, a non-Float64 operand or a shape the library refuses (DDPError) must reach the reference's method through `invoke`
+    with the REFERENCE's declared signature, and `uninstall!` must delete what `install!` added."""
+    src = _ddpamd_src()
+    body = _function_body(src, "install!")
+    assert "invoke(ref.back_pass, _ref_sig(kind)" in body
+    assert "_gpu_takes(" in body and "fallback()" in body
+    assert re.search(r"err isa DDPError \|\| rethrow\(\)", body)
+    takes = _function_body(src, "_gpu_takes")
+    assert "MAX_N" in takes and "MAX_M" in takes and "AbstractArray{Float64}" in takes
+    assert re.search(r"^const MAX_N = 64\b", src, flags=re.M) and re.search(r"^const MAX_M = 8\b", src, flags=re.M)
+    # the three invoke signatures are the reference's (Float64 instances of its AbstractArray annotations)
+    for kind, cxx_t, fx_t in ((":ltv_ti", "AbstractArray{Float64,2}", "AbstractArray{Float64,3}"),
+                              (":ltv_tv", "AbstractArray{Float64,3}", "AbstractArray{Float64,3}"),
+                              (":lti", "AbstractArray{Float64,2}", "AbstractMatrix{Float64}")):
+        m = re.search(rf"^_ref_sig\(::Val{{{kind}}}\)\s*=\s*Tuple{{Any,Any,([^,]+,\d+}}|[^,]+}}),Any,Any,([^,]+,\d+}}|[^,]+}}),", src, flags=re.M)
+        assert m and m.group(1) == cxx_t and m.group(2) == fx_t, (kind, m and m.groups())
+    un = _function_body(src, "uninstall!")
+    assert "Base.delete_method" in un and "empty!(_installed)" in un
+    names = top_level_functions(src)
+    assert "uninstall!" in names and "_gpu_takes" in names
+    assert re.search(r"^struct DDPError <: Exception", src, flags=re.M)
+    assert "throw(DDPError(" in src
+
+
+def test_back_pass_does_not_guess_the_batch_axis():
+    """a batched call with B == N and per-trajectory time-invariant dynamics was read as time-varying (`B != N` guess): now a keyword"""
+    body = _function_body(_ddpamd_src(), "back_pass")
+    assert "B != N" not in body
+    assert "batched_dynamics::Union{Nothing,Bool}=nothing" in body and "batched_cost::Union{Nothing,Bool}=nothing" in body
+    assert "fx_batched = batched_dynamics === nothing ? ndims(fx) == 4 : batched_dynamics" in body
