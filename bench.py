@@ -357,6 +357,11 @@ def main():
                           "one 32-byte RCCL all-reduce of line-search statistics per step when n_gpus>1 (issued by %s)" % ("the C ABI, ddp_allreduce_stats_f64_dev" if args.collective == "capi" else "torch.distributed")},
                "roofline": roofline, "cpu_baseline": cpu, "machine_filling": fill, "full_line_search": ls, "other_configs": other}
         out["n_ranks_seen"] = dist.get_world_size() if use_dist else 1     # from the communicator, not from the command line
+        # tiles of the shared-operand backward pass whose cross-work-group wait ran out (results stay correct — the tile is handed to the
+        # per-trajectory kernels — but a stall inside the headline kernel is a defect): must be 0; when it is not, who waited for what
+        out["sh_timeouts"] = h.sh_timeouts()
+        if out["sh_timeouts"]:
+            out["sh_timeout_info"] = h.sh_timeout_info()
         if use_dist:
             # the vector the ranks share per step (Σ new cost, Σ dV[1], Σ dV[2], #diverged — summed over the ranks) after the last step
             out["collective"] = {"issued_by": args.collective, "stats": [float(v) for v in stats_vec]}
@@ -469,7 +474,7 @@ def other_configs():
     env.setdefault("DDP_BC_STEPS", "40")
     out = []
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c2tv", "c4", "c5", "offA", "offB", "offC", "offD", "offE", "offL"], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "bench_configs.py"), "c3", "c2tv", "c4", "c4tv", "c5", "offA", "offB", "offC", "offD", "offE", "offL"], env=env, capture_output=True,
                            text=True, timeout=400)
         for line in r.stdout.splitlines():
             if line.startswith("{"):
@@ -484,10 +489,11 @@ def other_configs():
             tj = json.load(open(tfile))
             for o in out:
                 tag = o["config"].split()[0]
-                tag = "C2TV" if tag == "C2" else tag
+                tag = "C2TV" if tag == "C2" else tag.upper()          # off-shape lines: offA -> OFFA_* keys of pmc_traffic.json
                 o["back_pass_pmc_bytes_per_launch"] = tj.get("%s_back_pass_bytes_per_launch_B%d" % (tag, o["batch"]))
-                if tag == "C4":
-                    o["back_pass_mfma_busy_frac"] = tj.get("C4_back_pass_mfma_busy_frac")
+                busy = tj.get("%s_back_pass_mfma_busy_frac" % tag)
+                if busy is not None:
+                    o["back_pass_mfma_busy_frac"] = busy
         except Exception:
             pass
     return out

@@ -19,7 +19,7 @@ u8p = C.POINTER(C.c_uint8)
 vp = C.c_void_p
 
 EXPORTS = [
-    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_reload_env", "ddp_last_kernel", "ddp_sh_timeouts", "ddp_stream",
+    "ddp_last_error", "ddp_version", "ddp_device_count", "ddp_create", "ddp_create_with_stream", "ddp_destroy", "ddp_sync", "ddp_reload_env", "ddp_last_kernel", "ddp_sh_timeouts", "ddp_sh_timeout_info", "ddp_stream",
     "ddp_malloc", "ddp_free", "ddp_memcpy_h2d", "ddp_memcpy_d2h", "ddp_memset", "ddp_host_alloc", "ddp_host_free", "ddp_host_trim",
     "ddp_event_create", "ddp_event_destroy", "ddp_event_record", "ddp_event_elapsed_ms",
     "ddp_back_pass_f64_dev", "ddp_back_pass_f64", "ddp_boxqp_f64_dev", "ddp_boxqp_f64",
@@ -209,6 +209,20 @@ class Handle:
         if r < 0:
             check(r)
         return r
+
+    def sh_timeout_info(self):
+        """what the tiles counted by `sh_timeouts` were waiting for (ddp_sh_timeout_info): a list of dicts — work-group, group, the chunk
+        (of 8 time steps) it waited for, the progress word it last saw, ms waited, XCD, groups of that launch, launch number — and the 16
+        progress words as they stand now; empty in a healthy run"""
+        buf = (C.c_int * 80)()
+        r = lib().ddp_sh_timeout_info(self._h, buf, 80)
+        if r < 0:
+            check(r)
+        keys = ("work_group", "group", "chunk", "progress_seen", "waited_ms", "xcc", "groups", "launch")
+        recs = [dict(zip(keys, (int(buf[8 * i + e]) for e in range(8)))) for i in range(r)]
+        for d in recs:
+            d["published_seen"] = d["progress_seen"] & ((1 << 24) - 1); d["finished_seen"] = bool(d["progress_seen"] & (1 << 30))
+        return {"records": recs, "progress_now": [int(buf[64 + g]) for g in range(16)]}
 
     def sync(self):
         check(lib().ddp_sync(self._h))

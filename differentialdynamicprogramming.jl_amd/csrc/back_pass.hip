@@ -776,7 +776,7 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         const int rc = ddp_launch_back_pass_mxg(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mxg_kernel"; return rc; }
     }
-    if (force != 'g' && force != 'b' && force != 'r' && force != 't' && force != 'w') {
+    if (force != 'g' && force != 'b' && force != 'r' && force != 't' && force != 'w' && force != 'm') {      // (a forced family either runs or falls through to the general kernel)
         const int rc = ddp_launch_back_pass_dpp(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_dpp_kernel"; return rc; }
     }

@@ -98,7 +98,12 @@ struct ShCtl {                                      // device-resident control b
     int gcount[SH_GMAX], gstart[SH_GMAX];
     double glam[SH_GMAX];
     unsigned long long prof[64];                    // -DSH_PROF: phase sums of group 0's chain wave + wall-clock marks (ddp_sh_prof)
+    // the first SH_NDIAG tiles that gave up since the block was allocated (ddp_sh_timeout_info): which tile of which group waited for
+    // which chunk, the progress word it last saw, for how long, on which XCD, with which ticket, in which launch
+    int ndiag, launches, pad3, pad4;
+    int diag[8][8];                                 // {tile, group, chunk, progress word seen, waited ms, xcc id, G of the launch, launch number}
 };
+constexpr int SH_NDIAG = 8;
 
 struct ShArgs {
     int N, B, ncu, regType, wmax, test_abort;                   // wmax: the items[] capacity = the work-groups behind the SH_GMAX producers of the grid
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(1024) void sh_group_kernel(ShArgs a)
             for (int g = 0; g < G; ++g) { gtile[g] = W; W += (gcn[g] + T - 1) / T; }
             gtile[G] = W;
             Gs = G; Ts = T;
-            a.ctl->G = G; a.ctl->W = W; a.ctl->ticket = 0; a.ctl->error = 0;
+            a.ctl->G = G; a.ctl->W = W; a.ctl->ticket = 0; a.ctl->error = 0; a.ctl->launches += 1;
 #ifdef SH_PROF
             for (int e = 0; e < 64; ++e) a.ctl->prof[e] = 0;
             a.ctl->prof[19] = ~0ull;
@@ -710,13 +715,24 @@ __device__ __forceinline__ void sh_dma(const ShArgs &a, double *sm, const int gi
         }
     };
     static_assert(NAFF <= 8 && 22 + 3 * NAFF <= 63, "vmcnt is a 6-bit counter");
+    int qwait = 0;
     auto give_up = [&]() {
         for (int t = lane; t < item.z; t += DDP_WAVE) a.fb_active[a.perm[item.y + t]] = 1;
-        if (lane == 0) { atomicAdd(&a.ctl->error, 1); atomicAdd(&a.ctl->errors_total, 1); }
+        if (lane == 0) {
+            atomicAdd(&a.ctl->error, 1); atomicAdd(&a.ctl->errors_total, 1);
+            const int slot = atomicAdd(&a.ctl->ndiag, 1);
+            if (slot < SH_NDIAG) {
+                unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                int *d = a.ctl->diag[slot];
+                d[0] = (int)blockIdx.x; d[1] = gidx; d[2] = qwait; d[3] = pubd; d[4] = (int)((wall_clock64() - t0) / 100000ull);
+                d[5] = (int)(xcc & 15u); d[6] = a.ctl->G; d[7] = a.ctl->launches;
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // direct-to-LDS loads of earlier chunks may still be in flight
         lds_store_flag(&flags[CF_SREADY], SH_ABORT);
     };
     for (int q = 0; q < NCHK; ++q) {
+        qwait = q;
         if (__builtin_expect(a.test_abort && q == 1, 0)) { give_up(); return; }       // DDP_TEST_SH_ABORT: every tile gives up at its second chunk
         // (1) the chunk must have been published (or the group has ended before it)
         while ((pubd & SH_CNT) <= q && !(pubd & SH_FIN)) {
@@ -1089,6 +1105,24 @@ extern "C" int ddp_sh_prof(ddp_handle h, unsigned long long *out32)
     DDP_HIP(hipMemcpy(&c, h->sh, sizeof c, hipMemcpyDeviceToHost));
     for (int e = 0; e < 64; ++e) out32[e] = c.prof[e];
     return 0;
+}
+
+// the tiles that gave up (ddp_sh_timeouts > 0): up to 8 records of 8 ints — {work-group, group, chunk it waited for, progress word it
+// last saw (chunks published | 1 << 30 finished), milliseconds waited, XCD, groups of the launch, launch number} — followed by the 16
+// progress words as they stand now; returns the number of records (0 in a healthy run).  out: 8 * 8 + 16 ints.
+extern "C" int ddp_sh_timeout_info(ddp_handle h, int *out, int cap)
+{
+    DDP_DEVICE(h);
+    if (!out || cap < SH_NDIAG * 8 + SH_GMAX) { ddp_set_error("ddp_sh_timeout_info: out needs %d ints", SH_NDIAG * 8 + SH_GMAX); return -2; }
+    for (int e = 0; e < SH_NDIAG * 8 + SH_GMAX; ++e) out[e] = 0;
+    if (!h->sh) return 0;
+    DDP_HIP(hipStreamSynchronize(h->stream));
+    ShCtl c;
+    DDP_HIP(hipMemcpy(&c, h->sh, sizeof c, hipMemcpyDeviceToHost));
+    const int nd = c.ndiag < SH_NDIAG ? c.ndiag : SH_NDIAG;
+    for (int r = 0; r < nd; ++r) for (int e = 0; e < 8; ++e) out[8 * r + e] = c.diag[r][e];
+    for (int g = 0; g < SH_GMAX; ++g) out[SH_NDIAG * 8 + g] = c.progress[16 * g];
+    return nd;
 }
 
 extern "C" int ddp_sh_timeouts(ddp_handle h)

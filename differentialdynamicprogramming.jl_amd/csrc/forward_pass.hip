@@ -325,7 +325,8 @@ int ddp_forward_pass_f64_dev(ddp_handle h, const ddp_problem *p, const double *K
         // what no row holds (n > 14 or m > 4): one wave per rollout with the operands of a step requested a step ahead
         // (forward_mid_kernel, n <= 32; n = 24, m = 4, N = 300, B = 1 024 LTV: 0.56 ms against 3.1 on forward_big_kernel and 6.0 on the
         // group-of-lanes kernel below), forward_big_kernel above n = 32
-        if (p->kind == DDP_PROBLEM_LQ && (p->n > 14 || p->m > 4)) {
+        // (the row launcher also declines n > 12 with m > 2 — (13,3) (13,4) (14,3) (14,4): they used to drop to the group-of-lanes kernel — ADVICE r5)
+        if (p->kind == DDP_PROBLEM_LQ && (p->n > 14 || p->m > 4 || (p->n > 12 && p->m > 2))) {
             const int rb = ddp_launch_forward_big(h, p, K, k, x0, u, x, alpha, nalpha, lims, active, xnew, unew, cnew, csum);
             if (rb <= 0) return rb;
         }

@@ -147,6 +147,13 @@ reload_env(h::Handle=default_handle()) = check(@ccall libddp.ddp_reload_env(h.pt
 last_kernel(which::Integer=0; handle::Handle=default_handle()) = unsafe_string(@ccall libddp.ddp_last_kernel(handle.ptr::Ptr{Cvoid}, which::Cint)::Cstring)
 # tiles of the shared-operand backward pass that gave their trajectories to the per-trajectory kernels after a timed-out wait (0 in a healthy run)
 sh_timeouts(; handle::Handle=default_handle()) = Int(@ccall libddp.ddp_sh_timeouts(handle.ptr::Ptr{Cvoid})::Cint)
+"what those tiles waited for: rows {work-group, group, chunk, progress word seen, ms waited, XCD, groups, launch} + the 16 progress words now"
+function sh_timeout_info(; handle::Handle=default_handle())
+    buf = zeros(Cint, 80)
+    nrec = @ccall libddp.ddp_sh_timeout_info(handle.ptr::Ptr{Cvoid}, buf::Ptr{Cint}, 80::Cint)::Cint
+    nrec < 0 && check(nrec)
+    return permutedims(reshape(buf[1:64], 8, 8))[1:nrec, :], buf[65:80]
+end
 
 """
     result_array(dims...) -> Array{Float64}

@@ -50,6 +50,12 @@ const char *ddp_last_kernel(ddp_handle h, int which);
  * results stay correct — and is counted: this returns the number of such tiles since ddp_create (synchronises the stream; 0 in a
  * healthy run, < 0 on error).  A debug query like ddp_last_kernel.                                                                  */
 int  ddp_sh_timeouts(ddp_handle h);
+/* What the tiles counted by ddp_sh_timeouts were waiting for: up to 8 records of 8 ints — {work-group, group, chunk (of 8 time steps)
+ * waited for, progress word last seen (chunks published | 1 << 30: group finished), milliseconds waited, XCD, groups of that launch,
+ * launch number} — of the first tiles that gave up since the control block was allocated, followed by the 16 progress words as they
+ * stand now.  out: cap >= 80 ints.  Returns the number of records (0 in a healthy run), < 0 on error; synchronises the stream.  (Own
+ * protocol of the shared-operand kernel: no counterpart in the reference.)                                                              */
+int  ddp_sh_timeout_info(ddp_handle h, int *out, int cap);
 void *ddp_stream(ddp_handle h);                 /* the hipStream_t of the handle */
 /* device memory helpers for hosts without their own allocator (the Julia wrapper, tests) */
 int  ddp_malloc(ddp_handle h, size_t bytes, void **dptr);

@@ -1,6 +1,7 @@
 """Pass time (back_pass + forward_pass, one α) of the non-headline BASELINE configs with device-resident operands:
    C3  pendcart n=4 m=1 N=600, control limits (boxQP), B=4096
-   C4  large-state LTV n=64 m=8 N=256, per-trajectory dynamics (a3 layout), B=1024 per GPU
+   C4  large-state LTV n=64 m=8 N=256, per-trajectory time-varying dynamics, ONE time-invariant cost (a2 layout: 75.4 KB per step), B=1024 per GPU
+   C4TV the same with cxx, cxu, cuu time-varying and per trajectory (a3 layout, SURVEY 8d's C4: 112.8 KB per step = 29.4 GB per launch)
    C2TV the C2 shape (n=10, m=2, N=1000, B=1024) in the LTV / TV-cost layout (per-trajectory fx, fu, cxx, cxu, cuu; SURVEY 8d: 4.47 MB/pass)
    C5  one pass of the KL-constrained iteration (C3 + KL): back_pass_gps + forward_pass + forward_covariance + kl_div_wiki, B=4096
    offA / offB  shapes BASELINE does not name (the reference's back_pass is size-generic, backward_pass.jl:162-252): n=12 m=3 N=500
@@ -273,7 +274,10 @@ def c5(B=4096):
                       "diverged": int((ddiv != 0).sum().item())}))
 
 
-def c4(B=1024):
+def c4(B=1024, tv_cost=False):
+    """tv_cost=False: per-trajectory time-varying DYNAMICS with one time-invariant Q, R for the batch (the a2 method, backward_pass.jl:162-177:
+    9 424 doubles per step); tv_cost=True: SURVEY 8(d)'s C4 — cxx, cxu, cuu time-varying and per trajectory as well (the a3 method,
+    backward_pass.jl:179-215: 14 096 doubles = 112.8 KB per step and trajectory, 29.4 GB per launch at B = 1 024)"""
     import scipy.linalg as sla
     n, m, N = 64, 8, 256
     rng = np.random.default_rng(1)
@@ -296,7 +300,16 @@ def c4(B=1024):
     u0 = 0.1 * rng.standard_normal((m, N, B))
     c4lims = os.environ.get("DDP_C4_LIMS")                      # e.g. DDP_C4_LIMS=0.05: control limits ±0.05 (boxQP path)
     lims = None if not c4lims else float(c4lims) * np.stack([-np.ones(m), np.ones(m)], 1)
-    run("C4 large-state LTV" + (" lims" if c4lims else ""), prob, n, m, N, B, f64(x0), f64(u0), lims, 1, (dA, dB, 1, 1), steps=5, warmup=1)
+    if tv_cost:
+        # the reference's a3 layout: cxx[n,n,N], cxu[n,m,N], cuu[m,m,N] per trajectory (8.6 GB + 1.1 GB + 0.13 GB at B = 1 024), built on the device
+        sc = 1.0 + 0.1 * torch.rand(N * B, 1, dtype=torch.float64, device=dev)
+        dcxx = (f64(h_ * np.eye(n)).reshape(1, -1) * sc).reshape(-1).contiguous()
+        dcxu = (f64(1e-3 * h_ * rng.standard_normal((n, m))).reshape(1, -1) * sc).reshape(-1).contiguous()
+        dcuu = (f64(0.1 * h_ * np.eye(m)).reshape(1, -1) * sc).reshape(-1).contiguous()
+        run("C4TV large-state LTV, time-varying per-trajectory cost (a3 layout)" + (" lims" if c4lims else ""), prob, n, m, N, B, f64(x0), f64(u0), lims, 1,
+            (dA, dB, 1, 1), steps=5, warmup=1, cost_desc=(dcxx, dcxu, dcuu, 1, 1))
+        return
+    run("C4 large-state LTV, one time-invariant cost (a2 layout)" + (" lims" if c4lims else ""), prob, n, m, N, B, f64(x0), f64(u0), lims, 1, (dA, dB, 1, 1), steps=5, warmup=1)
     if os.environ.get("DDP_C4_SOLVE", "1") == "1":
         solve("C4 full iLQG solves (device-resident driver)", prob, n, m, N, B, f64(x0), f64(u0), nalpha=4)
 
@@ -341,6 +354,8 @@ if __name__ == "__main__":
         c2tv()
     if "c4" in which:
         c4()
+    if "c4tv" in which:
+        c4(tv_cost=True)
     if "c5" in which:
         c5()
     if "offA" in which:

@@ -21,6 +21,7 @@ def test_bench_line_has_the_contract_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    assert d.get("sh_timeouts") == 0, (d.get("sh_timeouts"), d.get("sh_timeout_info"))      # no tile of the shared kernel gave up in the timed run
     assert d["steps"] == 6 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 1024 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-3 * d["value"]                 # value = units / elapsed
@@ -34,7 +35,11 @@ def test_bench_line_has_the_contract_fields():
     # roofline.traffic is measured by this run (two rocprofv3 --pmc child runs), not replayed: within 5 % of the algorithmic bytes or above
     # (a box whose image is still paging in can run the profiler's child past its time limit: bench.py then says so and replays the
     # committed figure of the same kernel and batch — the line must still carry a traffic figure)
-    assert rf["traffic"] is not None and ("measured in this run" in rf["traffic_source"] or "timed out" in rf["traffic_source"]), rf["traffic_source"]
+    assert rf["traffic"] is not None, rf
+    if "measured in this run" not in rf["traffic_source"]:
+        # the replayed figure says nothing about THIS tree's kernels: no bound is asserted on it
+        assert "timed out" in rf["traffic_source"], rf["traffic_source"]
+        pytest.skip("rocprofv3 child ran past its time limit on this box: traffic replayed from profiles/pmc_traffic.json, bounds not checked (%s)" % rf["traffic_source"][:120])
     assert 0.95 * rf["bytes_per_launch"] < rf["traffic"] < 1.5 * rf["bytes_per_launch"]
 
 

@@ -268,6 +268,73 @@ def test_full_size_c4_pass_and_solves(ddp):
         assert relerr(sl(dVxx, n * n * N).reshape(n, n, N, order="F"), vxxr) < RTOL
 
 
+# ------------------------------------------------------------------------------------------------ C4 in the a3 layout
+@pytest.mark.parametrize("lims_on,regType", [(False, 1), (False, 2), (True, 1)])
+def test_full_size_c4_a3_layout_tv_cost(ddp, lims_on, regType):
+    """SURVEY 8(d)'s C4 as the reference's a3 method reads it (backward_pass.jl:179-215): cxx[n,n,N], cxu[n,m,N], cuu[m,m,N] time-varying
+    AND per trajectory beside per-trajectory time-varying fx, fu — n=64, m=8, N=256, B=256 (the `CTV = true` instantiation of the n = 64
+    matrix-core kernel at the full horizon; 2.1 GB of cost Hessians built on the device); 24 trajectories against the oracle"""
+    import scipy.linalg as sla
+    import torch
+    from ddp_amd import _lib
+    from oracle import oracle_ctypes as oc
+    n, m, N, B = 64, 8, 256, 256
+    dev = torch.device("cuda", 0)
+    L = _lib.lib()
+    h = ddp.default_handle()
+    p_ = lambda t: C.c_void_p(t.data_ptr())                                  # noqa: E731
+    f64 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))).to(dev)   # noqa: E731
+    empty = lambda cnt, dt=torch.float64: torch.empty(int(cnt), dtype=dt, device=dev)     # noqa: E731
+    rng = np.random.default_rng(11)
+    hh = 0.01
+    a0 = rng.standard_normal((n, n))
+    A = sla.expm(hh * (a0 - a0.T)); Bm = hh * rng.standard_normal((n, m))
+    q0 = rng.standard_normal((n, n)); Q0 = hh * (np.eye(n) + 0.05 * (q0 @ q0.T) / n)
+    r0 = rng.standard_normal((m, m)); R0 = 0.1 * hh * (np.eye(m) + 0.05 * (r0 @ r0.T) / m)
+    X0 = 1e-3 * hh * rng.standard_normal((n, m))
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    rnd = lambda: torch.rand(N * B, 1, dtype=torch.float64, device=dev, generator=g)          # noqa: E731
+    dA = (f64(A).reshape(1, -1) * (1.0 + 0.01 * rnd())).reshape(-1).contiguous()
+    dB = (f64(Bm).reshape(1, -1) * (1.0 + 0.01 * rnd())).reshape(-1).contiguous()
+    dcxx = (f64(Q0).reshape(1, -1) * (1.0 + 0.2 * rnd())).reshape(-1).contiguous()
+    dcxu = (f64(X0).reshape(1, -1) * (1.0 + 0.2 * rnd())).reshape(-1).contiguous()
+    dcuu = (f64(R0).reshape(1, -1) * (1.0 + 0.2 * rnd())).reshape(-1).contiguous()
+    cx = hh * rng.standard_normal((n, N, B)); cu = 0.1 * hh * rng.standard_normal((m, N, B)); u = 0.08 * rng.standard_normal((m, N, B))
+    dcx, dcu, du = f64(cx), f64(cu), f64(u)
+    lims = 0.1 * np.stack([-np.ones(m), np.ones(m)], 1) if lims_on else None
+    dl = f64(lims) if lims_on else None
+    lam = 10.0 ** rng.uniform(-3, 0, B)
+    dlam = f64(lam)
+    dK, dk, dQuu, dVx, dVxx, ddV = empty(m * n * N * B), empty(m * N * B), empty(m * m * N * B), empty(n * N * B), empty(n * n * N * B), empty(2 * B)
+    ddiv = torch.zeros(B, dtype=torch.int32, device=dev)
+    desc = _lib.BPDesc(n, m, N, B, 1, 1, 1, 1, regType, int(lims_on))
+    _lib.check(L.ddp_back_pass_f64_dev(h.raw, C.byref(desc), p_(dcx), p_(dcu), p_(dcxx), p_(dcxu), p_(dcuu), p_(dA), p_(dB), p_(dlam),
+                                       p_(dl) if lims_on else None, p_(du), None, p_(dK), p_(dk), p_(dQuu), p_(dVx), p_(dVxx), p_(ddV), p_(ddiv)))
+    torch.cuda.synchronize()
+    assert "mfma" in h.last_kernel(0), h.last_kernel(0)
+    assert int(ddiv.sum().item()) == 0
+    Vxx = dVxx.reshape(B, N, n, n)
+    assert torch.equal(Vxx, Vxx.transpose(2, 3))                             # exactly symmetric over the whole batch
+    assert bool(torch.isfinite(dK).all()) and bool(torch.isfinite(dVx).all())
+    dVh = ddV.cpu().numpy().reshape(2, B, order="F")
+    kk = dk.cpu().numpy().reshape(m, N, B, order="F")
+    if lims_on:                                                              # u + k inside the box wherever the QP ran (backward_pass.jl:45-46)
+        assert (u[:, :-1] + kk[:, :-1] <= 0.1 + 1e-12).all() and (u[:, :-1] + kk[:, :-1] >= -0.1 - 1e-12).all()
+        assert (np.abs(np.abs(u[:, :-1] + kk[:, :-1]) - 0.1) < 1e-12).any()    # ... and some controls on a bound
+
+    def check(b):
+        sl = lambda t, per, shp: t[per * b: per * (b + 1)].cpu().numpy().reshape(shp, order="F")          # noqa: E731
+        Ab, Bb = sl(dA, n * n * N, (n, n, N)), sl(dB, n * m * N, (n, m, N))
+        cxxb, cxub, cuub = sl(dcxx, n * n * N, (n, n, N)), sl(dcxu, n * m * N, (n, m, N)), sl(dcuu, m * m * N, (m, m, N))
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], cxxb, cxub, cuub, Ab, Bb, lam[b], regType, lims, None, u[..., b])
+        assert d == 0
+        for got, ref, name in ((sl(dK, m * n * N, (m, n, N)), K, "K"), (kk[..., b], k, "k"), (sl(dVx, n * N, (n, N)), vx, "Vx"),
+                               (sl(dVxx, n * n * N, (n, n, N)), vxx, "Vxx"), (sl(dQuu, m * m * N, (m, m, N)), Quu, "Quu"), (dVh[:, b], dv, "dV")):
+            assert relerr(got, ref) < RTOL, (name, b, relerr(got, ref))
+    for b in spots(B, 24, 7):                                                # (device slices: serial)
+        check(b)
+
+
 # ------------------------------------------------------------------------------------------------ C5
 def test_full_size_c5_kl_solves(ddp):
     """C5 = C3 + KL constraint at B = 4096: the KL-constrained iteration on device-resident arrays (lane-per-trajectory
