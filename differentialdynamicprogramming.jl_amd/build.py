@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libddp_amd.so")
-SOURCES = ["capi.hip", "back_pass.hip", "back_pass_dpp.hip", "back_pass_dppw.hip", "back_pass_row.hip", "back_pass_row_hi.hip", "back_pass_mid.hip", "back_pass_big.hip", "back_pass_gps_lane.hip", "back_pass_mfma.hip", "back_pass_mfma_lims.hip", "back_pass_mx.hip", "back_pass_mxg.hip", "back_pass_mx2.hip", "back_pass_sh.hip", "back_pass_q4.hip",
+SOURCES = ["capi.hip", "back_pass.hip", "back_pass_dpp.hip", "back_pass_dppw.hip", "back_pass_row.hip", "back_pass_row_hi.hip", "back_pass_mid.hip", "back_pass_big.hip", "back_pass_gps_lane.hip", "back_pass_mfma.hip", "back_pass_mfma_lims.hip", "back_pass_mf2.hip", "back_pass_mf2_lims.hip", "back_pass_mx.hip", "back_pass_mxg.hip", "back_pass_mx2.hip", "back_pass_sh.hip", "back_pass_q4.hip",
            "forward_pass.hip", "forward_pass_dpp.hip", "forward_pass_row.hip", "forward_pass_pipe.hip", "forward_pass_big.hip", "df.hip", "ilqg.hip", "kl.hip", "comm.hip", "boxqp_big.hip"]
 HEADERS = ["ddp_internal.h", "boxqp_dev.h", "boxqp_rows.h", "arena.h", os.path.join("..", "..", "include", "ddp_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Rpass-analysis=kernel-resource-usage", "-Wall", "-Wno-unused-function",
@@ -28,10 +28,12 @@ EXTRA_FLAGS = {"back_pass_mx.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "back_pass_sh.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "back_pass_mid.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "back_pass_q4.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-               "back_pass_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+               "back_pass_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "back_pass_mf2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "back_pass_mf2_lims.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
-EXTRA_DEPS = {"back_pass_row_hi.hip": ["back_pass_row.hip"], "back_pass_mfma.hip": ["back_pass_mfma_kernel.h"], "back_pass_mfma_lims.hip": ["back_pass_mfma_kernel.h"],
+EXTRA_DEPS = {"back_pass_mf2.hip": ["back_pass_mf2_kernel.h"], "back_pass_mf2_lims.hip": ["back_pass_mf2_kernel.h"], "back_pass_row_hi.hip": ["back_pass_row.hip"], "back_pass_mfma.hip": ["back_pass_mfma_kernel.h"], "back_pass_mfma_lims.hip": ["back_pass_mfma_kernel.h"],
               "back_pass_mx.hip": ["back_pass_mx_common.h"], "back_pass_mxg.hip": ["back_pass_mx_common.h"], "back_pass_mx2.hip": ["back_pass_mx_common.h"], "back_pass_sh.hip": ["back_pass_mx_common.h"],
               "forward_pass_dpp.hip": ["pend_math.h"]}
 

@@ -812,16 +812,23 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
 #ifndef DDP_FAST_BUILD
     if (d->n == 4 && d->m == 1) return launch_nm<4, 1>(h, d, a);
     if (d->n == 6 && d->m == 3) return launch_nm<6, 3>(h, d, a);
-    if (force != 'b' && force != 'g') {                          // n=64, m=8: fp64 matrix cores
+    // 32 < n <= 64, m <= 8: the fp64 matrix-core kernel with run-time sizes (back_pass_mf2_kernel.h; round 5 embedded 32 < n < 64 in the
+    // (64, 8) problem through padded COPIES of every operand and result — up to 48 GB of scratch on the handle, half of the time in the
+    // copy kernels).  DDP_BACKPASS=old: the round-5 kernel of the exact (64, 8) shape (A/B timing).
+    if (force == 'o') {
         const int rc = ddp_launch_back_pass_mfma(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mfma_kernel"; return rc; }
     }
-    // 32 < n < 64 (or n = 64 with m < 8): embedded in the (64, 8) problem of the matrix-core kernel — zero rows / columns of the
-    // Jacobians and cost terms, an identity block of cuu, controls free inside [-1, 1] — while the padded copies fit in 48 GB.  The
-    // 256-thread vector kernel below takes 27-36 ms at N = 300, B = 1 024 there (n = 33 was 9x slower than n = 32, 4x slower than n = 64).
-    if (force == 0 && d->n > DDP_MAX_N_GENERIC && d->n <= 64 && d->m <= 8 && padded_bytes(d, 64, 8) <= ((size_t)48 << 30)) {
-        const int rc = launch_back_pass_padded(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge, 64, 8, true);
-        if (rc <= 0) { h->last_kernel[0] = "back_pass_mfma_kernel"; return rc; }
+    if (force != 'b' && force != 'g') {
+        // (rc 2: the exact (64, 8) shape with REAL control limits — lims[1,1] <= lims[1,2], which the launcher has just looked at — stays
+        // on the round-5 kernel by default: its gain wave runs the 8 x 8 box-QP in 16 400 ticks per step against 21 200 in the
+        // run-time-sized kernel, 10.8 vs 13.3 ms at C4 with limits; DDP_BACKPASS=new forces the new one)
+        const int rc = ddp_launch_back_pass_mf2(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge, force != 'n');
+        if (rc <= 0) { h->last_kernel[0] = "back_pass_mf2_kernel"; return rc; }
+        if (rc == 2) {
+            const int ro = ddp_launch_back_pass_mfma(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);
+            if (ro <= 0) { h->last_kernel[0] = "back_pass_mfma_kernel"; return ro; }
+        }
     }
     if (d->n > DDP_MAX_N_GENERIC || force == 'b') {               // large states: 256-thread work-group per trajectory
         const int rc = ddp_launch_back_pass_big(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge);

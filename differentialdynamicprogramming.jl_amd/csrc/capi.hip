@@ -79,7 +79,9 @@ static int create_impl(int device, void *ext_stream, bool adopt, ddp_handle *out
         return -2;
     }
     if (hipHostMalloc((void **)&h->h_pinned, 256) != hipSuccess) h->h_pinned = nullptr;
-    if (hipMalloc(&h->sink, 4096 + 256) != hipSuccess) h->sink = nullptr;     // + a flag word behind it (df.hip)
+    // + a flag word behind it (df.hip) + 1 KB that stays ZERO (offset 4352: loads of padded rows / columns are pointed at it, back_pass_mf2)
+    if (hipMalloc(&h->sink, 4096 + 256 + 1024) != hipSuccess) h->sink = nullptr;
+    else if (hipMemset(h->sink, 0, 4096 + 256 + 1024) != hipSuccess) { hipFree(h->sink); h->sink = nullptr; }
     *out = h;
     return 0;
 }

@@ -168,6 +168,13 @@ int ddp_launch_back_pass_big(ddp_handle h, const ddp_bp_desc *d, const double *c
                              const int32_t *active, double *K, double *k, double *Quu, double *Vx,
                              double *Vxx, double *dV, int32_t *diverge);
 // n=64, m=8 on the fp64 matrix cores (v_mfma_f64_16x16x4_f64); returns 1 for any other shape
+// 32 < n <= 64, m <= 8 at run time: every product on the fp64 matrix cores (back_pass_mf2.hip); 1 = not applicable, 2 = (64, 8) with real
+// limits and `defer_64x8_lims`: nothing launched, the caller takes the round-5 kernel
+int ddp_launch_back_pass_mf2(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
+                             const double *cxx, const double *cxu, const double *cuu, const double *fx,
+                             const double *fu, const double *lambda, const double *lims, const double *u,
+                             const int32_t *active, double *K, double *k, double *Quu, double *Vx,
+                             double *Vxx, double *dV, int32_t *diverge, bool defer_64x8_lims);
 int ddp_launch_back_pass_mfma(ddp_handle h, const ddp_bp_desc *d, const double *cx, const double *cu,
                               const double *cxx, const double *cxu, const double *cuu, const double *fx,
                               const double *fu, const double *lambda, const double *lims, const double *u,

@@ -23,11 +23,16 @@ __global__ __launch_bounds__(256) void bench(double *out, long long *cyc, int sa
 #pragma unroll
             for (int u = 0; u < UNR; ++u) { q[(u & 3)] = acc + u; asm volatile("" ::: "memory"); }
         } else {
+            // 16 independent reads in flight, ONE wait: the issue rate of the LDS pipe, not its latency
             double v[UNR];
+            const unsigned ad = (unsigned)(size_t)(const __attribute__((address_space(3))) double *)p;
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) v[u] = *(volatile double *)(p + (u & 3));
+            for (int u = 0; u < UNR; ++u) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[u]) : "v"(ad), "n"((u & 3) * 8));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (it == ITERS - 1) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) acc += v[u];
+                for (int u = 0; u < UNR; ++u) acc += v[u];
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

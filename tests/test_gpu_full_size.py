@@ -311,7 +311,7 @@ def test_full_size_c4_a3_layout_tv_cost(ddp, lims_on, regType):
     _lib.check(L.ddp_back_pass_f64_dev(h.raw, C.byref(desc), p_(dcx), p_(dcu), p_(dcxx), p_(dcxu), p_(dcuu), p_(dA), p_(dB), p_(dlam),
                                        p_(dl) if lims_on else None, p_(du), None, p_(dK), p_(dk), p_(dQuu), p_(dVx), p_(dVxx), p_(ddV), p_(ddiv)))
     torch.cuda.synchronize()
-    assert "mfma" in h.last_kernel(0), h.last_kernel(0)
+    assert h.last_kernel(0) == ("back_pass_mfma_kernel" if lims_on else "back_pass_mf2_kernel"), h.last_kernel(0)
     assert int(ddiv.sum().item()) == 0
     Vxx = dVxx.reshape(B, N, n, n)
     assert torch.equal(Vxx, Vxx.transpose(2, 3))                             # exactly symmetric over the whole batch

@@ -40,8 +40,10 @@ def _problem(rng, n, m, N, B, tv_cost):
     return cx, cu, cxx, cxu, cuu, fx, fu, u
 
 
-@pytest.mark.parametrize("n,m,impl", [(64, 8, "auto"), (64, 8, "big"), (40, 4, "auto"),      # auto at (64,8) = MFMA kernel
-                                      (33, 2, "auto"), (35, 3, "auto"), (63, 7, "auto"), (40, 3, "auto"), (47, 8, "auto")])   # odd sizes: padded inside the launcher
+@pytest.mark.parametrize("n,m,impl", [(64, 8, "auto"), (64, 8, "big"), (64, 8, "old"), (64, 8, "new"), (40, 4, "auto"),      # auto = the run-time-sized matrix-core kernel (mf2)
+                                      (33, 2, "auto"), (35, 3, "auto"), (63, 7, "auto"), (40, 3, "auto"), (47, 8, "auto"),   # 3 tiles (n <= 48) and 4 tiles, odd sizes
+                                      (48, 6, "auto"), (49, 1, "auto"), (64, 1, "auto"), (33, 8, "auto"), (48, 8, "auto"), (57, 5, "auto"),
+                                      (35, 3, "big")])                                                                       # odd sizes on the vector kernel: padded copies
 @pytest.mark.parametrize("tv_cost", [False, True])
 @pytest.mark.parametrize("regType,lims", [(1, False), (2, False), (1, True)])
 def test_back_pass_large(ddp, monkeypatch, n, m, impl, tv_cost, regType, lims):
@@ -54,6 +56,11 @@ def test_back_pass_large(ddp, monkeypatch, n, m, impl, tv_cost, regType, lims):
     L = np.stack([-0.25 * np.ones(m), 0.4 * np.ones(m)], 1) if lims else None
     lam = np.array([1e-3, 0.1, 2.0])
     div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, L, None, u)
+    from ddp_amd import _lib
+    want = {"auto": "back_pass_mf2_kernel", "new": "back_pass_mf2_kernel", "old": "back_pass_mfma_kernel", "big": "back_pass_big_kernel"}[impl]
+    if impl == "auto" and lims and (n, m) == (64, 8):
+        want = "back_pass_mfma_kernel"             # the exact shape with limits: the round-5 kernel's gain wave is the faster one (back_pass.hip)
+    assert _lib.default_handle().last_kernel(0) == want or (impl == "big" and n % 2), _lib.default_handle().last_kernel(0)      # (odd sizes forced onto the vector kernel: the padded launcher)
     assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2, 3)))
     for b in range(B):
         sl = lambda a_, nd: a_[..., b] if a_.ndim == nd + 1 else a_
