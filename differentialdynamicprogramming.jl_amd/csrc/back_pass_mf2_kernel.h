@@ -52,7 +52,7 @@ struct BPM2Args {
 namespace mf2 {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int NTH = 256, NX = 64, MX = 8, LDV = 65, LDK = 66, KSD = 10, PTS = 36, FC = 80;
+constexpr int NTH = 256, NX = 64, MX = 8, LDV = 66, LDK = 66, KSD = 10, PTS = 36, FC = 80;
 // LDS image (doubles)
 constexpr int oVs = 0, oFs = oVs + NX * LDV, oW0 = oFs + FC * LDK, ovs = oW0 + NX * 16, oQs = ovs + NX, oXs = oQs + FC, oXadd = oXs + MX * NX,
               oQuus = oXadd + MX * NX, oRadd = oQuus + MX * MX, oKs = oRadd + MX * MX, oYs = oKs + KSD * NX, oKh = oYs + KSD * NX, oYh = oKh + KSD * NX, oks = oYh + KSD * NX,
@@ -131,7 +131,7 @@ template <int NT, bool LIMS> __device__ __forceinline__ Slots make_slots(int w)
 }
 template <int NT, bool LIMS> constexpr bool has_slot3() { return NT == 3 || LIMS; }
 
-template <int NT, bool LIMS, bool CTV>
+template <int NT, bool LIMS, bool CTV, bool PAIR>
 __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -193,41 +193,76 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
     // registers): fx column c = 3 q + wave - 1 (q < NFX), fu column c = 3 q' + wave - 1 (q' < 3), lane = row.  Every load has a wave-uniform
     // base and a 32-bit lane offset; rows past n and columns past n / m are CLAMPED to the last one (a valid address, the value is
     // dropped) and keep the zero of the padding in the LDS.
-    constexpr int NFX = (16 * NT + 2) / 3, NFL = NFX + 3;
+    // PAIR (n even): 16 bytes per lane — lane (p, h) = (lane & 31, lane >> 5) holds rows 2p, 2p + 1 of column 2 j + h, so ONE instruction
+    // moves the column pair j = 3 q + wave - 1 (1 KB): half the vector-memory instructions and half the LDS writes of the 8-byte form
+    // (~40 ticks each inside the product chains, where the address unit is shared by four waves).  fu (m may be odd) keeps 8-byte columns.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int NFX = PAIR ? (8 * NT + 2) / 3 : (16 * NT + 2) / 3, NFL = NFX + 3;
     const int rowc = lane < n ? lane : n - 1;
     const bool rowv = lane < n;
     const unsigned row8 = 8u * (unsigned)rowc;
+    const int pp_ = lane & 31, hh_ = lane >> 5;
+    const bool rowvP = 2 * pp_ < n;
+    const unsigned row16 = 8u * (unsigned)((2 * pp_ < n ? 2 * pp_ : n - 2) + n * hh_);
     const int fw = wv > 0 ? wv - 1 : 0;
-    // (the column part of the address is wave-uniform and goes into the scalar base, the lane part is the constant row8: NO vector
+    // (the column part of the address is wave-uniform and goes into the scalar base, the lane part is a constant 32-bit offset: NO vector
     // instruction per load — between two fp64 products a vector instruction does not hide, it adds its time: 35 ticks per product)
-    auto f_load = [&](const char *fxb, const char *fub, int nv, int q, unsigned r8, int fw) -> double {
-        const int c = 3 * (q < NFX ? q : q - NFX) + fw, lim = q < NFX ? nv : m;
-        const char *colb = (q < NFX ? fxb : fub) + (size_t)(unsigned)(8 * nv * (c < lim ? c : lim - 1));    // (a column past n / m: the last one, dropped below)
+    auto f_load8 = [&](const char *base, int nv, int c, int lim, unsigned r8) -> double {                   // 8-byte form: one column
+        const char *colb = base + (size_t)(unsigned)(8 * nv * (c < lim ? c : lim - 1));                    // (a column past n / m: the last one, dropped below)
         return *(const double *)(colb + r8);
     };
-    // One ds_write per column, address = a per-wave base + an immediate (the first form: compare, branch, multiply, add per column — 48
-    // ticks each).  A column past n / m is written as zeros (a wave-uniform select on the data; it was loaded from a clamped address);
-    // rows past n (lanes) are not written: they keep the zero of the initial image.  Only the last fx column of a wave can lie past
-    // the image (c = 64, 65): it goes to the zero padding behind fu.
+    auto f_loadP = [&](const char *fxb, int nv, int q, unsigned r16, int fw) -> d2 {                        // 16-byte form: fx column pair
+        const int j = 3 * q + fw, hv = nv >> 1;
+        const char *colb = fxb + (size_t)(unsigned)(16 * nv * (j < hv ? j : hv - 1));
+        return *(const d2 *)(colb + r16);
+    };
+    // One ds_write per column (pair), address = a per-wave base + an immediate (the first form: compare, branch, multiply, add per column
+    // — 48 ticks each).  A column past n / m is written as zeros (a wave-uniform select on the data; it was loaded from a clamped
+    // address); rows past n (lanes) are not written: they keep the zero of the initial image.  Only the last fx column (pair) of a wave
+    // can lie past the image: it goes to the zero padding behind fu.
     double *const fdst = Fs + lane + LDK * fw;
-    auto f_store = [&](const double (&r)[NFL], int nvs, int fws) {
-        if (rowv) {
+    double *const fdstP = Fs + 2 * pp_ + LDK * (2 * fw + hh_);
+    double pfF[PAIR ? 3 : NFL];                        // 8-byte pieces: [fx columns |] fu columns
+    d2 pfP[PAIR ? NFX : 1];                            // 16-byte pieces: fx column pairs
+    auto f_store = [&](int nvs, int fws) {
+        if constexpr (PAIR) {
+            if (rowvP) {
 #pragma unroll
-            for (int q = 0; q < NFL; ++q) {
-                const int c = 3 * (q < NFX ? q : q - NFX) + fws;
-                const double v = (q < NFX ? c < nvs : c < m) ? r[q] : 0.0;
-                if (q < NFX - 1) fdst[LDK * 3 * q] = v;
-                else if (q == NFX - 1) { double *p_ = c < 16 * NT ? fdst + LDK * 3 * q : Fs + lane + LDK * (FC - 1); *p_ = v; }
-                else fdst[LDK * (NX + 3 * (q - NFX))] = v;
+                for (int q = 0; q < NFX; ++q) {
+                    const int j = 3 * q + fws;
+                    const d2 v = 2 * j < nvs ? pfP[q] : d2{0.0, 0.0};
+                    if (q < NFX - 1) *(d2 *)(fdstP + LDK * 6 * q) = v;
+                    else { double *p_ = j < 8 * NT ? fdstP + LDK * 6 * q : Fs + 2 * pp_ + LDK * (FC - 2 + hh_); *(d2 *)p_ = v; }
+                }
+            }
+            if (rowv) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fdst[LDK * (NX + 3 * q)] = 3 * q + fws < m ? pfF[q] : 0.0;
+            }
+        } else {
+            if (rowv) {
+#pragma unroll
+                for (int q = 0; q < NFL; ++q) {
+                    const int c = 3 * (q < NFX ? q : q - NFX) + fws;
+                    const double v = (q < NFX ? c < nvs : c < m) ? pfF[q] : 0.0;
+                    if (q < NFX - 1) fdst[LDK * 3 * q] = v;
+                    else if (q == NFX - 1) { double *p_ = c < 16 * NT ? fdst + LDK * 3 * q : Fs + lane + LDK * (FC - 1); *p_ = v; }
+                    else fdst[LDK * (NX + 3 * (q - NFX))] = v;
+                }
             }
         }
     };
-    double pfF[NFL];
+    // piece s of the Jacobian of a wave (s < NFL): fx first, then the three fu columns
+    auto f_piece = [&](auto sc, const char *fxb, const char *fub, int nv, unsigned r8, unsigned r16, int fwl) {
+        constexpr int s_ = decltype(sc)::value;
+        if constexpr (s_ >= NFX) pfF[PAIR ? s_ - NFX : s_] = f_load8(fub, nv, 3 * (s_ - NFX) + fwl, m, r8);
+        else if constexpr (PAIR) pfP[s_] = f_loadP(fxb, nv, s_, r16, fwl);
+        else pfF[s_] = f_load8(fxb, nv, 3 * s_ + fwl, nv, r8);
+    };
     if (wv > 0) {
         const char *fxb = (const char *)(fx + nn * (tvF ? N - 2 : 0)), *fub = (const char *)(fu + nm * (tvF ? N - 2 : 0));
-#pragma unroll
-        for (int q = 0; q < NFL; ++q) pfF[q] = f_load(fxb, fub, n, q, row8, fw);
-        f_store(pfF, n, fw);
+        sfor<0, NFL>([&](auto sc) { f_piece(sc, fxb, fub, n, row8, row16, fw); });
+        f_store(n, fw);
     }
     __syncthreads();
     // K_i leaves through the LDS image, 256 consecutive doubles per store: element e = q + m j of K[m, n] (two per thread)
@@ -267,6 +302,17 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
     };
     auto cxx_init = [&](int u) { return d4{cxx_ok(u, 0) ? cxxr[u][0] : 0.0, cxx_ok(u, 1) ? cxxr[u][1] : 0.0, cxx_ok(u, 2) ? cxxr[u][2] : 0.0, cxx_ok(u, 3) ? cxxr[u][3] : 0.0}; };
     if (!CTV) load_cost_w(0);
+    // gradient entries cx[lane], cu of a step (wave 0 adds them to the reduced partial tiles), RAW, requested by the gain wave right
+    // behind their use for the step after: nothing is (re-)initialised at the top of the loop — a `= 0.0` there overwrites a register
+    // that a load of the previous iteration may still target on the paths that never read it, and the compiler answered with
+    // s_waitcnt vmcnt(0) at the loop header: every wave waited for all its stores of the last step (500 ticks per step)
+    double gxc = 0.0, gu[2] = {0.0, 0.0};
+    auto load_grad = [&](int i) {
+        gxc = *(const double *)((const char *)(cx + (size_t)n * i) + row8);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int aq = l4 + 4 * r; gu[r] = cu[(size_t)m * i + (aq < m ? aq : 0)]; }
+    };
+    if (wv == 0) load_grad(N - 2);
     MFP_DECL;
 
     for (int i = N - 2; i >= 0; --i) {
@@ -274,50 +320,50 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
         const int inext = i > 0 ? i - 1 : 0;             // the next Jacobian (the last step reads its own again: no branch around the loads)
         int nv = n;                                      // the address arithmetic of a step stays inside the step: hoisted out of the loop it
         asm volatile("" : "+s"(nv));                     // took 600 scalar registers (spilled through v_writelane / v_readlane)
-        double gxc = 0.0, gu[2] = {0.0, 0.0};            // gradient entries: cx[lane], cu (wave 0)
         char *goutb = (char *)(Vxxg + (size_t)(nv * nv) * (i + 1));
         const char *fxb = (const char *)(fx + (size_t)(nv * nv) * (tvF ? inext : 0)), *fub = (const char *)(fu + (size_t)(nv * m) * (tvF ? inext : 0));
         // side traffic, one piece per product of phase B (waves 1..3): FIRST the next Jacobian (NFL loads), THEN Vxx_{i+1} out — column
         // c = 3 q + wave - 1: an LDS read and (one product later) its store; rows / columns past n repeat the last one (the same value to
         // the same address: no mask, no second base).  Loads in front of the stores: the in-order vmcnt wait of the Jacobian in phase C
         // then never waits for a store to be acknowledged (with the stores in phase A it cost 2 500 ticks per step).
-        constexpr int NVX = (16 * NT + 2) / 3, VD = 3, NSIDE = NFL + 2 * NVX + VD;
-        // (the LDS read of column j sits in slot NFL + 2 j, its store VD slots later: one product is not enough for the LDS round trip;
-        // LDS address = a per-wave base + an immediate, global address = a scalar base per column + row8: no vector instruction; a
-        // column past n reads the zero padding and stores it into the sink)
+        constexpr int NVX = PAIR ? (8 * NT + 2) / 3 : (16 * NT + 2) / 3, VD = 3, NSIDE = 2 * NVX + VD;
+        // (the LDS read of column (pair) j sits in slot 2 j, its store VD slots later: one product is not enough for the LDS round trip;
+        // LDS address = a per-wave base + an immediate, global address = a scalar base per column + the lane offset: no vector
+        // instruction; a column past n reads the zero padding and stores it into the sink)
         double vq[2] = {0.0, 0.0};
-        const double *vsrc = Vs + rowc + LDV * fw;
-        // (the 32-bit lane offset, re-introduced in the block of the products: instruction selection only folds `scalar base + zero-
+        d2 vqP[2] = {d2{0.0, 0.0}, d2{0.0, 0.0}};
+        const double *vsrc = Vs + rowc + LDV * fw, *vsrcP = Vs + (2 * pp_ < n ? 2 * pp_ : n - 2) + LDV * (2 * fw + hh_);    // (rows past n repeat the last pair: the same value to the same address)
+        // (the 32-bit lane offsets, re-introduced in the block of the products: instruction selection only folds `scalar base + zero-
         // extended vector offset` into ONE load when it sees the extension in the same block — hoisted out of the loop as a 64-bit
         // value it became a 64-bit vector add per load)
-        unsigned r8 = row8;
-        asm volatile("" : "+v"(r8));
+        unsigned r8 = row8, r16 = row16;
+        asm volatile("" : "+v"(r8), "+v"(r16));
         int fwv = fw;                                    // (as nv: the 3 q + wave column numbers are not kept in 25 + 22 scalar registers)
         asm volatile("" : "+s"(fwv));
         const char *sinkb = (const char *)a.sink;
+        auto sideA = [&](auto sc) {                                  // phase A (every wave: wave 0 repeats wave 1's loads and never reads them)
+            if constexpr (decltype(sc)::value < NFL) f_piece(sc, fxb, fub, nv, r8, r16, fwv);
+        };
         auto sideB = [&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if constexpr (s < NFL) pfF[s] = f_load(fxb, fub, nv, s, r8, fwv);
-            else if constexpr (s < NSIDE) {
-                constexpr int t = s - NFL;
-                if constexpr ((t & 1) == 0 && (t >> 1) < NVX) vq[(t >> 1) & 1] = vsrc[LDV * 3 * (t >> 1)];
+            constexpr int t = decltype(sc)::value;
+            if constexpr (t < NSIDE) {
+                if constexpr ((t & 1) == 0 && (t >> 1) < NVX) {
+                    if constexpr (PAIR) vqP[(t >> 1) & 1] = *(const d2 *)(vsrcP + LDV * 6 * (t >> 1));
+                    else vq[(t >> 1) & 1] = vsrc[LDV * 3 * (t >> 1)];
+                }
                 if constexpr (t >= VD && ((t - VD) & 1) == 0 && ((t - VD) >> 1) < NVX) {
                     constexpr int j = (t - VD) >> 1;
-                    const int c = 3 * j + fwv;
+                    const int c = (PAIR ? 2 : 1) * (3 * j + fwv);
                     char *colb = c < nv ? goutb + (size_t)(unsigned)(8 * nv * c) : (char *)sinkb;
 #if !(defined(MF2_EXP) && (MF2_EXP & 2))       // timing experiment 2: no Vxx stores (results invalid)
-                    *(double *)(colb + r8) = vq[j & 1];
+                    if constexpr (PAIR) *(d2 *)(colb + r16) = vqP[j & 1];
+                    else *(double *)(colb + r8) = vq[j & 1];
 #endif
                 }
             }
         };
         auto sideB2 = [&](auto sc) { sideB(ic<decltype(sc)::value + KS * NT>{}); };        // continued behind the products of the own tiles
         auto no_side = [](auto) {};
-        if (wv == 0) {                                   // the gradients of this step (wave 0 reduces the partial tiles)
-            gxc = *(const double *)((const char *)(cx + (size_t)nv * i) + row8);        // (raw: the selects are at the use, in phase B)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) { const int aq = l4 + 4 * r; gu[r] = cu[(size_t)m * i + (aq < m ? aq : 0)]; }
-        }
 
         MFP(9);
         // ================= phase A: W[16w.., {u|Vx, 0}] = Vxx·F; partial G[:, u|Vx] from the registers ==========
@@ -326,7 +372,8 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
             const double *ap = Vs + 16 * wv + l15 + LDV * l4;          // A[i][k] = Vxx[16w+i, k]
             const double *bp = Fs + l4 + LDK * l15;                   // B[k][j] = F[k, 16c+j]
             chains<KS, 2, 0, true>([&](auto kc) { return ap[LDV * 4 * decltype(kc)::value]; },
-                                   [&](auto uc, auto kc) { return bp[(decltype(uc)::value == 0 ? LDK * NX : 0) + 4 * decltype(kc)::value]; }, acc2, no_side);
+                                   [&](auto uc, auto kc) { return bp[(decltype(uc)::value == 0 ? LDK * NX : 0) + 4 * decltype(kc)::value]; }, acc2, sideA);
+            static_assert(2 * KS >= NFL, "the Jacobian loads fit behind the products of phase A");
             MFP(0);
             {                                                         // D[row = l4 + 4r][col = l15] -> W0[col + 16 row]
                 double *wp = W0 + l15 + 16 * (16 * wv + l4);
@@ -351,6 +398,8 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
                     if (ti < NT) { pp[(tq * 4 + 2) * PTS] = pg[ti].z; pp[(tq * 4 + 3) * PTS] = pg[ti].w; }     // u tile: rows 0..7 only
                 }
             }
+        } else {
+            sfor<0, NFL>([&](auto sc) { sideA(sc); });              // NT = 3: wave 3 has no row tile, only its share of the Jacobian
         }
         if (regType == 2) {     // (:205-207): QuuF = Quu + λ·fu'fu, Qux_reg = Qux + λ·fu'fx — the λ terms only, added in phase B
             for (int e = tid; e < m8 * NX + m8 * m8; e += NTH) {
@@ -379,6 +428,52 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
                                         [&](auto, auto kc) { return apt[4 * decltype(kc)::value]; }, acc3 + u, [](auto) {});
             }
         };
+        auto phaseC = [&]() __attribute__((always_inline)) {
+        // ================= phase C: + ½(K'Y + Y'K) on the accumulators, tiles mirrored into Vxx (:69-72, :210) ==========
+        {
+            double kA[NSL][2], yA[NSL][2], kB[NSL][2], yB[NSL][2], *qp[NSL], *mp[NSL];
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                const int gj = 16 * sl.tc[u] + l15, gi0 = 16 * sl.ti[u] + l4;
+                qp[u] = Vs + gj + LDV * gi0;                          // Vxx[gi, gj] stored at (gj, gi): lanes contiguous
+                mp[u] = Vs + gi0 + LDV * gj;                          // mirror position (gi, gj)
+                const int ia = l4 + KSD * (16 * sl.ti[u] + l15), ib = l4 + KSD * gj;
+                kA[u][0] = Ks[ia]; kA[u][1] = Ks[ia + 4]; yA[u][0] = Ys[ia]; yA[u][1] = Ys[ia + 4];
+                kB[u][0] = Kh[ib]; kB[u][1] = Kh[ib + 4]; yB[u][0] = Yh[ib]; yB[u][1] = Yh[ib + 4];
+            }
+            // the four products of a tile depend on each other: run the tiles of the wave side by side (an unused slot multiplies
+            // whatever its registers hold and stores nothing)
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) acc3[u] = mf(kA[u][0], yB[u][0], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) acc3[u] = mf(kA[u][1], yB[u][1], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) acc3[u] = mf(yA[u][0], kB[u][0], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) acc3[u] = mf(yA[u][1], kB[u][1], acc3[u]);
+#pragma unroll
+            for (int u = 0; u < NSL; ++u) {
+                if (!sl.valid[u]) continue;
+                // slot 0 is (c, c), slot 1 never diagonal, slot 3 is (0, 0) for NT = 4 and (1, 0) for NT = 3; slot 2: (0, 0) or (w, 0)
+                const bool diag = u == 0 ? true : (u == 1 ? false : (u == 3 ? NT == 4 : sl.ti[u] == sl.tc[u]));
+                // Off-diagonal tiles exist once and are mirrored.  A diagonal tile holds both (i,j) and (j,i), equal up to rounding:
+                // its upper triangle is mirrored in the same way, so the result is exactly symmetric without an exchange
+                // (the reference averages the two halves, (:71-72); the difference is of the order of the rounding error of G).
+                const double av[4] = {acc3[u].x, acc3[u].y, acc3[u].z, acc3[u].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!diag || l4 + 4 * r <= l15) { qp[u][LDV * 4 * r] = av[r]; mp[u][4 * r] = av[r]; }
+                }
+            }
+        }
+        {                                                            // K_i[m, n]: 2 x 256 consecutive doubles (entries past m n repeat the last)
+            double *kgi = Kg + (size_t)(nv * m) * i;
+            const int e1 = tid + NTH < m * nv ? tid + NTH : m * nv - 1, e0 = tid < m * nv ? tid : m * nv - 1;
+#if !(defined(MF2_EXP) && (MF2_EXP & 4))       // timing experiment 4: no K stores
+            kgi[e0] = Ks[kls[0]]; kgi[e1] = Ks[kls[1]];
+#endif
+        }
+        };
         if (wv == 0) {
             // ================= phase B, wave 0: reduce the partial tiles, gains (backward_pass.jl:30-68) =========
             __builtin_amdgcn_s_setprio(3);
@@ -406,6 +501,7 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
                     else Qs[NX + aq] = s + (aq < m ? gu[r] : 0.0);                   // (:204)
                 }
             }
+            load_grad(inext);                                        // the gradients of the NEXT step, a whole step ahead of their use
             wave_sync();
             double H[m8 * m8], R[m8 * m8], kk[m8];
             unsigned clamped = 0u;
@@ -533,6 +629,20 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
             MFP(3);
             if constexpr (NT == 4 && !LIMS) image_tile(ic<2>{});     // (0, 0)
             MFP(4);
+            // The gain wave has its OWN copy of the second barrier and of phase C: the Jacobian registers of the other waves (requested in
+            // phase A, written to the LDS in phase C) are then dead on every path through this wave's code — its 8 x 8 solve is where the
+            // kernel runs out of registers.
+            MFP(5);
+            __syncthreads();
+            MFP(6);
+            if (flag[0] != 0.0) { diverge = i + 1; }                 // block-uniform
+            else {
+                phaseC();
+                MFP(11);
+                MFP(7);
+                __syncthreads();
+                MFP(8);
+            }
         } else {
             // ================= phase B, wave c = 1..3: column tile c of W = Vxx·F in the registers, then its tiles cxx + fx'W ==========
             if (wv < NT) {
@@ -564,72 +674,19 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
             image_tile(ic<2>{});
             if constexpr (has_slot3<NT, LIMS>()) image_tile(ic<3>{});
             MFP(5);
-        }
-        MFP(5);
-        __syncthreads();
-        MFP(6);
-        if (flag[0] != 0.0) { diverge = i + 1; break; }              // block-uniform
-
-        // ================= phase C: + ½(K'Y + Y'K) on the accumulators, tiles mirrored into Vxx (:69-72, :210) ==========
-        {
-            double kA[NSL][2], yA[NSL][2], kB[NSL][2], yB[NSL][2], *qp[NSL], *mp[NSL];
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) {
-                const int gj = 16 * sl.tc[u] + l15, gi0 = 16 * sl.ti[u] + l4;
-                qp[u] = Vs + gj + LDV * gi0;                          // Vxx[gi, gj] stored at (gj, gi): lanes contiguous
-                mp[u] = Vs + gi0 + LDV * gj;                          // mirror position (gi, gj)
-                const int ia = l4 + KSD * (16 * sl.ti[u] + l15), ib = l4 + KSD * gj;
-                kA[u][0] = Ks[ia]; kA[u][1] = Ks[ia + 4]; yA[u][0] = Ys[ia]; yA[u][1] = Ys[ia + 4];
-                kB[u][0] = Kh[ib]; kB[u][1] = Kh[ib + 4]; yB[u][0] = Yh[ib]; yB[u][1] = Yh[ib + 4];
-            }
-            // the four products of a tile depend on each other: run the tiles of the wave side by side (an unused slot multiplies
-            // whatever its registers hold and stores nothing)
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) acc3[u] = mf(kA[u][0], yB[u][0], acc3[u]);
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) acc3[u] = mf(kA[u][1], yB[u][1], acc3[u]);
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) acc3[u] = mf(yA[u][0], kB[u][0], acc3[u]);
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) acc3[u] = mf(yA[u][1], kB[u][1], acc3[u]);
-#pragma unroll
-            for (int u = 0; u < NSL; ++u) {
-                if (!sl.valid[u]) continue;
-                // slot 0 is (c, c), slot 1 never diagonal, slot 3 is (0, 0) for NT = 4 and (1, 0) for NT = 3; slot 2: (0, 0) or (w, 0)
-                const bool diag = u == 0 ? true : (u == 1 ? false : (u == 3 ? NT == 4 : sl.ti[u] == sl.tc[u]));
-                // Off-diagonal tiles exist once and are mirrored.  A diagonal tile holds both (i,j) and (j,i), equal up to rounding:
-                // its upper triangle is mirrored in the same way, so the result is exactly symmetric without an exchange
-                // (the reference averages the two halves, (:71-72); the difference is of the order of the rounding error of G).
-                const double av[4] = {acc3[u].x, acc3[u].y, acc3[u].z, acc3[u].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (!diag || l4 + 4 * r <= l15) { qp[u][LDV * 4 * r] = av[r]; mp[u][4 * r] = av[r]; }
-                }
+            __syncthreads();
+            MFP(6);
+            if (flag[0] != 0.0) { diverge = i + 1; }                 // block-uniform
+            else {
+                phaseC();
+                MFP(11);
+                f_store(nv, fwv);                                    // everybody is past its reads of F (second barrier)
+                MFP(7);
+                __syncthreads();
+                MFP(8);
             }
         }
-        {                                                            // K_i[m, n]: 2 x 256 consecutive doubles (entries past m n repeat the last)
-            double *kgi = Kg + (size_t)(nv * m) * i;
-            const int e1 = tid + NTH < m * nv ? tid + NTH : m * nv - 1, e0 = tid < m * nv ? tid : m * nv - 1;
-#if !(defined(MF2_EXP) && (MF2_EXP & 4))       // timing experiment 4: no K stores
-            kgi[e0] = Ks[kls[0]]; kgi[e1] = Ks[kls[1]];
-#endif
-        }
-        MFP(11);
-#if defined(MF2_EXP) && (MF2_EXP & 8)     // timing experiment 8: the wait for the Jacobian as a stamp of its own (slot "C" then holds the pure wait)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MFP(7);
-#endif
-#if defined(MF2_EXP) && (MF2_EXP & 1)     // timing experiment: the LDS image of F is written without waiting for the loads (results invalid)
-        if (wv > 0) { double z_[NFL]; for (int q = 0; q < NFL; ++q) z_[q] = 0.5; f_store(z_, nv, fwv); }
-#else
-        if (wv > 0) f_store(pfF, nv, fwv);                                // everybody is past its reads of F (second barrier)
-#endif
-        MFP(7);
-        __syncthreads();
-        MFP(8);
-#if defined(MF2_EXP) && (MF2_EXP & 1)
-        if (wv > 0) { for (int q = 0; q < NFL; ++q) asm volatile("" :: "v"(pfF[q])); }
-#endif
+        if (diverge) break;
     }
     MFP_PRINT;
     if (diverge) {   // outputs earlier in time than the failing step are zero (backward_pass.jl:226-229)
@@ -645,23 +702,27 @@ __global__ __launch_bounds__(NTH) void back_pass_mf2_kernel(BPM2Args a)
     if (tid == 0) { a.dV[2 * b] = dV0; a.dV[2 * b + 1] = dV1; a.diverge[b] = diverge; }
 }
 
-template <int NT, bool LIMS, bool CTV>
-static int launch_tv(ddp_handle h, const BPM2Args &a)
+template <int NT, bool LIMS, bool CTV, bool PAIR>
+static int launch_k(ddp_handle h, const BPM2Args &a)
 {
     const size_t shmem = (size_t)oTot * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mf2_kernel<NT, LIMS, CTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DDP_HIP(hipFuncSetAttribute((const void *)back_pass_mf2_kernel<NT, LIMS, CTV, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((back_pass_mf2_kernel<NT, LIMS, CTV>), dim3(a.B), dim3(NTH), shmem, h->stream, a);
+    hipLaunchKernelGGL((back_pass_mf2_kernel<NT, LIMS, CTV, PAIR>), dim3(a.B), dim3(NTH), shmem, h->stream, a);
     DDP_HIP(hipGetLastError());
     return 0;
 }
 
-// time-invariant cost: its terms are loaded once, before the loop
+// time-invariant cost: its terms are loaded once, before the loop; even n: 16-byte pieces of the Jacobian and of Vxx
 template <int NT, bool LIMS>
-static int launch(ddp_handle h, const BPM2Args &a) { return a.cost_tv ? launch_tv<NT, LIMS, true>(h, a) : launch_tv<NT, LIMS, false>(h, a); }
+static int launch(ddp_handle h, const BPM2Args &a)
+{
+    if (a.n & 1) return a.cost_tv ? launch_k<NT, LIMS, true, false>(h, a) : launch_k<NT, LIMS, false, false>(h, a);
+    return a.cost_tv ? launch_k<NT, LIMS, true, true>(h, a) : launch_k<NT, LIMS, false, true>(h, a);
+}
 
 }   // namespace mf2
 
