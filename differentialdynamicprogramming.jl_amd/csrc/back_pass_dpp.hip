@@ -325,7 +325,8 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_dpp_kernel(BPDArgs a)
                     result = boxqp_dev1(H[0], Qu[0], lo[0], up[0], kprev[0], qpo, kk[0], rH1, clamped, iters);
                     use_rh = true;
                 } else {
-                    result = boxqp_dev_ri<m>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);        // (:49)
+                    if constexpr (m == 2) result = boxqp_dev2(H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);       // (:49), straight-line
+                    else result = boxqp_dev_ri<m>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);        // (:49)
                 }
                 fail = (result < 1);                                     // (:53)
             }

@@ -393,7 +393,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
             if (mr <= 2) {                                 // (uniform) the usual sizes as a 2 x 2 problem: half the work of the padded MS x MS one
                 double H2[4] = {Hf[0], Hf[1], Hf[MS], Hf[1 + MS]}, g2[2] = {gq[0], gq[1]}, lo2[2] = {lo[0], lo[1]}, up2[2] = {up[0], up[1]},
                        x02[2] = {kprev[0], kprev[1]}, k2[2], R2[4], ri2[2];
-                result = boxqp_dev_ri<2>(2, H2, g2, lo2, up2, x02, qpo, k2, R2, ri2, clamped, iters);          // (:49), warm start k[:, min(i+1, N-1)]
+                // (:49), warm start k[:, min(i+1, N-1)]; boxqp_dev2: straight-line.  (Tried: the QP as a CALLED function — the limited
+                // instantiations are 140 KB of code, the step being unrolled 4-8 times, against 24 KB without limits; 40 KB with the call,
+                // but 370 ns of call overhead per step: 1.51 -> 1.88 ms at n=10, m=2, N=1000, B=1024, and 1.53 -> 5.2 ms for m = 3.)
+                result = boxqp_dev2(H2, g2, lo2, up2, x02, qpo, k2, R2, ri2, clamped, iters);
 #pragma unroll
                 for (int e = 0; e < MS * MS; ++e) R[e] = 0.0;
 #pragma unroll

@@ -285,6 +285,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_row_kernel(BPRArgs a)
                     result = boxqp_dev1(H[0], Qu[0], lo[0], up[0], kprev[0], qpo, kk[0], rH1, clamped, iters);
                     use_rh = true;
                 } else {
+                    if constexpr (MP == 2) {                             // m = 2: straight-line (boxqp_dev2: no loop for the four rows of the wave to diverge in)
+                        result = mfull ? boxqp_dev2(H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters)
+                                       : boxqp_dev_ri<MP>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);
+                    } else
                     result = mfull ? boxqp_dev_ri<MP>(MP, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters)        // (:49)
                                    : boxqp_dev_ri<MP>(m, H, Qu, lo, up, kprev, qpo, kk, R, ri, clamped, iters);
                 }

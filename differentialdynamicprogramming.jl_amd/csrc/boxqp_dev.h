@@ -269,6 +269,140 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
     return boxqp_dev_ri<MM>(m, H, g, lower, upper, x0, o, x, R, ri, clamped, iters);
 }
 
+// m = 2 in STRAIGHT-LINE code (src/boxQP.jl:58-169 for the reference's usual flow; everything else falls into boxqp_dev_ri<2>).
+//
+// The generic loop is a serial chain: per projected-Newton iteration ~55 dependent fp64 instructions (gradient, clamp tests, masked
+// Cholesky with two reciprocal square roots, two triangular solves, line-search value, Armijo test) and eight wave-uniform branches —
+// 1.1 us of a 1.6 us backward step with limits at one wave per trajectory, and in the 16-lane-row kernels the four trajectories of a
+// wave serialise their different paths through it.  For m = 2 almost all of that work does not depend on the iterate:
+//   * the masked factorisation depends on the CLAMPED SET only: three candidates (nothing clamped, coordinate 0, coordinate 1; both
+//     clamped is exit 6 before any factorisation) — computed up front, side by side, from rsqrt(H00), rsqrt(H11), rsqrt(H11 - R01^2);
+//   * a clamped coordinate sits exactly ON a bound (boxQP.jl:88-94 tests x == lower / upper), so the right-hand side g_f + H_fc x_c of the
+//     Newton system takes one of five values (free set {0,1}; {1} with x0 at lower / upper; {0} with x1 at lower / upper): the five
+//     solves are done up front as well.
+// What is left per iteration is: gradient (2 deep), clamp tests, a select among the candidates, search = -sol - x, s'g, the projected
+// step and its value, the Armijo test — ~19 dependent instructions.  Three iterations are unrolled, each left as soon as the loop would
+// leave (the reference's flow: iteration 1 factorises and steps, iteration 2 or 3 finds the same clamped set and leaves through exit
+// 4 / 5 / 6; the first form ran all three under a predicate and was SLOWER than the loop on the bench shapes, whose controls sit on their
+// bounds at almost every step: exit 6 in the first iteration, tested here before anything else is computed);
+// a back-tracking line search (Armijo fails at step 1) or a fourth iteration hands the WHOLE problem to the generic routine, which
+// starts from x0 again — so every case it does not finish itself is the generic result by construction.  Same formulas, same order of
+// sums as boxqp_dev_ri<2>; results, result codes, clamped sets, factors and iteration counts are those of the loop.
+__device__ __forceinline__ int boxqp_dev2(const double (&H)[4], const double (&g)[2], const double (&lower)[2], const double (&upper)[2],
+                                          const double (&x0)[2], const QPOptsDev &o, double (&x)[2], double (&R)[4], double (&ri)[2],
+                                          unsigned &clamped, int &iters)
+{
+#ifdef DDP_QP2_OFF       // A/B builds: the generic loop everywhere
+    return boxqp_dev_ri<2>(2, H, g, lower, upper, x0, o, x, R, ri, clamped, iters);
+#endif
+    if (o.maxIter < 5) return boxqp_dev_ri<2>(2, H, g, lower, upper, x0, o, x, R, ri, clamped, iters);      // (the unrolled part assumes iterations 1..4 are allowed)
+    const double H0 = H[0], H1 = H[1], H2 = H[2], H3 = H[3], g0 = g[0], g1 = g[1], lo0 = lower[0], lo1 = lower[1], up0 = upper[0], up1 = upper[1];
+    double xa = ddp_clamp(x0[0], lo0, up0), xb = ddp_clamp(x0[1], lo1, up1);                             // :58
+    // ---- the cheapest way out first: the warm start sits on the bounds and the gradient pushes outward — exit 6 in iteration 1
+    // (:98-101), before anything is factorised (with tight limits this is most steps of a backward pass)
+    // (no lambdas in this routine: a closure that captures the locals by reference keeps them in memory, and the selects among the
+    // candidates became selects among POINTERS into scratch — 9.7 ms instead of 1.6 for the first build)
+    double gr0, gr1;
+    bool c0, c1;
+#define DDP_QP2_GRAD_CLAMP()                                                                                   \
+    do {                                                                                                        \
+        double s_ = 0.0; s_ += H0 * xa; s_ += H2 * xb; gr0 = g0 + s_;                            /* :85 */     \
+        s_ = 0.0; s_ += H1 * xa; s_ += H3 * xb; gr1 = g1 + s_;                                                  \
+        c0 = ((xa == lo0) && (gr0 > 0)) || ((xa == up0) && (gr0 < 0));                        /* :88-94 */     \
+        c1 = ((xb == lo1) && (gr1 > 0)) || ((xb == up1) && (gr1 < 0));                                          \
+    } while (0)
+#define DDP_QP2_VAL(res_, a0_, a1_)                                                          /* qp_value<2> */ \
+    do {                                                                                                        \
+        double xg_ = 0.0; xg_ += (a0_) * g0; xg_ += (a1_) * g1;                                                 \
+        double q_ = 0.0, t_ = 0.0;                                                                              \
+        t_ += (0.5 * (a0_)) * H0; t_ += (0.5 * (a1_)) * H1; q_ += t_ * (a0_);                                   \
+        t_ = 0.0; t_ += (0.5 * (a0_)) * H2; t_ += (0.5 * (a1_)) * H3; q_ += t_ * (a1_);                         \
+        res_ = xg_ + q_;                                                                                        \
+    } while (0)
+#define DDP_QP2_SOLVE(ria_, rib_, r01_, b0i_, b1i_, s0_, s1_)                          /* chol_solve_ri<2> */ \
+    do {                                                                                                        \
+        double b0_ = (b0i_) * (ria_), t2_ = (b1i_); t2_ -= (r01_) * b0_; double b1_ = t2_ * (rib_);             \
+        b1_ = b1_ * (rib_); t2_ = b0_; t2_ -= (r01_) * b1_; b0_ = t2_ * (ria_);                                 \
+        s0_ = b0_; s1_ = b1_;                                                                                   \
+    } while (0)
+    DDP_QP2_GRAD_CLAMP();
+    if (c0 && c1) {
+        x[0] = xa; x[1] = xb; ri[0] = ri[1] = 0.0; R[0] = R[1] = R[2] = R[3] = 0.0;
+        clamped = 3u; iters = 1;
+        return 6;
+    }
+    // ---- candidates that do not depend on the iterate (chol_masked_ri<2> for the masks 0, 1, 2; chol_solve_ri<2> on the five right-hand sides)
+    const double rone = ddp_rsqrt(1.0);
+    const double r0 = ddp_rsqrt(H0), r1b = ddp_rsqrt(H3);
+    const double R00 = H0 * r0, R01 = H2 * r0;
+    double a11 = H3;
+    a11 -= R01 * R01;
+    const double r1 = ddp_rsqrt(a11);
+    const bool bad00 = !(H0 > 0.0), bad11a = !(a11 > 0.0), bad11b = !(H3 > 0.0);
+    // factor of mask c: ri0, ri1, R00, R01, R11 and its failure (scalars, not arrays: a select between two array elements becomes a
+    // select between two POINTERS, and the arrays — with the options struct captured by the lambdas — went to scratch memory: 9.7 ms
+    // instead of 1.6 for the first build of this routine)
+    const double F0a = r0, F0b = r1, F0c = R00, F0d = R01, F0e = a11 * r1;
+    const double F1a = rone, F1b = r1b, F1c = 1.0 * rone, F1d = 0.0 * rone, F1e = H3 * r1b;
+    const double F2a = r0, F2b = rone, F2c = R00, F2d = 0.0 * r0, F2e = 1.0 * rone;
+    const bool fail0 = bad00 || bad11a, fail1 = bad11b, fail2 = bad00;
+    double S0a, S0b, S1lo, S1up, S2lo, S2up, dmy;
+    DDP_QP2_SOLVE(F0a, F0b, F0d, g0 + 0.0, g1 + 0.0, S0a, S0b);                             // nothing clamped: rhs = g + 0
+    DDP_QP2_SOLVE(F1a, F1b, F1d, 0.0, g1 + fma(H1, lo0, 0.0), dmy, S1lo);                   // coordinate 0 clamped at its lower / upper bound
+    DDP_QP2_SOLVE(F1a, F1b, F1d, 0.0, g1 + fma(H1, up0, 0.0), dmy, S1up);
+    DDP_QP2_SOLVE(F2a, F2b, F2d, g0 + fma(H2, lo1, 0.0), 0.0, S2lo, dmy);                   // coordinate 1 clamped
+    DDP_QP2_SOLVE(F2a, F2b, F2d, g0 + fma(H2, up1, 0.0), 0.0, S2up, dmy);
+    // ---- the iterations; `done` is the same in every lane that works on this problem, so the early ways out are cheap
+    double value, oldvalue = 0.0;                                                                     // :63
+    DDP_QP2_VAL(value, xa, xb);
+    int result = 0, iter = 1;
+    unsigned cl = 0u;
+    double Fca = 0.0, Fcb = 0.0, Fcc = 0.0, Fcd = 0.0, Fce = 0.0;      // the factor in use (zeros: nothing factorised yet, as the loop returns it)
+    bool slow = false;
+    const double mg2 = o.minGrad * o.minGrad, mri = o.minRelImprove, arm = o.Armijo;
+#pragma unroll
+    for (int it = 1; it <= 4; ++it) {
+        if (it > 1) {
+            if ((oldvalue - value) < mri * fabs(oldvalue)) { result = 4; break; }                     // :76-79
+            if (it == 4) { slow = true; break; }                                                      // a fourth iteration: the generic loop
+            DDP_QP2_GRAD_CLAMP();
+        }
+        oldvalue = value;
+        const unsigned newc = (c0 ? 1u : 0u) | (c1 ? 2u : 0u), oldc = cl;
+        cl = newc;
+        if (newc == 3u) { result = 6; break; }                                                        // :98-101
+        if (it == 1 || oldc != newc) {                                                                // :104-117
+            Fca = newc == 0u ? F0a : (newc == 1u ? F1a : F2a); Fcb = newc == 0u ? F0b : (newc == 1u ? F1b : F2b);
+            Fcc = newc == 0u ? F0c : (newc == 1u ? F1c : F2c); Fcd = newc == 0u ? F0d : (newc == 1u ? F1d : F2d);
+            Fce = newc == 0u ? F0e : (newc == 1u ? F1e : F2e);
+            if (newc == 0u ? fail0 : (newc == 1u ? fail1 : fail2)) break;                              // PosDefException -> result 0
+        }
+        double gn = 0.0; gn += c0 ? 0.0 : gr0 * gr0; gn += c1 ? 0.0 : gr1 * gr1;                       // :120-124
+        if (gn < mg2) { result = 5; break; }
+        // :127-129 with the solves done up front: the Newton point of the face
+        const double sol0 = newc == 0u ? S0a : (xb == lo1 ? S2lo : S2up);
+        const double sol1 = newc == 0u ? S0b : (xa == lo0 ? S1lo : S1up);
+        const double se0 = c0 ? 0.0 : (-sol0 - xa), se1 = c1 ? 0.0 : (-sol1 - xb);
+        double sdotg = 0.0; sdotg += se0 * gr0; sdotg += se1 * gr1;                                   // :132
+        if (sdotg >= 0) break;                                                                        // :133-135 (result stays 0)
+        const double xca = ddp_clamp(xa + 1.0 * se0, lo0, up0), xcb = ddp_clamp(xb + 1.0 * se1, lo1, up1);   // :138-151, step = 1
+        double vc;
+        DDP_QP2_VAL(vc, xca, xcb);
+        if ((vc - oldvalue) > arm * (1.0 * sdotg)) { slow = true; break; }                             // the line search would back-track: the generic loop
+        xa = xca; xb = xcb; value = vc;                                                               // :161-163
+        iter += 1;
+    }
+#undef DDP_QP2_GRAD_CLAMP
+#undef DDP_QP2_VAL
+#undef DDP_QP2_SOLVE
+    if (__builtin_expect(slow, 0)) return boxqp_dev_ri<2>(2, H, g, lower, upper, x0, o, x, R, ri, clamped, iters);
+    x[0] = xa; x[1] = xb;
+    ri[0] = Fca; ri[1] = Fcb; R[0] = Fcc; R[1] = 0.0; R[2] = Fcd; R[3] = Fce;
+    clamped = cl;
+    iters = iter;
+    return result;
+}
+
 // m = 1 (the reference's own limited case, pendcart): the same control flow as boxqp_dev<1> written on scalars and
 // without divisions or square roots —  (g/R)/R with R = sqrt(H) becomes g·(1/H) (v_rcp_f64 + 2 Newton steps), the
 // gradient norm sqrt(grad²) is |grad|, and the Armijo test (vc - old)/(step·sdotg) < Armijo is multiplied through by

@@ -416,7 +416,9 @@ __global__ __launch_bounds__(DDP_WAVE) void boxqp_kernel(int m, int count, const
     }
     unsigned clamped;
     int iters;
-    const int res = boxqp_dev<MM>(m, H, g, lo, up, x0, o, x, R, clamped, iters);
+    int res;
+    if constexpr (MM == 2) { double ri2[2]; res = boxqp_dev2(H, g, lo, up, x0, o, x, R, ri2, clamped, iters); }     // the straight-line form of the backward kernels
+    else res = boxqp_dev<MM>(m, H, g, lo, up, x0, o, x, R, clamped, iters);
     resg[t] = res;
     // compact the masked factor to the leading nfree x nfree block (the reference's Hfree)
     int pos[MM], nf = 0;
