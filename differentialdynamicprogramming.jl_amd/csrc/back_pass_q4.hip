@@ -60,6 +60,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double mm(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+#ifdef Q4_COUNT_SLOW
+__device__ unsigned long long q4_slow_count = 0ull, q4_step_count = 0ull, q4_slow_why[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
 
 // (a, b) -> (x, y): x = rows [a0, b0, a2, b2], y = rows [a1, b1, a3, b3] of the 16-lane rows (v_permlane16_swap per dword)
 __device__ __forceinline__ void row_swap(double a, double b, double &x, double &y)
@@ -100,16 +103,42 @@ __device__ __forceinline__ void boxqp1_two_iterations(double H, double g, double
     rH = ddp_rcp_nr(H);
     const double search = -(g * rH) - x1;                                                       // :127-129
     const double sdotg = search * grad1;                                                        // :132
-    const double xc = clampf(x1 + search, lower, upper);                                        // step = 1 (:138-141)
-    const double vc = val(xc);
-    // iteration 1 runs to its end with step 1: H > 0 (:111), |grad| >= minGrad (:120), sdotg < 0 (:133), Armijo holds (:142)
-    const bool plain = bool((H > 0.0) & !(fabs(grad1) < o.minGrad) & (sdotg < 0) & !((vc - v1) > o.Armijo * sdotg));
+    double xc = clampf(x1 + search, lower, upper);                                              // step = 1 (:138-141)
+    double vc = val(xc);
+    // iteration 1 runs to its end: H > 0 (:111), |grad| >= minGrad (:120), sdotg < 0 (:133), and the line search accepts a step (:142-151)
+    const bool descent = bool((H > 0.0) & !(fabs(grad1) < o.minGrad) & (sdotg < 0));
+    bool need = bool(descent & ((vc - v1) > o.Armijo * sdotg));                                 // Armijo fails at step 1
+    // The back-tracking line search (:142-151) in closed form for the case that makes it long.  It is not rare: when the Newton point lies
+    // beyond a bound the projected step is shorter than the model promises, Armijo fails, and at BASELINE config 3 (pendulum, limits +-5)
+    // 18 % of all trajectory-steps — at four trajectories per wave about half of the wave-steps — left through here into the generic
+    // loop, many of them for TENS of step sizes (a warm start near the bound: 0.6^k has to fall to ~(v1 - v(bound)) / (Armijo |s'g|)),
+    // 285 ns on top of a 360 ns step (profiles/microbench/q4c_chain_floor.hip, profiles/q4_slow_count.py).  As long as the ray
+    // x1 + step·search stays outside the box the projected point IS the bound and its value does not change with the step, so the loop
+    // ends at x = bound as soon as step <= s* = (v1 - v(bound)) / (Armijo |s'g|), whatever the number of step sizes — provided it gets
+    // there before the ray re-enters the box at s_in = |bound - x1| / |search|.  The accepted step is the largest 0.6^k <= s*, which is
+    // > 0.6 s*: 0.6 s* >= s_in is sufficient (tested with 0.59 and without divisions; what is nearer goes to the generic loop, as do a
+    // value at the bound that is no improvement and step sizes near minStep).
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+        const double bnd = search > 0 ? upper : lower;
+        const double vbn = val(bnd);
+        const double dv = v1 - vbn, ps = -(o.Armijo * sdotg), dist = fabs(bnd - x1), as = fabs(search);
+        const bool closed = bool(need & (xc == bnd) & (dv > 0.0) & (((0.59 * dv) * as) >= (dist * ps)) & (dv > 1e-21 * ps));
+        xc = closed ? bnd : xc; vc = closed ? vbn : vc;
+        need = bool(need & !closed);
+    }
+    const bool plain = bool(descent & !need);
     // second iteration
     const bool relimp = (v1 - vc) < o.minRelImprove * fabs(v1);                                 // result 4 (:78-81), free set of iteration 1
     const double grad2 = g + H * xc;
     const bool c2 = bool(((xc == lower) & (grad2 > 0)) | ((xc == upper) & (grad2 < 0)));        // result 6
     const bool small2 = fabs(grad2) < o.minGrad;                                                // result 5
     slow = bool(!c1 & !(plain & (relimp | c2 | small2)));
+#ifdef Q4_COUNT_SLOW      // why: [0] H <= 0, [1] |grad| < minGrad at the warm start, [2] no descent, [3] Armijo back-off, [4] a third iteration
+    if (slow && (threadIdx.x & 15) == 0) {
+        const int why = !(H > 0.0) ? 0 : (fabs(grad1) < o.minGrad ? 1 : (!(sdotg < 0) ? 2 : (((vc - v1) > o.Armijo * sdotg) ? 3 : 4)));
+        atomicAdd(&q4_slow_why[why], 1ull);
+    }
+#endif
     x = c1 ? x1 : xc;
     clamped = bool(c1 | (!relimp & c2));
 }
@@ -120,6 +149,7 @@ struct Q4Out { double Vn, Kc, vx, kk, Quu; };
 struct Q4Par { double lam, limlo, limhi; bool nolims; double ieta; };
 
 struct Q4NoMid { __device__ __forceinline__ void operator()() const {} };
+
 
 // `mid` runs once the matrix instructions of the step have been issued (the LDS-chunk kernel puts the LDS writes of the PREVIOUS
 // step there: behind the products their latency costs nothing, in front of them it delays the first product)
@@ -164,6 +194,10 @@ __device__ __forceinline__ void q4_step(int i, const Q4In &o, Q4State &s, Q4Out 
         bool slow;
         boxqp1_two_iterations(QuuF, Qu, lo, up, s.kprev, qpo, kk, rH, clamped, slow);     // :49 (warm start k[:, min(i+1,N-1)])
         fail = false;
+#ifdef Q4_COUNT_SLOW      // profiling builds: how often the two-iteration form hands a step to the generic loop (ddp_q4_slow_count)
+        if (slow && s.diverge == 0 && (threadIdx.x & 15) == 0) atomicAdd(&q4_slow_count, 1ull);
+        if ((threadIdx.x & 15) == 0) atomicAdd(&q4_step_count, 1ull);
+#endif
         if (__builtin_expect(slow && s.diverge == 0, 0)) {                           // rare: the generic loop decides
             unsigned cl; int iters;
             const int result = boxqp_dev1(QuuF, Qu, lo, up, s.kprev, qpo, kk, rH, cl, iters);
@@ -1052,3 +1086,13 @@ int ddp_launch_back_pass_gps_q4(ddp_handle h, const ddp_bp_desc *d, const double
     DDP_HIP(hipGetLastError());
     return 0;
 }
+
+#ifdef Q4_COUNT_SLOW
+extern "C" int ddp_q4_slow_count(unsigned long long *out2)      /* out2: 7 entries */
+{
+    if (hipMemcpyFromSymbol(&out2[0], HIP_SYMBOL(q4_slow_count), 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&out2[1], HIP_SYMBOL(q4_step_count), 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&out2[2], HIP_SYMBOL(q4_slow_why), 40) != hipSuccess) return -1;
+    return 0;
+}
+#endif
