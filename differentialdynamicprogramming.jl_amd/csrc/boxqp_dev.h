@@ -388,7 +388,19 @@ __device__ __forceinline__ int boxqp_dev2(const double (&H)[4], const double (&g
         const double xca = ddp_clamp(xa + 1.0 * se0, lo0, up0), xcb = ddp_clamp(xb + 1.0 * se1, lo1, up1);   // :138-151, step = 1
         double vc;
         DDP_QP2_VAL(vc, xca, xcb);
-        if ((vc - oldvalue) > arm * (1.0 * sdotg)) { slow = true; break; }                             // the line search would back-track: the generic loop
+        if ((vc - oldvalue) > arm * (1.0 * sdotg)) {
+            // The line search backs off (:142-151).  Usual cause: the Newton point lies beyond the bounds, the projected step is shorter than
+            // the model promises.  While every moving coordinate of the ray x + step·search stays outside its bound the projected point — and
+            // its value — do not change with the step, so the loop accepts exactly this point as soon as step <= s* = (old - vc) / (Armijo
+            // |s'g|), after however many step sizes (tens, when the iterate starts near the bound: with tight limits that was the time of a
+            // limited backward step; the m = 1 form in back_pass_q4.hip: 18 % of the steps of BASELINE config 3).  The accepted step is the
+            // largest 0.6^k <= s*, which is > 0.6 s*: each moving coordinate must re-enter the box below that (0.59, no divisions).
+            // Everything else — a coordinate that moves inside the box, no improvement at the projected point — is the generic loop's.
+            const double dv = oldvalue - vc, ps = -(arm * sdotg);
+            const bool pin0 = (se0 == 0.0) || ((xca == (se0 > 0 ? up0 : lo0)) && ((0.59 * dv) * fabs(se0) >= fabs(xca - xa) * ps));
+            const bool pin1 = (se1 == 0.0) || ((xcb == (se1 > 0 ? up1 : lo1)) && ((0.59 * dv) * fabs(se1) >= fabs(xcb - xb) * ps));
+            if (!(pin0 && pin1 && dv > 1e-21 * ps && o.stepDec == 0.6 && o.minStep <= 1e-22)) { slow = true; break; }
+        }
         xa = xca; xb = xcb; value = vc;                                                               // :161-163
         iter += 1;
     }
