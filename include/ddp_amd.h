@@ -99,8 +99,8 @@ typedef struct {
  *          (diverge: 0 ok, else the 1-based failing time index; outputs earlier in time than the
  *          failing step are zero like the reference's zero-initialised arrays)
  * shapes : m <= DDP_MAX_M (8); n <= 64 (kernel families by size: n = 10/m = 2, n = 4/m = 1, any n <= 12/m <= 4, n <= 14/m <= 4, n <= 32/m <= 8,
- *          n = 64/m = 8; 32 < n < 64 runs embedded in the (64, 8) problem through a pad buffer of the handle — zero rows / columns, an
- *          identity block of cuu — or, beyond 48 GB of padded copies, in the next even sizes).  Larger n or m: return code < 0.
+ *          32 < n <= 64 with m <= 8 at run time on the matrix-core kernel back_pass_mf2: padded to 16-row tiles and 8 controls inside the LDS
+ *          only, no scratch on the handle).  Larger n or m: return code < 0.
  *          back_pass_gps: n <= 32.                                                                     */
 int ddp_back_pass_f64_dev(ddp_handle h, const ddp_bp_desc *d,
                           const double *cx, const double *cu, const double *cxx, const double *cxu,

@@ -6,7 +6,7 @@
    C5  one pass of the KL-constrained iteration (C3 + KL): back_pass_gps + forward_pass + forward_covariance + kl_div_wiki, B=4096
    offA / offB  shapes BASELINE does not name (the reference's back_pass is size-generic, backward_pass.jl:162-252): n=12 m=3 N=500
        B=2048 with per-trajectory time-varying dynamics (one-tile matrix-core kernel); n=6 m=2 N=1000 B=4096 LTI with control limits (padded row kernel)
-   offE  n=48 m=6 N=300 B=1024: between the mid-size kernels and n = 64 (embedded in the (64, 8) matrix-core kernel; forward_big_kernel)
+   offE  n=48 m=6 N=300 B=1024: between the mid-size kernels and n = 64 (back_pass_mf2 with 3 tiles of 16 states; forward_big_kernel)
    offL  the C2 shape (n=10 m=2 N=1000 B=1024, LTI) with control limits +-0.05 (back_pass_mxg<LIMS>)
    offC / offD  n=24 m=4 and n=32 m=8, N=300, B=1024, per-trajectory time-varying dynamics: the mid-size kernels (back_pass_mid.hip, forward_mid_kernel)
 Prints one JSON line per config.  Informational; the graded line is bench.py's."""
@@ -365,7 +365,7 @@ if __name__ == "__main__":
                   int(os.environ.get("DDP_OFFC_B", 1024)), os.environ.get("DDP_OFFC_LTI") != "1", False)
     if "offL" in which:                                          # the C2 shape WITH control limits (iLQG(...; lims) on the LQ example): box-QP on the one-tile kernel
         off_shape("offL", 10, 2, 1000, 1024, False, True)
-    if "offE" in which:                                          # 32 < n < 64: the backward pass embedded in the (64, 8) matrix-core kernel (23 GB of padded copies here)
+    if "offE" in which:                                          # 32 < n < 64: the run-time-sized matrix-core kernel back_pass_mf2 (round 5: embedded in the (64, 8) kernel through 23 GB of padded copies)
         off_shape("offE", 48, 6, 300, 1024, True, False)
     if "offD" in which:                                          # the 8 x 8 control system (4 < m <= 8): one coordinate per lane, gains on the matrix cores
         off_shape("offD", 32, 8, 300, 1024, True, False)
