@@ -820,7 +820,7 @@ static int launch_back_pass_inner(ddp_handle h, const ddp_bp_desc *d, const doub
         if (rc <= 0) { h->last_kernel[0] = "back_pass_mfma_kernel"; return rc; }
     }
     if (force != 'b' && force != 'g') {
-        // (rc 2: the exact (64, 8) shape with REAL control limits — lims[1,1] <= lims[1,2], which the launcher has just looked at — stays
+        // (rc 2: the exact (64, 8) shape with a time-varying cost, or with REAL control limits — lims[1,1] <= lims[1,2], which the launcher has just looked at — stays
         // on the round-5 kernel by default: its gain wave runs the 8 x 8 box-QP in 16 400 ticks per step against 21 200 in the
         // run-time-sized kernel, 10.8 vs 13.3 ms at C4 with limits; DDP_BACKPASS=new forces the new one)
         const int rc = ddp_launch_back_pass_mf2(h, d, cx, cu, cxx, cxu, cuu, fx, fu, lambda, lims, u, active, K, k, Quu, Vx, Vxx, dV, diverge, force != 'n');

@@ -10,6 +10,9 @@ int ddp_launch_back_pass_mf2(ddp_handle h, const ddp_bp_desc *d, const double *c
 {
     if (d->n <= 32 || d->n > mf2::NX || d->m < 1 || d->m > mf2::MX) return 1;
     const int nt = (d->n + 15) / 16;                 // 3 or 4 tiles of 16 states
+    // the exact (64, 8) shape with a time-varying cost (SURVEY 8d's C4 layout) is 3-4 % faster on the round-5 kernel (8.42 vs 8.66-8.78 ms
+    // at N = 256, B = 1 024: this kernel fetches its cost tiles with run-time strides at the top of every step)
+    if (defer_64x8_lims && d->n == 64 && d->m == 8 && d->cost_tv && !d->has_lims) return 2;
     BPM2Args a;
     a.n = d->n; a.m = d->m; a.N = d->N; a.B = d->B;
     a.fx_tv = d->fx_tv; a.fx_batched = d->fx_batched; a.cost_tv = d->cost_tv; a.cost_batched = d->cost_batched;

@@ -269,8 +269,8 @@ def test_full_size_c4_pass_and_solves(ddp):
 
 
 # ------------------------------------------------------------------------------------------------ C4 in the a3 layout
-@pytest.mark.parametrize("lims_on,regType", [(False, 1), (False, 2), (True, 1)])
-def test_full_size_c4_a3_layout_tv_cost(ddp, lims_on, regType):
+@pytest.mark.parametrize("lims_on,regType,impl", [(False, 1, "auto"), (False, 2, "auto"), (True, 1, "auto"), (False, 1, "new"), (True, 2, "new")])
+def test_full_size_c4_a3_layout_tv_cost(ddp, monkeypatch, lims_on, regType, impl):
     """SURVEY 8(d)'s C4 as the reference's a3 method reads it (backward_pass.jl:179-215): cxx[n,n,N], cxu[n,m,N], cuu[m,m,N] time-varying
     AND per trajectory beside per-trajectory time-varying fx, fu — n=64, m=8, N=256, B=256 (the `CTV = true` instantiation of the n = 64
     matrix-core kernel at the full horizon; 2.1 GB of cost Hessians built on the device); 24 trajectories against the oracle"""
@@ -279,9 +279,12 @@ def test_full_size_c4_a3_layout_tv_cost(ddp, lims_on, regType):
     from ddp_amd import _lib
     from oracle import oracle_ctypes as oc
     n, m, N, B = 64, 8, 256, 256
+    if impl != "auto":
+        monkeypatch.setenv("DDP_BACKPASS", impl)                             # "new": the run-time-sized kernel also at the exact (64, 8) shape
     dev = torch.device("cuda", 0)
     L = _lib.lib()
     h = ddp.default_handle()
+    h.raw
     p_ = lambda t: C.c_void_p(t.data_ptr())                                  # noqa: E731
     f64 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))).to(dev)   # noqa: E731
     empty = lambda cnt, dt=torch.float64: torch.empty(int(cnt), dtype=dt, device=dev)     # noqa: E731
@@ -311,7 +314,7 @@ def test_full_size_c4_a3_layout_tv_cost(ddp, lims_on, regType):
     _lib.check(L.ddp_back_pass_f64_dev(h.raw, C.byref(desc), p_(dcx), p_(dcu), p_(dcxx), p_(dcxu), p_(dcuu), p_(dA), p_(dB), p_(dlam),
                                        p_(dl) if lims_on else None, p_(du), None, p_(dK), p_(dk), p_(dQuu), p_(dVx), p_(dVxx), p_(ddV), p_(ddiv)))
     torch.cuda.synchronize()
-    assert h.last_kernel(0) == ("back_pass_mfma_kernel" if lims_on else "back_pass_mf2_kernel"), h.last_kernel(0)
+    assert h.last_kernel(0) == ("back_pass_mf2_kernel" if impl == "new" else "back_pass_mfma_kernel"), h.last_kernel(0)      # (64, 8) with a time-varying cost: the round-5 kernel by default
     assert int(ddiv.sum().item()) == 0
     Vxx = dVxx.reshape(B, N, n, n)
     assert torch.equal(Vxx, Vxx.transpose(2, 3))                             # exactly symmetric over the whole batch

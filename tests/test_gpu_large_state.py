@@ -58,8 +58,8 @@ def test_back_pass_large(ddp, monkeypatch, n, m, impl, tv_cost, regType, lims):
     div, pol, Vx, Vxx, dV = ddp.back_pass(cx, cu, cxx, cxu, cuu, fx, fu, lam, regType, L, None, u)
     from ddp_amd import _lib
     want = {"auto": "back_pass_mf2_kernel", "new": "back_pass_mf2_kernel", "old": "back_pass_mfma_kernel", "big": "back_pass_big_kernel"}[impl]
-    if impl == "auto" and lims and (n, m) == (64, 8):
-        want = "back_pass_mfma_kernel"             # the exact shape with limits: the round-5 kernel's gain wave is the faster one (back_pass.hip)
+    if impl == "auto" and (lims or tv_cost) and (n, m) == (64, 8):
+        want = "back_pass_mfma_kernel"             # the exact shape with limits or a time-varying cost: the round-5 kernel is the faster one (back_pass.hip)
     assert _lib.default_handle().last_kernel(0) == want or (impl == "big" and n % 2), _lib.default_handle().last_kernel(0)      # (odd sizes forced onto the vector kernel: the padded launcher)
     assert np.array_equal(Vxx, np.transpose(Vxx, (1, 0, 2, 3)))
     for b in range(B):
