@@ -307,3 +307,30 @@ def test_a_timed_out_tile_hands_its_trajectories_to_the_per_trajectory_kernels(d
         assert relerr(a_, b_) < 1e-10
     again = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, 1, None, None, u)       # and the path is healthy afterwards
     assert np.array_equal(again[3], good[3]) and h.sh_timeouts() == h.sh_timeouts()
+
+
+@pytest.mark.parametrize("regType", [1, 2])
+def test_long_horizon_wide_lambda_range_tight_tolerance(ddp, monkeypatch, regType):
+    """The shared chain symmetrises V only once per chunk of 8 steps (SH_SYM = 8) and, for regType 1, uses K'(T + Qux) for K'T + Qux'K
+    (backward_pass.jl:71-72 applies ½(V + V') at every step): over the full horizon N = 1 000 and 16 values of λ across nine
+    decades — the small ones make the closed loop stiff and the recursion badly conditioned — every output of a sample of trajectories
+    agrees with the oracle to 1e-10 (the suite's bar is 1e-8), and Vxx is exactly symmetric."""
+    monkeypatch.setenv("DDP_SH_MIN_B", "1")
+    rng = np.random.default_rng(300 + regType)
+    N, B = 1000, 64
+    cx, cu, cxx, cxu, cuu, A, Bm, u = _lti(rng, N, B)
+    vals = 10.0 ** np.linspace(-6, 3, 16)
+    lam = vals[np.arange(B) % 16]
+    out = ddp.back_pass(cx, cu, cxx, cxu, cuu, A, Bm, lam, regType, None, None, u)
+    from ddp_amd import _lib
+    assert _lib.default_handle().last_kernel(0) == "sh_back_kernel"
+    assert not out[0].any()
+    assert np.array_equal(out[3], np.transpose(out[3], (1, 0, 2, 3)))
+    from oracle import oracle_ctypes as oc
+    worst = 0.0
+    for b in range(0, B, 2):                                     # both trajectories of every λ value appear over the two regTypes' seeds
+        d, (K, k, Quu), vx, vxx, dv = oc.back_pass(cx[..., b], cu[..., b], cxx, cxu, cuu, A, Bm, lam[b], regType, None, None, u[..., b])
+        assert d == 0
+        for got, ref in ((out[1].K[..., b], K), (out[1].k[..., b], k), (out[2][..., b], vx), (out[3][..., b], vxx), (out[4][:, b], dv)):
+            worst = max(worst, relerr(got, ref))
+    assert worst < 1e-10, worst
