@@ -42,10 +42,20 @@ constexpr int even_up(int x) { return (x + 1) & ~1; }
 // the unrolled slot), and the tile operands are LDS reads; the results of a step are written into an LDS record in memory order
 // (Vxx | K | Vx | k | Quu) and leave as 16-byte pieces (+ one 8-byte piece per block of odd length).  A piece of an odd-length block
 // reads 8 bytes into the NEXT time step of the same array (never the last one: the loop starts at N-2) and ignores them.
+// A/B switches of the limited instantiations (profiles/build_variant.sh; defaults = what ships; same-box table in DESIGN section 9):
+#ifndef MXG_LIMS_PDC
+#define MXG_LIMS_PDC 0      // != 0: unroll / prefetch distance of the limited kernels (default: as without limits)
+#endif
+#ifndef MXG_U_IMAGE
+#define MXG_U_IMAGE 1       // u_i rides in the operand image (0: a load of its own per step, behind the stores in the in-order counter)
+#endif
+#ifndef MXG_GAIN22
+#define MXG_GAIN22 1        // m <= 2: gain columns from the 2 x 2 factor on scalars (0: the padded MS x MS solve)
+#endif
 template <int NP> struct MxgLds {                   // doubles
     static constexpr int MS = NP == 12 ? 3 : 4;
     static constexpr int HC = 0, ZERO = 16 * VG, CONSTS = 256;        // offset of the time-invariant H tile [row + 16 col] (its column VG is zero), its size
-    static constexpr int IMG = 2 * even_up(NP * NP) + 2 * even_up(NP * MS) + even_up(NP) + even_up(MS) + even_up(MS * MS);
+    static constexpr int IMG = 2 * even_up(NP * NP) + 2 * even_up(NP * MS) + even_up(NP) + 2 * even_up(MS) + even_up(MS * MS);     // (+ u_i with limits)
     static constexpr int BUF = CONSTS + IMG;
     static constexpr int RECD = even_up(NP * NP) + even_up(NP * MS) + even_up(NP) + even_up(MS) + even_up(MS * MS);
     static constexpr int REC = RECD + 64;           // + one dump cell per lane
@@ -71,16 +81,31 @@ __device__ __forceinline__ void store_results(char *vst, const double (&S)[KS], 
                      ::"v"(vst), "v"(S[0]), "v"(S[1]), "v"(S[2]), "s"(full), "s"(last), "v"(kq), "v"(kv), "s"(lanesK) : "memory");
 }
 
+#ifdef DDP_MXGPROF     // per-phase cycle counts (s_memtime) of trajectory 0: profiling builds only (profiles/build_variant.sh)
+#define MXP_DECL long long mxp_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mxp_t = __builtin_amdgcn_s_memtime()
+#define MXP(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); mxp_[k] += t_ - mxp_t; mxp_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MXP_PRINT do { if (b == 0 && lane == 0) printf("MXGPROF steps %d: operands %lld | products + control rows %lld | row reads %lld | box-QP %lld | gain solve %lld | K, T, Y %lld | value update %lld | transpose %lld | record + stores %lld | refill %lld\n", N - 1, \
+    mxp_[0] / (N - 1), mxp_[1] / (N - 1), mxp_[2] / (N - 1), mxp_[3] / (N - 1), mxp_[4] / (N - 1), mxp_[5] / (N - 1), mxp_[6] / (N - 1), mxp_[7] / (N - 1), mxp_[8] / (N - 1), mxp_[9] / (N - 1)); } while (0)
+#else
+#define MXP_DECL
+#define MXP(k)
+#define MXP_PRINT
+#endif
+
 template <int NP, bool FXTV, bool CTV, bool REG2, bool COAL, bool LIMS = false>
-__global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
+// With limits: two waves per SIMD (<= 256 registers).  The limited instantiations sit at 250-256 vector registers and the allocator took a few
+// accumulator registers on top in SOME of them — one wave per SIMD, i.e. two rounds for any batch of 1 025 .. 2 048 trajectories
+// (n = 12, m = 3, B = 2 048: 1.51 or 2.13 ms depending on which side of 256 a build fell).
+__global__ __launch_bounds__(DDP_WAVE) __attribute__((amdgpu_waves_per_eu(LIMS ? 2 : 1))) void back_pass_mxg_kernel(BPXArgs a)
 {
     constexpr int KS = NP / 4, UR = NP / 4, MS = NP == 12 ? 3 : 4;
     using L = MxgLds<NP>;
     // 16-byte pieces of a step's time-varying operand blocks / of its result blocks -> vector-memory instructions per step
     constexpr int LPC = (FXTV ? even_up(NP * NP) / 2 + even_up(NP * MS) / 2 : 0) + even_up(NP) / 2 + even_up(MS) / 2 +
-                        (CTV ? even_up(NP * NP) / 2 + even_up(NP * MS) / 2 + even_up(MS * MS) / 2 : 0);
+                        (CTV ? even_up(NP * NP) / 2 + even_up(NP * MS) / 2 + even_up(MS * MS) / 2 : 0) + ((LIMS && MXG_U_IMAGE) ? even_up(MS) / 2 : 0);
     constexpr int NLI = (LPC + 63) / 64, NSI = (L::RECD / 2 + 63) / 64;
-    constexpr int PDC = COAL ? (NLI <= 2 ? 8 : 4) : PD;       // prefetch distance = slots of the unrolled loop (even)
+    // prefetch distance = slots of the unrolled loop (even)
+    constexpr int PDC = (LIMS && MXG_LIMS_PDC != 0) ? MXG_LIMS_PDC : (COAL ? (NLI <= 2 ? 8 : 4) : PD);
     const int b = blockIdx.x, lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
     if (a.active && a.active[b] == 0) return;
     const int N = a.N, nr = a.n, mr = a.m;
@@ -190,24 +215,29 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     // step, byte offset in an image); co/fo: where my tile operands sit in a buffer; wS/wK: where my results go in the record;
     // sp/sstr/srd: my 16-byte piece of instruction j of the record; tp/tstr/trd: the last element of a block of odd length
     const char *lg[NLI];
-    unsigned lgs[NLI], lim[NLI], co[4], fo[KS], wS[KS], wK = 0, sstr[NSI], srd[NSI], tstr = 0, trd = 0;
+    unsigned lgs[NLI], lim[NLI], co[4], fo[KS], wS[KS], wK = 0, sstr[NSI], srd[NSI], tstr = 0, trd = 0, uo = 0;
+    const double *ug = LIMS ? a.u + (size_t)mr * N * b : nullptr;
     char *sp[NSI], *tp = nullptr;
     bool has4 = false, hast = false;
     d2 ring[COAL ? PDC : 1][NLI];
     if constexpr (COAL) {
-        const double *bp[7] = {fx, fu, cx, cu, cxx, cxu, cuu};
-        const int bsz[7] = {(int)nn, (int)nm, nr, mr, (int)nn, (int)nm, (int)mm};
-        const bool bon[7] = {FXTV, FXTV, true, true, CTV, CTV, CTV};
-        int off[7], o = L::CONSTS;
+        // (with limits u_i rides in the image as well: a load of its own would sit in the SAME in-order counter as the operand ring and the
+        // stores — the first limited build waited at the top of the box-QP for the stores and the refill of the step before, 2 000 ticks
+        // of memory latency per step that looked like the QP's arithmetic in every profile)
+        const double *bp[8] = {fx, fu, cx, cu, cxx, cxu, cuu, ug};
+        const int bsz[8] = {(int)nn, (int)nm, nr, mr, (int)nn, (int)nm, (int)mm, mr};
+        const bool bon[8] = {FXTV, FXTV, true, true, CTV, CTV, CTV, LIMS && MXG_U_IMAGE};
+        int off[8], o = L::CONSTS;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) { off[q] = o; if (bon[q]) o += even_up(bsz[q]); }
+        for (int q = 0; q < 8; ++q) { off[q] = o; if (bon[q]) o += even_up(bsz[q]); }
+        uo = (unsigned)off[7] * 8u;
 #pragma unroll
         for (int j = 0; j < NLI; ++j) {
             int pi = lane + 64 * j;
             bool found = false;
             lg[j] = (const char *)cx; lgs[j] = nr * 8u; lim[j] = (unsigned)off[2] * 8u;     // lanes past the end repeat piece 0 of cx
 #pragma unroll
-            for (int q = 0; q < 7; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 if (!bon[q]) continue;
                 const int np = (bsz[q] + 1) / 2;
                 if (!found && pi < np) { lg[j] = (const char *)bp[q] + 16 * pi; lgs[j] = (unsigned)bsz[q] * 8u; lim[j] = (unsigned)(off[q] + 2 * pi) * 8u; found = true; }
@@ -301,12 +331,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
 
     // ---- control limits (backward_pass.jl:43-62): the box-QP on the MS x MS system — the same solve on the same (LDS-broadcast) data in every
     // lane, so its branches are wave-uniform (boxqp_dev.h); controls past m: gradient 1 on [0, 0], clamped in every iteration.  u_i comes
-    // by scalar loads a step ahead.
+    // with the operand image of its step.
     bool nolims = true;
     double limlo[MS], limhi[MS], ucur[MS], kprev[MS];
 #pragma unroll
     for (int c2 = 0; c2 < MS; ++c2) { limlo[c2] = 0.0; limhi[c2] = 0.0; ucur[c2] = 0.0; kprev[c2] = 0.0; }
-    const double *ug = LIMS ? a.u + (size_t)mr * N * b : nullptr;
     if constexpr (LIMS) {
         nolims = a.lims[0] > a.lims[mr];                    // backward_pass.jl:31
 #pragma unroll
@@ -316,6 +345,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
     const QPOptsDev qpo = {100, 1e-8, 1e-8, 0.6, 1e-22, 0.1};       // boxQP.jl:30-35
     double dVa = 0.0, dVp = 0.0;                    // Σ k'Qu (lanes of column VG) and the per-row parts of Σ k'(Quu k + Qu)
     int diverge = 0;
+    MXP_DECL;
     auto reg = [](const d4 &v, int r) __attribute__((always_inline)) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
     // One time step; no exits inside (a diverged trajectory steps through garbage until the loop around the step looks at `diverge`;
     // its outputs below the failing step are zero-filled after the loop).
@@ -342,6 +372,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
                 for (int s = 0; s < KS; ++s) F[s] = fr[slot][s];
             }
         }
+        MXP(0);
         // ================= GEMM1: W = Vxx·F; column VG := Vx (F[:,VG] = 0, S[:,VG] = Vx) ============================
         d4 w = __builtin_amdgcn_mfma_f64_16x16x4f64(S[0], F[0], zero4, 0, 0, 0);
 #pragma unroll
@@ -363,6 +394,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
             zl[1][lane] = reg(gr, UR) + 0.0;
         }
         wave_sync();
+        MXP(1);
         // ================= gains (backward_pass.jl:30-42): every lane factorises QuuF, solves its own column ===========
         const double *zs = zl[REG2 ? 1 : 0];
         double Hq[MS * MS], R[MS * MS], ri[MS], q[MS];
@@ -376,49 +408,89 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
 #pragma unroll
         for (int c2 = 0; c2 < MS; ++c2) Qu[c2] = REG2 ? zl[0][16 * c2 + l15] : q[c2];
         int fail;
+#ifdef DDP_MXGPROF
+        asm volatile("" : "+v"(q[0]), "+v"(Hq[0]), "+v"(Qu[MS - 1]));
+#endif
+        MXP(2);
         if (!LIMS || nolims) {
             fail = ddp_chol_rinv<MS>(Hq, R, ri);
             ddp_rsolve_neg<MS>(R, ri, q);                  // q <- -(QuuF)\q: K[:, col] (:42), column VG: k_i (:41)
         } else {
-            double Hf[MS * MS], gq[MS], lo[MS], up[MS], kk[MS];
+            if (MXG_U_IMAGE) {   // u_i: from the image of this step
+                const double *ui = (const double *)((const char *)img + (slot & 1) * L::BUF * 8 + uo);
 #pragma unroll
-            for (int c2 = 0; c2 < MS; ++c2) {
-#pragma unroll
-                for (int c1 = 0; c1 <= c2; ++c1) { Hf[c1 + MS * c2] = Hq[c1 + MS * c2]; Hf[c2 + MS * c1] = Hq[c1 + MS * c2]; }
-                gq[c2] = c2 < mr ? zl[0][16 * c2 + VG] : 1.0;                      // Qu (the gradient column of the unregularised rows)
-                lo[c2] = c2 < mr ? limlo[c2] - ucur[c2] : 0.0; up[c2] = c2 < mr ? limhi[c2] - ucur[c2] : 0.0;      // (:45-46)
+                for (int c2 = 0; c2 < MS; ++c2)
+                    if (c2 < mr) ucur[c2] = ui[c2];
             }
+            bool tail = true;                               // the padded MS x MS gain solve below
+            double kk[MS];
             unsigned clamped = 0u;
             int iters, result;
-            if (mr <= 2) {                                 // (uniform) the usual sizes as a 2 x 2 problem: half the work of the padded MS x MS one
-                double H2[4] = {Hf[0], Hf[1], Hf[MS], Hf[1 + MS]}, g2[2] = {gq[0], gq[1]}, lo2[2] = {lo[0], lo[1]}, up2[2] = {up[0], up[1]},
+            if (mr <= 2) {
+                // (uniform) the usual sizes as a 2 x 2 problem on scalars
+                const double h01 = Hq[MS];
+                double H2[4] = {Hq[0], h01, h01, Hq[1 + MS]}, g2[2] = {zl[0][VG], mr > 1 ? zl[0][16 + VG] : 1.0},        // Qu: the gradient column of the unregularised rows
+                       lo2[2] = {limlo[0] - ucur[0], mr > 1 ? limlo[1] - ucur[1] : 0.0}, up2[2] = {limhi[0] - ucur[0], mr > 1 ? limhi[1] - ucur[1] : 0.0},      // (:45-46)
                        x02[2] = {kprev[0], kprev[1]}, k2[2], R2[4], ri2[2];
-                // (:49), warm start k[:, min(i+1, N-1)]; boxqp_dev2: straight-line.  (Tried: the QP as a CALLED function — the limited
-                // instantiations are 140 KB of code, the step being unrolled 4-8 times, against 24 KB without limits; 40 KB with the call,
-                // but 370 ns of call overhead per step: 1.51 -> 1.88 ms at n=10, m=2, N=1000, B=1024, and 1.53 -> 5.2 ms for m = 3.)
-                result = boxqp_dev2(H2, g2, lo2, up2, x02, qpo, k2, R2, ri2, clamped, iters);
+                // (:49), warm start k[:, min(i+1, N-1)]
+                result = boxqp_dev2(H2, g2, lo2, up2, x02, qpo, k2, R2, ri2, clamped, iters);     // straight-line (boxqp_dev.h)
+#ifdef DDP_MXGPROF
+                asm volatile("" : "+v"(k2[0]), "+v"(R2[0]));
+#endif
+                MXP(3);
+                if (MXG_GAIN22) {                          // K[free, col] = -(R'R)\Qux_reg[free, col] with the 2 x 2 factor (:57-61)
+                    tail = false;
+                    kprev[0] = k2[0]; kprev[1] = k2[1];
+                    const bool cl0 = (clamped & 1u) != 0, cl1 = (clamped & 2u) != 0;
+                    double b0 = (cl0 ? 0.0 : q[0]) * ri2[0], t2 = cl1 ? 0.0 : q[1];                            // chol_solve_ri<2>
+                    t2 -= R2[2] * b0;
+                    double b1 = t2 * ri2[1];
+                    b1 = b1 * ri2[1]; t2 = b0; t2 -= R2[2] * b1; b0 = t2 * ri2[0];
+                    q[0] = l15 == VG ? k2[0] : (cl0 ? 0.0 : -b0);                                              // column VG: k_i from the QP (bounds included)
+                    q[1] = l15 == VG ? k2[1] : (cl1 ? 0.0 : -b1);
 #pragma unroll
-                for (int e = 0; e < MS * MS; ++e) R[e] = 0.0;
+                    for (int c2 = 2; c2 < MS; ++c2) q[c2] = 0.0;                                               // the controls past 2: clamped
+                } else {
 #pragma unroll
-                for (int c2 = 0; c2 < MS; ++c2) { R[c2 + MS * c2] = 1.0; ri[c2] = 1.0; kk[c2] = 0.0; }
-                R[0] = R2[0]; R[MS] = R2[2]; R[1 + MS] = R2[3]; ri[0] = ri2[0]; ri[1] = ri2[1]; kk[0] = k2[0]; kk[1] = k2[1];
-                clamped |= ((1u << MS) - 1u) & ~3u;        // the controls past 2: clamped
+                    for (int e = 0; e < MS * MS; ++e) R[e] = 0.0;
+#pragma unroll
+                    for (int c2 = 0; c2 < MS; ++c2) { R[c2 + MS * c2] = 1.0; ri[c2] = 1.0; kk[c2] = 0.0; }
+                    R[0] = R2[0]; R[MS] = R2[2]; R[1 + MS] = R2[3]; ri[0] = ri2[0]; ri[1] = ri2[1]; kk[0] = k2[0]; kk[1] = k2[1];
+                    clamped |= ((1u << MS) - 1u) & ~3u;    // the controls past 2: clamped
+                }
             } else {
+                double Hf[MS * MS], gq[MS], lo[MS], up[MS];
+#pragma unroll
+                for (int c2 = 0; c2 < MS; ++c2) {
+#pragma unroll
+                    for (int c1 = 0; c1 <= c2; ++c1) { Hf[c1 + MS * c2] = Hq[c1 + MS * c2]; Hf[c2 + MS * c1] = Hq[c1 + MS * c2]; }
+                    gq[c2] = c2 < mr ? zl[0][16 * c2 + VG] : 1.0;                  // Qu (the gradient column of the unregularised rows)
+                    lo[c2] = c2 < mr ? limlo[c2] - ucur[c2] : 0.0; up[c2] = c2 < mr ? limhi[c2] - ucur[c2] : 0.0;      // (:45-46)
+                }
                 result = boxqp_dev_ri<MS>(MS, Hf, gq, lo, up, kprev, qpo, kk, R, ri, clamped, iters);
+                MXP(3);
             }
             fail = result < 1;                             // (:53)
+            if (tail) {
 #pragma unroll
-            for (int c2 = 0; c2 < MS; ++c2) { kprev[c2] = kk[c2]; q[c2] = ((clamped >> c2) & 1u) ? 0.0 : q[c2]; }
-            chol_solve_ri<MS>(MS, R, ri, q);               // K[free, col] = -(R'R)\Qux_reg[free, col], clamped rows zero (:57-61)
+                for (int c2 = 0; c2 < MS; ++c2) { kprev[c2] = kk[c2]; q[c2] = ((clamped >> c2) & 1u) ? 0.0 : q[c2]; }
+                chol_solve_ri<MS>(MS, R, ri, q);           // K[free, col] = -(R'R)\Qux_reg[free, col], clamped rows zero (:57-61)
 #pragma unroll
-            for (int c2 = 0; c2 < MS; ++c2) {
-                const double kq_ = ((clamped >> c2) & 1u) ? 0.0 : -q[c2];
-                q[c2] = l15 == VG ? kk[c2] : kq_;          // column VG: k_i from the QP (bounds included)
+                for (int c2 = 0; c2 < MS; ++c2) {
+                    const double kq_ = ((clamped >> c2) & 1u) ? 0.0 : -q[c2];
+                    q[c2] = l15 == VG ? kk[c2] : kq_;      // column VG: k_i from the QP (bounds included)
+                }
             }
+            if (!MXG_U_IMAGE) {
 #pragma unroll
-            for (int c2 = 0; c2 < MS; ++c2)                // u_{i-1} for the next step (scalar loads: their latency is the rest of this step)
-                if (c2 < mr) ucur[c2] = ug[(size_t)mr * (i > 0 ? i - 1 : 0) + c2];
+                for (int c2 = 0; c2 < MS; ++c2)            // u_{i-1} for the next step
+                    if (c2 < mr) ucur[c2] = ug[(size_t)mr * (i > 0 ? i - 1 : 0) + c2];
+            }
         }
+#ifdef DDP_MXGPROF
+        asm volatile("" : "+v"(q[0]), "+v"(q[1]));
+#endif
+        MXP(4);
         double Ksel = q[0] * rowm[0];                      // K[a = l4, col]: a sum with lane constants 1 / 0, no selects
 #pragma unroll
         for (int c2 = 1; c2 < MS; ++c2) Ksel = fma(q[c2], rowm[c2], Ksel);
@@ -434,6 +506,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
             });
         }
         const double Ysel = fma(Z, maskM, Tsel);           // Y = T + Qux; column VG: Quu k + Qu
+#ifdef DDP_MXGPROF
+        { double y_ = Ysel; asm volatile("" : "+v"(y_)); }
+#endif
+        MXP(5);
         // ================= value update (:69-72): D = G + K'Y, column VG also + Qux'k ==================================
         d4 v = __builtin_amdgcn_mfma_f64_16x16x4f64(Ksel, Ysel, g, 0, 0, 0);
         v = __builtin_amdgcn_mfma_f64_16x16x4f64(Z, Ksel * maskV, v, 0, 0, 0);     // A[i][a] = G[control a][i], B[a][VG] = k_a
@@ -447,6 +523,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
             for (int c2 = 0; c2 < MS; ++c2) dVa = fma(q[c2], Qu[c2], dVa);
             dVp = fma(Ksel, Tsel, dVp);
         }
+#ifdef DDP_MXGPROF
+        asm volatile("" : "+v"(v.x));
+#endif
+        MXP(6);
         // ---- ½(D + D') through the transpose tile (column VG: Vx, not symmetrised)
 #pragma unroll
         for (int s = 0; s < KS; ++s) lds[wr + 4 * s] = reg(v, s);
@@ -455,6 +535,10 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
         for (int s = 0; s < KS; ++s) S[s] = vscl * (reg(v, s) + lds[rdT + s * rdS]);
         // Stores are unconditional: a diverged trajectory writes garbage into time steps that are zero-filled after the loop
         const double kv = quu_lane ? Z : Ksel;             // K | k | Quu (:75-76)
+#ifdef DDP_MXGPROF
+        asm volatile("" : "+v"(S[0]));
+#endif
+        MXP(7);
         if constexpr (COAL) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) *(double *)((char *)rec + wS[s]) = S[s];
@@ -474,6 +558,7 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
                 }
             }
             wave_sync();                                   // the tile, the image and the record are free again
+            MXP(8);
             if (!(MXG_EXP & 2)) {   // refill the ring slot with the step PDC ahead (clamped: always a valid load)
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -514,6 +599,11 @@ __global__ __launch_bounds__(DDP_WAVE) void back_pass_mxg_kernel(BPXArgs a)
         if (i >= 0 && diverge == 0) { step(i, sc); --i; }
     });
 
+    MXP_PRINT;
+#ifdef DDP_QP2_STATS
+    if (b == 0 && lane == 0) printf("QP2STATS (all launches so far) first-iteration exit 6: %llu | finished straight-line: %llu (iterations %llu; result 0: %llu 2: %llu 4: %llu 5: %llu 6: %llu) | generic loop: %llu\n",
+        ddp_qp2_stats[10], ddp_qp2_stats[1], ddp_qp2_stats[2], ddp_qp2_stats[3], ddp_qp2_stats[5], ddp_qp2_stats[7], ddp_qp2_stats[8], ddp_qp2_stats[9], ddp_qp2_stats[0]);
+#endif
     if (diverge) {   // outputs earlier in time than the failing step are zero (backward_pass.jl:226-229)
         const size_t ie = (size_t)diverge;          // = i + 1
         __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the garbage of the steps after the failure has landed

@@ -288,6 +288,9 @@ __device__ __forceinline__ int boxqp_dev(int m, const double (&H)[MM * MM], cons
 // a back-tracking line search (Armijo fails at step 1) or a fourth iteration hands the WHOLE problem to the generic routine, which
 // starts from x0 again — so every case it does not finish itself is the generic result by construction.  Same formulas, same order of
 // sums as boxqp_dev_ri<2>; results, result codes, clamped sets, factors and iteration counts are those of the loop.
+#ifdef DDP_QP2_STATS
+__device__ unsigned long long ddp_qp2_stats[12];
+#endif
 __device__ __forceinline__ int boxqp_dev2(const double (&H)[4], const double (&g)[2], const double (&lower)[2], const double (&upper)[2],
                                           const double (&x0)[2], const QPOptsDev &o, double (&x)[2], double (&R)[4], double (&ri)[2],
                                           unsigned &clamped, int &iters)
@@ -327,6 +330,9 @@ __device__ __forceinline__ int boxqp_dev2(const double (&H)[4], const double (&g
     } while (0)
     DDP_QP2_GRAD_CLAMP();
     if (c0 && c1) {
+#ifdef DDP_QP2_STATS
+        if (threadIdx.x == 0) atomicAdd(&ddp_qp2_stats[10], 1ull);
+#endif
         x[0] = xa; x[1] = xb; ri[0] = ri[1] = 0.0; R[0] = R[1] = R[2] = R[3] = 0.0;
         clamped = 3u; iters = 1;
         return 6;
@@ -407,6 +413,9 @@ __device__ __forceinline__ int boxqp_dev2(const double (&H)[4], const double (&g
 #undef DDP_QP2_GRAD_CLAMP
 #undef DDP_QP2_VAL
 #undef DDP_QP2_SOLVE
+#ifdef DDP_QP2_STATS     // profiling builds: [calls that fell into the generic loop, calls finished here, their iterations]
+    if (threadIdx.x == 0) { atomicAdd(&ddp_qp2_stats[slow ? 0 : 1], 1ull); if (!slow) atomicAdd(&ddp_qp2_stats[2], (unsigned long long)iter); atomicAdd(&ddp_qp2_stats[3 + (result < 0 ? 0 : (result > 6 ? 6 : result))], slow ? 0ull : 1ull); }
+#endif
     if (__builtin_expect(slow, 0)) return boxqp_dev_ri<2>(2, H, g, lower, upper, x0, o, x, R, ri, clamped, iters);
     x[0] = xa; x[1] = xb;
     ri[0] = Fca; ri[1] = Fcb; R[0] = Fcc; R[1] = 0.0; R[2] = Fcd; R[3] = Fce;

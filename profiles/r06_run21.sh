@@ -1,0 +1,9 @@
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+export DDP_BC_WARMUP=3 DDP_BC_STEPS=20
+for V in head base v000o2; do
+if [ $V != base ]; then export DDP_AMD_LIB=$PWD/differentialdynamicprogramming.jl_amd/build/libddp_$V.so; else unset DDP_AMD_LIB; fi
+echo "$V offL $(timeout 300 python profiles/bench_configs.py offL 2>&1 | grep -o '"back_pass_ms": [0-9.]*')  LTV-lims $(DDP_OFFX="10 2 1000 1024 1 1" timeout 300 python profiles/bench_configs.py offX 2>&1 | grep -o '"back_pass_ms": [0-9.]*')  n12m2 $(DDP_OFFX="12 2 500 2048 1 1" timeout 300 python profiles/bench_configs.py offX 2>&1 | grep -o '"back_pass_ms": [0-9.]*') n12m3 $(DDP_OFFX="12 3 500 2048 1 1" timeout 300 python profiles/bench_configs.py offX 2>&1 | grep -o '"back_pass_ms": [0-9.]*') n8m2 $(DDP_OFFX="8 2 500 2048 1 1" timeout 300 python profiles/bench_configs.py offX 2>&1 | grep -o '"back_pass_ms": [0-9.]*') n8m4 $(DDP_OFFX="8 4 500 2048 1 1" timeout 300 python profiles/bench_configs.py offX 2>&1 | grep -o '"back_pass_ms": [0-9.]*') n4m2lti $(DDP_OFFX="4 2 1000 2048 0 1" timeout 300 python profiles/bench_configs.py offX 2>&1 | grep -o '"back_pass_ms": [0-9.]*') n10m2B4096 $(DDP_OFFX="10 2 500 4096 1 1" timeout 300 python profiles/bench_configs.py offX 2>&1 | grep -o '"back_pass_ms": [0-9.]*')"
+done
+unset DDP_AMD_LIB
+timeout 1500 python -m pytest tests/test_gpu_boxqp2.py tests/test_gpu_row_shapes.py tests/test_gpu_parity.py tests/test_gpu_tile_shapes.py tests/test_gpu_edge_cases.py -x -q -m gpu 2>&1 | grep "passed\|failed" | cut -c1-300
