@@ -24,7 +24,7 @@ extern "C" {
 const char *ddp_last_error(void) { return g_err; }
 const char *ddp_version(void) { return "ddp_amd 0.3.0 (gfx950, fp64)"; }
 
-static const char *const ddp_env_names[ENV_COUNT] = {"DDP_BACKPASS", "DDP_SH_MIN_B", "DDP_MX2", "DDP_DPPW", "DDP_DPPW_EXP", "DDP_MX_LDS", "DDP_Q4_EXP", "DDP_Q4_SINGLE", "DDP_Q4_LDS", "DDP_GPS_Q4", "DDP_GPS_Q4L", "DDP_DF_DENSE", "DDP_FORWARD", "DDP_FORWARD64", "DDP_FORWARD_FAST", "DDP_FORWARD_FUSE", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND", "DDP_FORWARD_PIPE", "DDP_ILQG_COMPACT", "DDP_ILQG_LSGROUPS", "DDP_TEST_COMPACT_ALLOC_FAIL", "DDP_GPS_LANE", "DDP_FCOV_Q4", "DDP_FCOV_Q4L", "DDP_KL_LDS", "DDP_TEST_SH_ABORT", "DDP_SH_NT_MAX_B", "DDP_MXG_COAL", "DDP_FORWARD_MID"};
+static const char *const ddp_env_names[ENV_COUNT] = {"DDP_BACKPASS", "DDP_SH_MIN_B", "DDP_MX2", "DDP_DPPW", "DDP_DPPW_EXP", "DDP_MX_LDS", "DDP_Q4_EXP", "DDP_Q4_SINGLE", "DDP_Q4_LDS", "DDP_GPS_Q4", "DDP_GPS_Q4L", "DDP_DF_DENSE", "DDP_FORWARD", "DDP_FORWARD64", "DDP_FORWARD_FAST", "DDP_FORWARD_FUSE", "DDP_FORWARD_LANE", "DDP_FORWARD_PEND", "DDP_FORWARD_PIPE", "DDP_ILQG_COMPACT", "DDP_ILQG_LSGROUPS", "DDP_TEST_COMPACT_ALLOC_FAIL", "DDP_GPS_LANE", "DDP_FCOV_Q4", "DDP_FCOV_Q4L", "DDP_KL_LDS", "DDP_TEST_SH_ABORT", "DDP_SH_NT_MAX_B", "DDP_MXG_COAL", "DDP_FORWARD_MID", "DDP_PEND_CHUNK"};
 
 int ddp_reload_env(ddp_handle h)
 {

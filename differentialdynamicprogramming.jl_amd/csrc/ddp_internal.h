@@ -12,7 +12,7 @@
 // The DDP_* switches of the dispatchers (kernel choice for A/B timing and for the tests that force every code path) are read from the
 // environment ONCE per handle (ddp_create) and again on ddp_reload_env(): no launch calls getenv, and a setenv() in another thread
 // cannot race with a launch.  ddp_env() returns the cached value or nullptr.
-enum ddp_env_id { ENV_BACKPASS, ENV_SH_MIN_B, ENV_MX2, ENV_DPPW, ENV_DPPW_EXP, ENV_MX_LDS, ENV_Q4_EXP, ENV_Q4_SINGLE, ENV_Q4_LDS, ENV_GPS_Q4, ENV_GPS_Q4L, ENV_DF_DENSE, ENV_FORWARD, ENV_FORWARD64, ENV_FORWARD_FAST, ENV_FORWARD_FUSE, ENV_FORWARD_LANE, ENV_FORWARD_PEND, ENV_FORWARD_PIPE, ENV_ILQG_COMPACT, ENV_ILQG_LSGROUPS, ENV_TEST_COMPACT_ALLOC_FAIL, ENV_GPS_LANE, ENV_FCOV_Q4, ENV_FCOV_Q4L, ENV_KL_LDS, ENV_TEST_SH_ABORT, ENV_SH_NT_MAX_B, ENV_MXG_COAL, ENV_FORWARD_MID, ENV_COUNT };
+enum ddp_env_id { ENV_BACKPASS, ENV_SH_MIN_B, ENV_MX2, ENV_DPPW, ENV_DPPW_EXP, ENV_MX_LDS, ENV_Q4_EXP, ENV_Q4_SINGLE, ENV_Q4_LDS, ENV_GPS_Q4, ENV_GPS_Q4L, ENV_DF_DENSE, ENV_FORWARD, ENV_FORWARD64, ENV_FORWARD_FAST, ENV_FORWARD_FUSE, ENV_FORWARD_LANE, ENV_FORWARD_PEND, ENV_FORWARD_PIPE, ENV_ILQG_COMPACT, ENV_ILQG_LSGROUPS, ENV_TEST_COMPACT_ALLOC_FAIL, ENV_GPS_LANE, ENV_FCOV_Q4, ENV_FCOV_Q4L, ENV_KL_LDS, ENV_TEST_SH_ABORT, ENV_SH_NT_MAX_B, ENV_MXG_COAL, ENV_FORWARD_MID, ENV_PEND_CHUNK, ENV_COUNT };
 
 struct ddp_handle_s {
     int          device;

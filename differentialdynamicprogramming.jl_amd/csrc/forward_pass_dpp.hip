@@ -28,6 +28,7 @@ struct FDArgs {
     double goal[4];
     double *cnew, *csum;
     double *sink;               // >= 64 x 8 B that lanes without an output write to (stores carry no exec-mask branch); NULL: masked stores
+    int chunked;                // forward_pend_row_kernel: whole 16-step chunks through LDS (set by its launcher)
     unsigned wrap;              // ddp_problem::diff_wrap: coordinates whose difference x̂ - x is wrapped to [-π, π] (pendulum kernels)
 };
 
@@ -497,12 +498,32 @@ __device__ __forceinline__ double row_bcast_all(double x)
     asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(x), "n"(L));
     return d;
 }
+template <int I> struct PIC { static constexpr int value = I; };
+template <int I, int E, class Fn>
+__device__ __forceinline__ void pend_static_for(Fn &&f)
+{
+    if constexpr (I < E) { f(PIC<I>{}); pend_static_for<I + 1, E>(f); }
+}
+typedef double pend_d4 __attribute__((ext_vector_type(4)));
+// Memory side (round 6, profiles/microbench/narrow_streams.hip): one 8-byte element per lane and step from six streams per rollout tops out at
+// 1.7-1.85 TB/s however many rollouts run (every request is 8-32 bytes wide) — above the 208 ns compute floor of a step from ~2 600 rollouts
+// on; the same bytes in 512-byte runs reach 5.3-7.7 TB/s.  So the whole 16-step chunks of a rollout go through LDS: per chunk a lane
+// fetches 32 bytes of K and of x (the step 16 c + j of its row) and 8 of ū and k, one chunk ahead; a step reads its K_i | x_i element from
+// the LDS image (one ds_read in place of the global load, a step ahead), takes ū_i and k_i from the chunk registers by the same row
+// broadcast as before (lane d of the row instead of lanes 8 / 9), and puts x̂_i | u_i into an LDS image that leaves as 32 + 8 bytes per
+// lane at the end of the chunk.  The N mod 16 last steps run the element-wise path.
+#ifndef PEND_ROW_CHUNK
+#define PEND_ROW_CHUNK 1
+#endif
 template <bool POLICY, bool LIMS, bool FUSE, bool WRAP = false>
 __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
 {
     constexpr int n = 4, G = 16, GPW = DDP_WAVE / G, TS = 17, D = 8;
     const bool wrapj = WRAP && (((a.wrap >> (threadIdx.x & 3)) & 1u) != 0) && (threadIdx.x % G) < n;      // this lane's coordinate is an angle
     __shared__ double ctile[FUSE ? GPW * 16 * TS : 1];
+    constexpr int CIN = 128, COUT = 208;                                      // doubles per rollout: [K 16 x 4 | x 16 x 4] per buffer; [x̂ 16 x 4 | u 16 x 4 (stride 4) | dump]
+    __shared__ __attribute__((aligned(16))) double cin[(PEND_ROW_CHUNK && POLICY) ? GPW * 2 * CIN : 2];
+    __shared__ __attribute__((aligned(16))) double cout[PEND_ROW_CHUNK ? GPW * COUT : 2];
     const int N = a.N, B = a.B;
     const int lane = threadIdx.x, grp = lane / G, j = lane % G;
     const long total = (long)B * a.nalpha;
@@ -558,20 +579,25 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
         wave_sync();
     };
     const bool is1 = j == 1, is3 = j == 3, isu = j == n;
+    double *co_ = &cout[PEND_ROW_CHUNK ? grp * COUT : 0];
+    double *cow = co_ + (j < n ? j : (j == n ? 64 : 128 + j));            // my cell of a step's result (+ 4 per step); lanes > n: dump cells
     PendTrig trig;
     trig.init();
     dpp_fence(xh);
     auto run = [&](auto minmax_c) __attribute__((always_inline)) {
     constexpr bool MINMAX = decltype(minmax_c)::value;
-    auto step = [&](int i, double ld, bool advance) {
+    // ld: K_i | x_i in lanes 0-7; ū_i in lane UL of usrc, k_i in lane KL of ksrc (element-wise path: all three are the one loaded register)
+    auto step = [&](int i, double ld, double usrc, double ksrc, auto ul_c, auto kl_c, bool advance, auto store_c) __attribute__((always_inline)) {
+        constexpr int UL = decltype(ul_c)::value, KL = decltype(kl_c)::value;
+        constexpr bool TO_LDS = decltype(store_c)::value >= 0;
         // ---- control (forward_pass.jl:17-24): u = ū + α k + K (x̂ - x), clamp, NaN -> 0 (inside f, system_pendcart.jl:120)
-        double uu = row_bcast_all<8>(ld);                                // ū_i  (ld comes from memory: no VALU -> DPP hazard)
+        double uu = row_bcast_all<UL>(usrc);                             // ū_i  (from memory: no VALU -> DPP hazard)
         if (POLICY) {
             const double xi = __builtin_amdgcn_update_dpp(0.0, ld, 0x104, 0xf, 0xf, true);      // row_shl:4: x_i[j] from lane j + 4
             double dxj = xh - xi;
             if (WRAP) dxj = wrapj ? wrap_pi2(dxj) : dxj;                 // diff_fun (forward_pass.jl:19)
             double pr = ld * dxj;                                        // K_i[j] diff(x̂_j, x_j) in lanes 0-3
-            fmac_bc<9>(uu, ld, alpha);                                   // unew .+= k*α
+            fmac_bc<KL>(uu, ksrc, alpha);                                // unew .+= k*α
             dpp_fence(pr);
             double s1 = 0.0;
             RowSum<n>::run(uu, s1, pr, one);                             // unew .+= K*dx, two interleaved partial sums
@@ -581,7 +607,8 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
         if (LIMS) uu = MINMAX ? fmin(fmax(uu, lo), hi) : clampd(uu, lo, hi);
         uu = nan ? 0.0 : uu;
         const double v = isu ? uu : xh;
-        *(double *)(stb + (size_t)sts * (unsigned)i) = v;
+        if constexpr (TO_LDS) cow[4 * decltype(store_c)::value] = v;     // x̂_i | u_i into the chunk image
+        else *(double *)(stb + (size_t)sts * (unsigned)i) = v;
         if (FUSE) {
             const double dv = v - cg;
             const double pc = (cw * dv) * dv;
@@ -602,15 +629,59 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
             dpp_fence(xh);
         }
     };
+    int i0 = 0;
+    if (PEND_ROW_CHUNK && a.chunked && N >= 16) {
+        const int nch = N / 16;
+        const bool lastadv = 16 * nch < N;                                  // the last step of the last chunk advances unless it is step N-1
+        const pend_d4 *K4 = (const pend_d4 *)(a.K + (size_t)n * N * b) + j, *x4 = (const pend_d4 *)(a.x + (size_t)n * N * b) + j;
+        const double *u1 = ug + j, *k1 = POLICY ? a.k + (size_t)N * b + j : ug + j;
+        pend_d4 Kn = pend_d4{0, 0, 0, 0}, xn = Kn;
+        double uch = u1[0], kch = POLICY ? k1[0] : 0.0, un, kn = 0.0;
+        double *ci = &cin[POLICY ? grp * 2 * CIN : 0];
+        const int rd = j < 4 ? j : (j < 8 ? 64 + (j - 4) : 0);           // my element of a step in an input buffer (+ 4 per step)
+        if (POLICY) {
+            Kn = K4[0]; xn = x4[0];
+            *(pend_d4 *)(ci + 4 * j) = Kn; *(pend_d4 *)(ci + 64 + 4 * j) = xn;
+        }
+        pend_d4 *xo4 = (pend_d4 *)(a.xnew + (size_t)n * N * rho) + j;
+        double *uo1 = a.unew + (size_t)N * rho + j;
+        wave_sync();
+        for (int c = 0; c < nch; ++c) {
+            const int cn = c + 1 < nch ? c + 1 : c;                        // the chunk after this one (clamped: always a valid load)
+            if (POLICY) { Kn = K4[16 * cn]; xn = x4[16 * cn]; kn = k1[16 * cn]; }
+            un = u1[16 * cn];
+            const double *cr = ci + (c & 1) * CIN + rd;
+            const bool advl = c + 1 < nch || lastadv;
+            double ldc = POLICY ? cr[0] : 0.0;
+            pend_static_for<0, 16>([&](auto dc) __attribute__((always_inline)) {
+                constexpr int d = decltype(dc)::value;
+                if (FUSE && (d == 0 || d == 8)) ctw = ct + j + d * TS;
+                const double ld = ldc;
+                if (POLICY && d < 15) ldc = cr[4 * (d + 1)];               // a step ahead
+                step(16 * c + d, ld, uch, kch, dc, dc, d < 15 ? true : advl, dc);
+            });
+            wave_sync();                                                    // the images of this chunk are complete / no longer read
+            if (POLICY) { double *cw2 = ci + ((c + 1) & 1) * CIN; *(pend_d4 *)(cw2 + 4 * j) = Kn; *(pend_d4 *)(cw2 + 64 + 4 * j) = xn; }
+            {
+                const pend_d4 xv = *(const pend_d4 *)(co_ + 4 * j);
+                const double uv = co_[64 + 4 * j];
+                if (act) { xo4[16 * c] = xv; uo1[16 * c] = uv; }
+            }
+            uch = un; kch = kn;
+            dpp_fence(uch, kch);
+            if (FUSE) flush_cost(16 * c, 16);                               // (its two wave_syncs also fence the images for the next chunk)
+            else wave_sync();
+        }
+        i0 = 16 * nch;
+    }
     double ring[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) ring[d] = fetch(d < N ? d : N - 1);
-    int i0 = 0;
+    for (int d = 0; d < D; ++d) ring[d] = fetch(i0 + d < N ? i0 + d : N - 1);
     for (; i0 + 2 * D <= N; i0 += D) {
         if (FUSE) ctw = ct + j + (i0 & 8) * TS;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            step(i0 + d, ring[d], true);
+            step(i0 + d, ring[d], ring[d], ring[d], PIC<8>{}, PIC<9>{}, true, PIC<-1>{});
             ring[d] = fetch(i0 + d + D);
         }
         if (FUSE && (i0 & 8)) flush_cost(i0 - 8, 16);
@@ -621,7 +692,7 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
         for (int d = 0; d < D; ++d) {
             const int i = i0 + d;
             if (i < N) {
-                step(i, ring[d], i < N - 1);
+                step(i, ring[d], ring[d], ring[d], PIC<8>{}, PIC<9>{}, i < N - 1, PIC<-1>{});
                 ring[d] = fetch(i + D < N ? i + D : N - 1);
             }
         }
@@ -737,9 +808,15 @@ int launch_dpp(ddp_handle h, const FDArgs &a)
 }
 
 template <bool FUSE>
-int launch_pend_row(ddp_handle h, const FDArgs &a)
+int launch_pend_row(ddp_handle h, const FDArgs &a0)
 {
+    FDArgs a = a0;
     const long total = (long)a.B * a.nalpha;
+    // 16-step chunks through LDS from 3 584 rollouts on: below that the element-wise streams keep up with the 208 ns step (0.133 ms at
+    // 2 048 rollouts of N = 600 against 0.145 chunked: ~25 ticks of chunk bookkeeping per step), above it they are the bound (4 096:
+    // 0.189 -> 0.153 ms).  DDP_PEND_CHUNK=0 / 1: never / always (A/B, tests).
+    const char *pc = ddp_env(h, ENV_PEND_CHUNK);
+    a.chunked = pc ? (pc[0] != '0') : (total >= 3584);
     const dim3 grid((unsigned)((total + 3) / 4)), block(DDP_WAVE);
     const int key = (a.has_policy ? 2 : 0) | (a.has_lims ? 1 : 0);
     if (a.wrap != 0 && a.has_policy) {                          // diff_fun with wrapped coordinates (only a policy has a difference to wrap)
@@ -773,7 +850,7 @@ int ddp_launch_forward_dpp(ddp_handle h, const ddp_problem *p, const double *K, 
     a.A = p->A; a.Bm = p->Bm; a.K = K; a.k = k; a.x0 = x0; a.u = u; a.x = x; a.lims = lims; a.active = active;
     for (int i = 0; i < 16; ++i) a.alpha[i] = i < nalpha ? alpha[i] : 0.0;
     a.g = p->g; a.l = p->l; a.h = p->h; a.d = p->d;
-    a.xnew = xnew; a.unew = unew; a.sink = (double *)h->sink; a.wrap = p->diff_wrap;
+    a.xnew = xnew; a.unew = unew; a.sink = (double *)h->sink; a.wrap = p->diff_wrap; a.chunked = 0;
     // wrapped differences exist in the pendulum's own kernels only (row and lane); everything else goes to the run-time-sized kernel
     if (p->diff_wrap != 0 && (lq || !a.sink || (ddp_env(h, ENV_FORWARD_PEND) && ddp_env(h, ENV_FORWARD_PEND)[0] == '0'))) return 1;
     const char *fuse_env = ddp_env(h, ENV_FORWARD_FUSE);           // 0: keep the separate cost kernel (A/B timing, tests)
