@@ -646,31 +646,41 @@ __global__ __launch_bounds__(DDP_WAVE) void forward_pend_row_kernel(FDArgs a)
         pend_d4 *xo4 = (pend_d4 *)(a.xnew + (size_t)n * N * rho) + j;
         double *uo1 = a.unew + (size_t)N * rho + j;
         wave_sync();
+        double ldc = POLICY ? (ci + rd)[0] : 0.0;                          // K_i | x_i of the step to come: read a step ahead, across chunks too
         for (int c = 0; c < nch; ++c) {
             const int cn = c + 1 < nch ? c + 1 : c;                        // the chunk after this one (clamped: always a valid load)
             if (POLICY) { Kn = K4[16 * cn]; xn = x4[16 * cn]; kn = k1[16 * cn]; }
             un = u1[16 * cn];
             const double *cr = ci + (c & 1) * CIN + rd;
             const bool advl = c + 1 < nch || lastadv;
-            double ldc = POLICY ? cr[0] : 0.0;
             pend_static_for<0, 16>([&](auto dc) __attribute__((always_inline)) {
                 constexpr int d = decltype(dc)::value;
                 if (FUSE && (d == 0 || d == 8)) ctw = ct + j + d * TS;
                 const double ld = ldc;
-                if (POLICY && d < 15) ldc = cr[4 * (d + 1)];               // a step ahead
+                if (POLICY && d < 15) ldc = cr[4 * (d + 1)];
                 step(16 * c + d, ld, uch, kch, dc, dc, d < 15 ? true : advl, dc);
             });
-            wave_sync();                                                    // the images of this chunk are complete / no longer read
-            if (POLICY) { double *cw2 = ci + ((c + 1) & 1) * CIN; *(pend_d4 *)(cw2 + 4 * j) = Kn; *(pend_d4 *)(cw2 + 64 + 4 * j) = xn; }
-            {
-                const pend_d4 xv = *(const pend_d4 *)(co_ + 4 * j);
-                const double uv = co_[64 + 4 * j];
-                if (act) { xo4[16 * c] = xv; uo1[16 * c] = uv; }
+            // end of the chunk: one round of LDS traffic between two fences (the four rollouts of the wave are the only users of these tiles,
+            // and a wave's LDS operations stay in order) — the next input image, the result image and the cost tile of the chunk
+            wave_sync();
+            double *cw2 = ci + ((c + 1) & 1) * CIN;
+            if (POLICY) { *(pend_d4 *)(cw2 + 4 * j) = Kn; *(pend_d4 *)(cw2 + 64 + 4 * j) = xn; }
+            const pend_d4 xv = *(const pend_d4 *)(co_ + 4 * j);
+            const double uv = co_[64 + 4 * j];
+            double cs = 0.0;
+            if (FUSE) {
+#pragma unroll
+                for (int l = 0; l < n + 1; ++l) cs += ct[j * TS + l];          // (flush_cost(16 c, 16))
+            }
+            wave_sync();
+            if (POLICY) ldc = (cw2 + rd)[0];
+            if (act) { xo4[16 * c] = xv; uo1[16 * c] = uv; }
+            if (FUSE) {
+                if (act) co[16 * c + j] = cs;
+                cacc += cs;
             }
             uch = un; kch = kn;
             dpp_fence(uch, kch);
-            if (FUSE) flush_cost(16 * c, 16);                               // (its two wave_syncs also fence the images for the next chunk)
-            else wave_sync();
         }
         i0 = 16 * nch;
     }
@@ -813,8 +823,8 @@ int launch_pend_row(ddp_handle h, const FDArgs &a0)
     FDArgs a = a0;
     const long total = (long)a.B * a.nalpha;
     // 16-step chunks through LDS from 3 584 rollouts on: below that the element-wise streams keep up with the 208 ns step (0.133 ms at
-    // 2 048 rollouts of N = 600 against 0.145 chunked: ~25 ticks of chunk bookkeeping per step), above it they are the bound (4 096:
-    // 0.189 -> 0.153 ms).  DDP_PEND_CHUNK=0 / 1: never / always (A/B, tests).
+    // 2 048 rollouts of N = 600 against 0.142 chunked: ~15 ticks of chunk bookkeeping per step), above it they are the bound (4 096:
+    // 0.189 -> 0.147 ms).  DDP_PEND_CHUNK=0 / 1: never / always (A/B, tests).
     const char *pc = ddp_env(h, ENV_PEND_CHUNK);
     a.chunked = pc ? (pc[0] != '0') : (total >= 3584);
     const dim3 grid((unsigned)((total + 3) / 4)), block(DDP_WAVE);
